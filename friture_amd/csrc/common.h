@@ -1,0 +1,71 @@
+// common.h — host-side helpers shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/friture_hip.h"
+
+namespace frt {
+
+void set_last_error(const char* fmt, ...);
+
+#define FRT_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            frt::set_last_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,           \
+                                hipGetErrorString(e__));                                     \
+            return FRT_ERR_HIP;                                                         \
+        }                                                                                    \
+    } while (0)
+
+#define FRT_REQUIRE(cond, ...)                     \
+    do {                                           \
+        if (!(cond)) {                             \
+            frt::set_last_error(__VA_ARGS__);      \
+            return FRT_ERR_INVALID;           \
+        }                                          \
+    } while (0)
+
+// true when `p` points to device (or managed) memory usable by kernels directly.
+bool is_device_pointer(const void* p);
+
+// A grow-only device buffer used for staging host-pointer calls and for plan-owned scratch.
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t n) {
+        if (n <= bytes) return FRT_OK;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+        FRT_HIP_CHECK(hipMalloc(&ptr, n));
+        bytes = n;
+        return FRT_OK;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    template <typename T>
+    T* as() const { return reinterpret_cast<T*>(ptr); }
+};
+
+template <typename T>
+int upload(DeviceBuffer& buf, const std::vector<T>& host) {
+    int rc = buf.reserve(host.size() * sizeof(T));
+    if (rc) return rc;
+    FRT_HIP_CHECK(hipMemcpy(buf.ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return FRT_OK;
+}
+
+int device_cu_count();
+
+}  // namespace frt

@@ -1,0 +1,519 @@
+// stft.hip — K1: batched short-time Fourier transform -> power spectrum for gfx950.
+//
+// Reference semantics (all citations relative to the reference checkout):
+//   P[k] = |rfft(x * w)[k]|^2 / N^2, w = symmetric Hann        friture/audioproc.py:42-50,76-80
+//   frame loop with hop = int(N * (1 - overlap))                 friture/spectrum.py:144-155,
+//                                                                friture/spectrogram.py:149-159
+//   dB = 10 log10(P + 1e-30) + weight[k]                         friture/spectrogram.py:119-125
+//   norm = (dB - spec_min) / (spec_max - spec_min)               friture/spectrogram.py:128-129
+//   pixel = lut[int(clip(norm, 0, 1) * 255)]                     friture/signal/color_tranform.py:48-51,
+//                                                                friture/signal/lookup_table.py:50-52
+//
+// Kernel shape.  A frame of N real samples is an M = N/2 point complex FFT served by TPF = M/8
+// threads holding 8 points each (fft_core.h).  A "lane group" of TPF threads walks a run of
+// consecutive frames of one channel.  With hop = s*N/8 the last 8-s register slots of a frame are
+// the first 8-s slots of the next one, so each input sample is fetched from HBM once per run and
+// the only HBM traffic is 4*hop bytes in and 4*(N/2+1) bytes out per spectrum.  The samples of the
+// next frame are requested before the current frame is transformed (one frame of prefetch per
+// wave).  For N <= 1024 a frame lives inside one wavefront: pass exchanges need no barrier and the
+// conjugate-symmetric unpack is done with wavefront shuffles instead of LDS.
+#include <cmath>
+
+#include "common.h"
+#include "fft_core.h"
+
+namespace frt {
+
+struct StftArgs {
+    const void* x;         // [C][x_stride] samples
+    void* out;             // [C][F][M+1]
+    const void* window;    // [N] T
+    const void* tw;        // [M] cpx<T>: exp(-2 pi i n / M)
+    const void* twn;       // [M] cpx<T>: exp(-2 pi i k / N)
+    const void* weight;    // [M+1] T or null
+    const uint32_t* lut;   // [256] or null
+    long long x_stride;    // elements between channels
+    long long n_frames;    // frames per channel
+    long long out_cstride; // elements between channels in out
+    int hop;
+    int run;               // frames per run
+    int runs_per_channel;
+    int n_groups;          // total lane groups = C * runs_per_channel
+    int kind;              // FRT_STFT_*
+    int vec2;              // 1: 2-sample vector loads are aligned
+    double psd_scale;      // 1 / N^2
+    double norm_off;       // -spec_min
+    double norm_scale;     // 1 / (spec_max - spec_min)
+};
+
+template <typename T> __device__ __forceinline__ T db10(T p);
+template <> __device__ __forceinline__ float db10<float>(float p) {
+    // 10*log10(v) = (10/log2(10)) * log2(v); v >= 1e-30 is a normal float, v_log_f32 is exact enough
+    return 3.01029995663981195f * __log2f(p + 1e-30f);
+}
+template <> __device__ __forceinline__ double db10<double>(double p) { return 10.0 * log10(p + 1e-30); }
+
+template <typename T>
+__device__ __forceinline__ T shfl_t(T v, int lane) { return __shfl(v, lane, 64); }
+
+// TIN: sample type in HBM; T: arithmetic type; SHIFT: register slots a hop advances (0 = reload all)
+template <typename TIN, typename T, int LOG2M, int SHIFT>
+__global__ void __launch_bounds__((Pow2Plan<LOG2M>::TPF < 256 ? 256 : Pow2Plan<LOG2M>::TPF))
+stft_kernel(const StftArgs a) {
+    using P = Pow2Plan<LOG2M>;
+    constexpr int M = P::M, N = 2 * M, TPF = P::TPF;
+    constexpr int BLOCK = TPF < 256 ? 256 : TPF;
+    constexpr int GPB = BLOCK / TPF;                 // lane groups (concurrent frames) per block
+    constexpr bool WAVE = TPF <= 64;                 // a frame lives inside one wavefront
+    using C = cpx<T>;
+    using CIN = cpx<TIN>;
+
+    __shared__ C lds[GPB * lds_padded_size(M)];
+
+    const int tid = threadIdx.x;
+    const int grp = tid / TPF;
+    const int i = tid - grp * TPF;
+    C* buf = lds + grp * lds_padded_size(M);
+
+    const int gg = blockIdx.x * GPB + grp;
+    const bool group_ok = gg < a.n_groups;
+    const int ggc = group_ok ? gg : 0;
+    const int chan = ggc / a.runs_per_channel;
+    const int run = ggc - chan * a.runs_per_channel;
+    const long long f0 = (long long)run * a.run;
+    long long nfr = a.n_frames - f0;
+    if (nfr > a.run) nfr = a.run;
+    if (!group_ok) nfr = 0;
+
+    const TIN* xc = (const TIN*)a.x + chan * a.x_stride;
+    T* outc = (T*)a.out + chan * a.out_cstride;
+
+    // ---- per-thread constants ----------------------------------------------------------------
+    // One-wave frames (N <= 1024) keep window, twiddles and weights in registers for the whole
+    // run; many-wave frames re-read them from the (L2 resident) tables at every use because the
+    // workgroup size caps their register budget (1024 threads -> 128 VGPRs).
+    constexpr bool HOIST = WAVE;
+    constexpr int NC = HOIST ? 8 : 1;
+    C win[NC], twu[NC];
+    T wdb[NC], wdb_last = 0;
+    const T* wtab = (const T*)a.window;
+    const C* twn = (const C*)a.twn;
+    const T* wgt = (const T*)a.weight;
+    TwRegs<T, LOG2M> twr;
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = i + j * TPF;
+            win[j] = {wtab[2 * n], wtab[2 * n + 1]};
+            twu[j] = twn[n];
+            wdb[j] = wgt ? wgt[n] : (T)0;
+        }
+        twr.load((const C*)a.tw, i);
+    }
+    if (wgt) wdb_last = wgt[M];
+
+    const T psd_scale = (T)(0.25 * a.psd_scale);
+    const T norm_off = (T)a.norm_off, norm_scale = (T)a.norm_scale;
+
+    auto load_slot = [&](long long f, int j) -> C {
+        const long long s = f * a.hop + 2 * (i + j * TPF);
+        if (a.vec2) {
+            CIN v = *(const CIN*)(xc + s);
+            return {(T)v.x, (T)v.y};
+        }
+        return {(T)xc[s], (T)xc[s + 1]};
+    };
+
+    constexpr int NEW = SHIFT == 0 ? 8 : SHIFT;       // slots fetched per frame
+    C raw[8], nxt[NEW];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) raw[j] = {(T)0, (T)0};
+    if (nfr > 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[j] = load_slot(f0, j);
+    }
+
+    const int nloop = a.run;                          // uniform trip count keeps barriers aligned
+    for (int g = 0; g < nloop; ++g) {
+        const bool valid = g < nfr;
+        if (!WAVE) {
+            if (!__syncthreads_or(valid)) break;      // whole block finished
+        } else if (!__any(valid)) {
+            break;
+        }
+        // prefetch the new slots of the next frame
+        if (g + 1 < nfr) {
+#pragma unroll
+            for (int t = 0; t < NEW; ++t) nxt[t] = load_slot(f0 + g + 1, 8 - NEW + t);
+        }
+
+        int zero = 0;
+        if constexpr (!HOIST) asm volatile("s_mov_b32 %0, 0" : "=s"(zero));   // opaque per iteration
+
+        C v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            C wj;
+            if constexpr (HOIST) {
+                wj = win[j];
+            } else {
+                wj = ((const C*)wtab)[i + j * TPF + zero];
+            }
+            v[j] = {raw[j].x * wj.x, raw[j].y * wj.y};
+        }
+
+        if constexpr (HOIST) {
+            fft_pow2_forward<T, LOG2M, WAVE>(v, buf, i, twr);
+        } else {
+            TwTable<T, LOG2M> twt{(const C*)a.tw, zero};
+            fft_pow2_forward<T, LOG2M, WAVE>(v, buf, i, twt);
+        }
+
+        // ---- conjugate-symmetric unpack: X[k] = ((A+B) - i w^k (A-B))/2, A = Z[k], B = conj Z[M-k]
+        C part[8];
+        if constexpr (WAVE) {
+            const int lane = tid & 63;
+            const int src = lane - i + ((TPF - i) & (TPF - 1));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                C o = v[7 - j];
+                C p = {shfl_t(o.x, src), shfl_t(o.y, src)};
+                C own = v[(8 - j) & 7];
+                part[j] = (i == 0) ? own : p;
+            }
+        } else {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) buf[lds_pad(i + j * TPF)] = v[j];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[j] = buf[lds_pad((M - (i + j * TPF)) & (M - 1))];
+        }
+
+        T res[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            C A = v[j], B = cconj(part[j]);
+            C S = A + B, D = A - B;
+            C tu;
+            if constexpr (HOIST) {
+                tu = twu[j];
+            } else {
+                tu = twn[i + j * TPF + zero];
+            }
+            C t = cmul(tu, D);
+            T xr = S.x + t.y, xi = S.y - t.x;
+            res[j] = (xr * xr + xi * xi) * psd_scale;
+        }
+        T d0 = v[0].x - v[0].y;
+        T res_last = d0 * d0 * (T)a.psd_scale;
+
+        if (valid) {
+            T* row = outc + (f0 + g) * (M + 1);
+            if (a.kind == FRT_STFT_PSD) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) row[i + j * TPF] = res[j];
+                if (i == 0) row[M] = res_last;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    T wj;
+                    if constexpr (HOIST) {
+                        wj = wdb[j];
+                    } else {
+                        wj = wgt ? wgt[i + j * TPF + zero] : (T)0;
+                    }
+                    res[j] = db10<T>(res[j]) + wj;
+                }
+                res_last = db10<T>(res_last) + wdb_last;
+                if (a.kind == FRT_STFT_DB) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) row[i + j * TPF] = res[j];
+                    if (i == 0) row[M] = res_last;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) res[j] = (res[j] + norm_off) * norm_scale;
+                    res_last = (res_last + norm_off) * norm_scale;
+                    if (a.kind == FRT_STFT_NORM) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) row[i + j * TPF] = res[j];
+                        if (i == 0) row[M] = res_last;
+                    } else {
+                        // colour words are 4 bytes whatever the arithmetic type
+                        uint32_t* prow = (uint32_t*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
+                        auto pix = [&](T vv) -> uint32_t {
+                            vv = fmin(fmax(vv, (T)0), (T)1);   // NaN -> 0
+                            return a.lut[(int)(vv * (T)255)];
+                        };
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) prow[i + j * TPF] = pix(res[j]);
+                        if (i == 0) prow[M] = pix(res_last);
+                    }
+                }
+            }
+        }
+
+        // advance the register window by one hop
+        if (g + 1 < nfr) {
+#pragma unroll
+            for (int j = 0; j < 8 - NEW; ++j) raw[j] = raw[j + NEW];
+#pragma unroll
+            for (int t = 0; t < NEW; ++t) raw[8 - NEW + t] = nxt[t];
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+
+template <typename TIN, typename T, int LOG2M, int SHIFT>
+static int launch_one(const StftArgs& a, int blocks, hipStream_t stream) {
+    using P = Pow2Plan<LOG2M>;
+    constexpr int BLOCK = P::TPF < 256 ? 256 : P::TPF;
+    hipLaunchKernelGGL((stft_kernel<TIN, T, LOG2M, SHIFT>), dim3(blocks), dim3(BLOCK), 0, stream, a);
+    FRT_HIP_CHECK(hipGetLastError());
+    return FRT_OK;
+}
+
+template <typename TIN, typename T, int LOG2M>
+static int launch_shift(const StftArgs& a, int shift, int blocks, hipStream_t stream) {
+    if constexpr (sizeof(T) == 4) {
+        if (shift == 2) return launch_one<TIN, T, LOG2M, 2>(a, blocks, stream);
+        if (shift == 4) return launch_one<TIN, T, LOG2M, 4>(a, blocks, stream);
+    }
+    return launch_one<TIN, T, LOG2M, 0>(a, blocks, stream);
+}
+
+template <typename TIN, typename T>
+static int launch_size(int log2m, const StftArgs& a, int shift, int blocks, hipStream_t stream) {
+    switch (log2m) {
+        case 4: return launch_shift<TIN, T, 4>(a, shift, blocks, stream);
+        case 5: return launch_shift<TIN, T, 5>(a, shift, blocks, stream);
+        case 6: return launch_shift<TIN, T, 6>(a, shift, blocks, stream);
+        case 7: return launch_shift<TIN, T, 7>(a, shift, blocks, stream);
+        case 8: return launch_shift<TIN, T, 8>(a, shift, blocks, stream);
+        case 9: return launch_shift<TIN, T, 9>(a, shift, blocks, stream);
+        case 10: return launch_shift<TIN, T, 10>(a, shift, blocks, stream);
+        case 11: return launch_shift<TIN, T, 11>(a, shift, blocks, stream);
+        case 12: return launch_shift<TIN, T, 12>(a, shift, blocks, stream);
+        case 13: return launch_shift<TIN, T, 13>(a, shift, blocks, stream);
+    }
+    set_last_error("unsupported fft size 2^%d", log2m + 1);
+    return FRT_ERR_UNSUPPORTED;
+}
+
+}  // namespace frt
+
+using namespace frt;
+
+struct frt_stft {
+    int fft_size = 0, hop = 0, n_channels = 0, precision = 32, log2m = 0;
+    int run_length = 0;
+    hipStream_t stream = nullptr;
+    DeviceBuffer window, tw, twn, weight, lut;
+    bool has_weight = false, has_lut = false;
+    double spec_min = -140.0, spec_max = 0.0;
+    DeviceBuffer stage_in, stage_out;
+};
+
+template <typename T>
+static int build_tables(frt_stft* h) {
+    const int N = h->fft_size, M = N / 2;
+    const double pi = 3.14159265358979323846;
+    std::vector<T> win(N);
+    // symmetric Hann, audioproc.py:76-80: 0.5 * (1 - cos(2 pi n / (N - 1)))
+    for (int n = 0; n < N; ++n) win[n] = (T)(0.5 * (1.0 - std::cos(2.0 * pi * n / (N - 1))));
+    std::vector<T> tw(2 * M), twn(2 * M);
+    for (int n = 0; n < M; ++n) {
+        tw[2 * n] = (T)std::cos(2.0 * pi * n / M);
+        tw[2 * n + 1] = (T)(-std::sin(2.0 * pi * n / M));
+        twn[2 * n] = (T)std::cos(2.0 * pi * n / N);
+        twn[2 * n + 1] = (T)(-std::sin(2.0 * pi * n / N));
+    }
+    int rc;
+    if ((rc = upload(h->window, win))) return rc;
+    if ((rc = upload(h->tw, tw))) return rc;
+    if ((rc = upload(h->twn, twn))) return rc;
+    return FRT_OK;
+}
+
+extern "C" int frt_stft_create(frt_stft** out, int fft_size, int hop, int n_channels, int precision) {
+    FRT_REQUIRE(out != nullptr, "frt_stft_create: null handle pointer");
+    *out = nullptr;
+    FRT_REQUIRE(fft_size >= 32 && fft_size <= 16384 && (fft_size & (fft_size - 1)) == 0,
+                "frt_stft_create: fft_size %d is not a power of two in [32, 16384]", fft_size);
+    FRT_REQUIRE(hop >= 1, "frt_stft_create: hop %d < 1", hop);
+    FRT_REQUIRE(n_channels >= 1, "frt_stft_create: n_channels %d < 1", n_channels);
+    FRT_REQUIRE(precision == 32 || precision == 64, "frt_stft_create: precision must be 32 or 64");
+    frt_stft* h = new frt_stft();
+    h->fft_size = fft_size;
+    h->hop = hop;
+    h->n_channels = n_channels;
+    h->precision = precision;
+    int l = 0;
+    while ((2 << l) < fft_size) ++l;   // M = 2^l
+    h->log2m = l;
+    int rc = precision == 32 ? build_tables<float>(h) : build_tables<double>(h);
+    if (rc) {
+        frt_stft_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return FRT_OK;
+}
+
+extern "C" void frt_stft_destroy(frt_stft* h) {
+    if (!h) return;
+    h->window.release();
+    h->tw.release();
+    h->twn.release();
+    h->weight.release();
+    h->lut.release();
+    h->stage_in.release();
+    h->stage_out.release();
+    delete h;
+}
+
+extern "C" int frt_stft_set_stream(frt_stft* h, void* s) {
+    FRT_REQUIRE(h, "frt_stft_set_stream: null handle");
+    h->stream = (hipStream_t)s;
+    return FRT_OK;
+}
+
+extern "C" int frt_stft_set_run_length(frt_stft* h, int r) {
+    FRT_REQUIRE(h && r >= 0, "frt_stft_set_run_length: bad argument");
+    h->run_length = r;
+    return FRT_OK;
+}
+
+extern "C" int frt_stft_set_epilogue(frt_stft* h, const double* weight_db, double spec_min, double spec_max,
+                                     const uint32_t* lut256) {
+    FRT_REQUIRE(h, "frt_stft_set_epilogue: null handle");
+    FRT_REQUIRE(spec_max != spec_min, "frt_stft_set_epilogue: empty dB range");
+    const int nb = h->fft_size / 2 + 1;
+    int rc;
+    h->has_weight = weight_db != nullptr;
+    if (weight_db) {
+        if (h->precision == 32) {
+            std::vector<float> w(nb);
+            for (int k = 0; k < nb; ++k) w[k] = (float)weight_db[k];
+            if ((rc = upload(h->weight, w))) return rc;
+        } else {
+            std::vector<double> w(weight_db, weight_db + nb);
+            if ((rc = upload(h->weight, w))) return rc;
+        }
+    }
+    h->has_lut = lut256 != nullptr;
+    if (lut256) {
+        std::vector<uint32_t> l(lut256, lut256 + 256);
+        if ((rc = upload(h->lut, l))) return rc;
+    }
+    h->spec_min = spec_min;
+    h->spec_max = spec_max;
+    return FRT_OK;
+}
+
+extern "C" int64_t frt_stft_frames_for(const frt_stft* h, int64_t T) {
+    if (!h || T < h->fft_size) return 0;
+    return (T - h->fft_size) / h->hop + 1;
+}
+
+static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride, void* d_out, int64_t F,
+                       hipStream_t stream) {
+    const int N = h->fft_size, M = N / 2;
+    StftArgs a{};
+    a.x = d_x;
+    a.out = d_out;
+    a.window = h->window.ptr;
+    a.tw = h->tw.ptr;
+    a.twn = h->twn.ptr;
+    a.weight = h->has_weight ? h->weight.ptr : nullptr;
+    a.lut = h->has_lut ? h->lut.as<uint32_t>() : nullptr;
+    a.x_stride = x_stride;
+    a.n_frames = F;
+    a.out_cstride = F * (M + 1);
+    a.hop = h->hop;
+    a.kind = kind;
+    const size_t esz = h->precision == 32 ? 4 : 8;
+    a.vec2 = (h->hop % 2 == 0) && (x_stride % 2 == 0) && (((uintptr_t)d_x) % (2 * esz) == 0);
+    a.psd_scale = 1.0 / ((double)N * (double)N);
+    a.norm_off = -h->spec_min;
+    a.norm_scale = 1.0 / (h->spec_max - h->spec_min);
+
+    // slots of 2*TPF samples a hop advances; the register-shift kernels need hop = s*N/8, s in {2,4}
+    int shift = 0;
+    if (a.vec2 && h->hop * 8 % N == 0) {
+        const int s = h->hop * 8 / N;
+        if (s == 2 || s == 4) shift = s;
+    }
+    const int tpf = M / 8;
+    const int gpb = tpf < 256 ? 256 / tpf : 1;
+    // run length: enough lane groups to fill the chip several times over, long enough to amortise
+    // the one-off loads of a run (window, twiddles, first frame)
+    int run = h->run_length;
+    if (run <= 0) {
+        const long long total = (long long)F * h->n_channels;
+        const long long want_groups = (long long)device_cu_count() * 8 * gpb;
+        run = (int)((total + want_groups - 1) / want_groups);
+        if (run < 8) run = 8;
+        if (run > 64) run = 64;
+    }
+    if (run > F) run = (int)F;
+    a.run = run;
+    a.runs_per_channel = (int)((F + run - 1) / run);
+    const long long groups = (long long)a.runs_per_channel * h->n_channels;
+    FRT_REQUIRE(groups < (1ll << 31), "frt_stft_run: too many lane groups");
+    a.n_groups = (int)groups;
+    const int blocks = (int)((groups + gpb - 1) / gpb);
+    if (h->precision == 32) return launch_size<float, float>(h->log2m, a, shift, blocks, stream);
+    return launch_size<double, double>(h->log2m, a, shift, blocks, stream);
+}
+
+extern "C" int frt_stft_run(frt_stft* h, int kind, const void* x, int64_t T, int64_t x_stride, void* out,
+                            int64_t* n_frames_out) {
+    FRT_REQUIRE(h, "frt_stft_run: null handle");
+    FRT_REQUIRE(kind >= FRT_STFT_PSD && kind <= FRT_STFT_IMAGE, "frt_stft_run: unknown output kind %d", kind);
+    FRT_REQUIRE(kind != FRT_STFT_IMAGE || h->has_lut, "frt_stft_run: IMAGE output needs a colour LUT");
+    FRT_REQUIRE(T >= 0 && x_stride >= T, "frt_stft_run: bad T/x_stride");
+    const int64_t F = frt_stft_frames_for(h, T);
+    if (n_frames_out) *n_frames_out = F;
+    if (F == 0) return FRT_OK;
+    FRT_REQUIRE(x && out, "frt_stft_run: null buffer");
+    const bool dx = is_device_pointer(x), dout = is_device_pointer(out);
+    FRT_REQUIRE(dx == dout, "frt_stft_run: input and output must both be host or both be device memory");
+    const int nb = h->fft_size / 2 + 1;
+    const size_t in_esz = h->precision == 32 ? 4 : 8;
+    const size_t out_esz = (kind == FRT_STFT_IMAGE) ? 4 : in_esz;
+    if (dx) return stft_launch(h, kind, x, x_stride, out, F, h->stream);
+
+    // host buffers: stage through device memory, return when the result is back
+    const size_t in_bytes = (size_t)h->n_channels * x_stride * in_esz;
+    const size_t out_bytes = (size_t)h->n_channels * F * nb * out_esz;
+    int rc;
+    if ((rc = h->stage_in.reserve(in_bytes))) return rc;
+    if ((rc = h->stage_out.reserve(out_bytes))) return rc;
+    FRT_HIP_CHECK(hipMemcpyAsync(h->stage_in.ptr, x, in_bytes, hipMemcpyHostToDevice, h->stream));
+    if ((rc = stft_launch(h, kind, h->stage_in.ptr, x_stride, h->stage_out.ptr, F, h->stream))) return rc;
+    FRT_HIP_CHECK(hipMemcpyAsync(out, h->stage_out.ptr, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return FRT_OK;
+}
+
+extern "C" int frt_stft_psd(frt_stft* h, const float* x, int64_t T, float* psd_out, int64_t* n_frames_out) {
+    FRT_REQUIRE(h && h->precision == 32, "frt_stft_psd: needs a precision-32 handle");
+    return frt_stft_run(h, FRT_STFT_PSD, x, T, T, psd_out, n_frames_out);
+}
+
+extern "C" int frt_stft_image(frt_stft* h, const float* x, int64_t T, uint32_t* rgba_out, int64_t* n_frames_out) {
+    FRT_REQUIRE(h && h->precision == 32, "frt_stft_image: needs a precision-32 handle");
+    return frt_stft_run(h, FRT_STFT_IMAGE, x, T, T, rgba_out, n_frames_out);
+}
+
+extern "C" int frt_stft_analyzelive_f64(frt_stft* h, const double* frame, double* psd_out) {
+    FRT_REQUIRE(h && h->precision == 64, "frt_stft_analyzelive_f64: needs a precision-64 handle");
+    FRT_REQUIRE(h->n_channels == 1, "frt_stft_analyzelive_f64: handle must have one channel");
+    int64_t F = 0;
+    int rc = frt_stft_run(h, FRT_STFT_PSD, frame, h->fft_size, h->fft_size, psd_out, &F);
+    if (rc) return rc;
+    FRT_REQUIRE(F == 1, "frt_stft_analyzelive_f64: internal frame count %lld", (long long)F);
+    return FRT_OK;
+}

@@ -1,0 +1,94 @@
+/* friture_hip.h — C ABI of libfriture_hip.so, the MI355X (gfx950) backend for Friture's
+ * spectral-analysis hot path.
+ *
+ * The reference (tlecomte/friture) has no FFI: its boundary is a set of duck-typed Python
+ * classes and functions.  Every entry point below names the reference interface
+ * it replaces (paths relative to the reference checkout); the ctypes bindings that present the
+ * reference's own names on top of this ABI live in friture_amd/ and are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative status on failure, never throws;
+ *     frt_last_error() returns a thread-local description of the last failure;
+ *   - handles are opaque and own all device memory; one handle per Python object, used from
+ *     one thread at a time (the reference calls everything from the Qt GUI thread);
+ *   - buffers are caller owned.  A buffer argument may be a host pointer (staged through an
+ *     internal device buffer, call returns after the result is back on the host) or a device
+ *     pointer (kernels are enqueued on the handle's stream and the call returns immediately);
+ *     inputs and outputs of one call must live on the same side;
+ *   - audio is channel-major: x[c][t].
+ */
+#ifndef FRITURE_HIP_H
+#define FRITURE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes */
+#define FRT_OK 0
+#define FRT_ERR_INVALID (-1)
+#define FRT_ERR_HIP (-2)
+#define FRT_ERR_NO_DEVICE (-3)
+#define FRT_ERR_UNSUPPORTED (-4)
+#define FRT_ERR_TOO_SMALL (-5)
+
+/* ---- library ---------------------------------------------------------------------------- */
+
+/* Binds the calling process to HIP device `device` (one process per GPU) and verifies that it is
+ * a gfx950 part.  n_cus_out / hbm_bytes_out may be NULL. */
+int frt_init(int device, int* n_cus_out, int64_t* hbm_bytes_out);
+const char* frt_last_error(void);
+const char* frt_version(void);
+/* 1 if `p` is device memory, 0 if host memory. */
+int frt_is_device_pointer(const void* p);
+
+/* ---- K1: STFT -> power spectrum ( -> dB / normalised / colour pixels) -------------------------
+ * Replaces audioproc.analyzelive + norm_square (friture/audioproc.py:42-50) looped by the STFT
+ * drivers Spectrum_Widget.handle_new_data (friture/spectrum.py:144-155) and
+ * Spectrogram_Widget.handle_new_data (friture/spectrogram.py:149-159), and the dB / weighting /
+ * normalise / colour-LUT steps that follow (friture/spectrogram.py:119-129,161-162,
+ * friture/signal/color_tranform.py:48-51, friture/signal/lookup_table.py:50-52).
+ *
+ * Frame f of channel c covers x[c][f*hop .. f*hop + fft_size); n_frames = (T - fft_size)/hop + 1.
+ * Outputs are frame-major: out[c][f][k], k = 0..fft_size/2 (the reference's (N/2+1, frames)
+ * array is the transpose of one channel's slab). */
+typedef struct frt_stft frt_stft;
+
+/* output kinds for frt_stft_run */
+#define FRT_STFT_PSD 0   /* float: |rfft(x*w)|^2 / N^2                      audioproc.py:44-50  */
+#define FRT_STFT_DB 1    /* float: 10 log10(psd + 1e-30) + weight[k]        spectrum.py:95-101  */
+#define FRT_STFT_NORM 2  /* float: (dB - spec_min)/(spec_max - spec_min)    spectrogram.py:128  */
+#define FRT_STFT_IMAGE 3 /* uint32: lut[int(clip(norm,0,1)*255)]            lookup_table.py:50  */
+
+/* fft_size: power of two in [32, 16384] (spectrum_settings.py:61-70); hop in [1, ...);
+ * precision: 32 (float in, float arithmetic) or 64 (double in, double arithmetic, double out). */
+int frt_stft_create(frt_stft** h, int fft_size, int hop, int n_channels, int precision);
+void frt_stft_destroy(frt_stft* h);
+/* hipStream_t used for device-pointer calls (NULL = default stream). */
+int frt_stft_set_stream(frt_stft* h, void* hip_stream);
+/* weight_db: fft_size/2+1 values added to the dB spectrum or NULL (no weighting);
+ * lut256: 256 colour words or NULL. */
+int frt_stft_set_epilogue(frt_stft* h, const double* weight_db, double spec_min, double spec_max,
+                          const uint32_t* lut256);
+/* x: [n_channels][x_stride] samples (float for precision 32, double for 64), T valid per channel.
+ * out: [n_channels][n_frames][fft_size/2+1] elements of the output kind (4 bytes each at
+ * precision 32; at precision 64 PSD/DB/NORM are doubles and IMAGE stays uint32). */
+int frt_stft_run(frt_stft* h, int kind, const void* x, int64_t T, int64_t x_stride, void* out,
+                 int64_t* n_frames_out);
+/* survey-named conveniences (precision-32 handles): */
+int frt_stft_psd(frt_stft* h, const float* x, int64_t T, float* psd_out, int64_t* n_frames_out);
+int frt_stft_image(frt_stft* h, const float* x, int64_t T, uint32_t* rgba_out, int64_t* n_frames_out);
+/* Exact drop-in for audioproc.analyzelive (audioproc.py:42-47): one double frame of fft_size
+ * samples -> fft_size/2+1 doubles.  Requires a precision-64 handle. */
+int frt_stft_analyzelive_f64(frt_stft* h, const double* frame, double* psd_out);
+/* Number of frames frt_stft_run produces for T samples per channel. */
+int64_t frt_stft_frames_for(const frt_stft* h, int64_t T);
+/* Tuning hook (bench / tests): frames a workgroup lane-group processes back to back; 0 = auto. */
+int frt_stft_set_run_length(frt_stft* h, int frames_per_run);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRITURE_HIP_H */
