@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): the rolling
+spectrogram of one 48 kHz channel per GPU — 1024-point Hann STFT at 50 % overlap, dB,
+A-weighting, normalisation to [-140, 0] dB and the colour look-up — over T = 2^26 synthetic
+samples resident in HBM (131 071 spectra per channel per step).  A step is one pass of the hot
+path over that batch.  With N GPUs every rank owns its own channel(s) (weak scaling, no data-path
+collective); `value` is the whole-job spectra/s: total spectra of all ranks / max-over-ranks time.
+
+One JSON line is printed by rank 0; besides the contract fields it carries
+  roofline      HBM roofline of the dominant kernel (stft_kernel): algorithmic bytes per launch
+                (4*hop + 4*(N/2+1) = 4100 B per spectrum) / average launch duration measured with
+                HIP events on the launch stream, against the 8 TB/s peak
+  cpu_baseline  the oracle (numpy restatement of the reference path, 1 core) timed on a bounded
+                sample of the same input on this box's host
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def synth_channel(channel: int, n: int) -> np.ndarray:
+    """S-noise of SURVEY.md §8d: 0.25 * standard_normal, seed 42 + channel, float32 PCM."""
+    return (0.25 * np.random.default_rng(42 + channel).standard_normal(n, dtype=np.float32)).astype(np.float32)
+
+
+def cpu_baseline(x: np.ndarray, n_fft: int, hop: int, weight, lut, budget_s: float):
+    """Oracle timed on one host core over a bounded prefix of the same channel."""
+    from oracle import dsp
+    frames_total = (len(x) - n_fft) // hop + 1
+    probe = 2048
+    t0 = time.perf_counter()
+    dsp.spectrogram_image(x[: n_fft + hop * (probe - 1)].astype(np.float64), n_fft, hop, weight, -140.0, 0.0, lut)
+    per = (time.perf_counter() - t0) / probe
+    frames = int(min(frames_total, max(probe, budget_s / per)))
+    xs = x[: n_fft + hop * (frames - 1)].astype(np.float64)
+    t0 = time.perf_counter()
+    dsp.spectrogram_image(xs, n_fft, hop, weight, -140.0, 0.0, lut)
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "spectra/s", "cores": 1, "kind": "port",
+            "sample": f"first {frames} of {frames_total} spectra of channel 0 (same input), numpy float64 "
+                      f"oracle of audioproc.analyzelive + dB + A-weighting + colour LUT, {dt:.1f} s",
+            "host_cpus": os.cpu_count()}
+
+
+def pmc_traffic(n_fft: int, hop: int, frames: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary of this command, if any."""
+    p = ROOT / "profiles" / "pmc_traffic.json"
+    if not p.exists():
+        return None
+    try:
+        rec = json.loads(p.read_text())
+        if rec.get("n_fft") == n_fft and rec.get("hop") == hop and rec.get("frames") == frames:
+            return rec.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--fft-size", type=int, default=1024)
+    ap.add_argument("--hop", type=int, default=0, help="default fft_size/2 (50 %% overlap)")
+    ap.add_argument("--log2-samples", type=int, default=26)
+    ap.add_argument("--channels-per-gpu", type=int, default=1)
+    ap.add_argument("--kind", choices=["image", "psd", "db"], default="image")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+
+    from friture_amd import _lib, distributed, palette, tables
+    from friture_amd.stft import StftEngine
+
+    rank, local_rank, world = distributed.init_process_group()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP backend has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    _lib.init(local_rank)
+
+    n_fft = args.fft_size
+    hop = args.hop or n_fft // 2
+    T = 1 << args.log2_samples
+    cpg = args.channels_per_gpu
+    n_channels = cpg * world
+    my_channels = distributed.shard_channels(n_channels, rank, world)
+
+    # constant tables: computed on rank 0, broadcast over RCCL so every rank uses identical bits
+    consts = {"weight": np.zeros(n_fft // 2 + 1), "lut": np.zeros(256, np.uint32)}
+    if rank == 0:
+        consts["weight"] = tables.weighting_db(tables.rfft_frequencies(n_fft), 1e-50)[0]
+        consts["lut"] = palette.cmr_lut()
+    consts = distributed.broadcast_tables(consts, src=0, device=dev)
+
+    host_x = [synth_channel(c, T) for c in my_channels]
+    x = torch.from_numpy(np.stack(host_x)).to(dev)
+    eng = StftEngine(n_fft, hop, len(my_channels), 32)
+    eng.set_epilogue(consts["weight"], -140.0, 0.0, consts["lut"])
+    kind = {"image": 3, "psd": 0, "db": 1}[args.kind]
+    F = eng.frames_for(T)
+    out = torch.empty((len(my_channels), F, n_fft // 2 + 1), dtype=torch.int32 if kind == 3 else torch.float32, device=dev)
+
+    for _ in range(args.warmup):
+        eng.run(kind, x, out)
+    torch.cuda.synchronize()
+    distributed.barrier(dev)
+    torch.cuda.synchronize()
+
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        starts[k].record()
+        eng.run(kind, x, out)                 # one kernel launch on torch's current stream
+        stops[k].record()
+    torch.cuda.synchronize()
+    distributed.barrier(dev)
+    torch.cuda.synchronize()
+    elapsed = distributed.max_over_ranks(time.perf_counter() - t0, dev)
+
+    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, stops)]))
+    kernel_ms_max = distributed.max_over_ranks(kernel_ms, dev)
+
+    # post-batch summary gather (outside the timed region): per-channel mean pixel/PSD digest
+    digest = out.to(torch.float64).mean(dim=(1, 2)).reshape(-1, 1)
+    digest_all = distributed.gather_channel_summaries(digest, n_channels)
+
+    if rank == 0:
+        spectra_per_step = n_channels * F
+        value = spectra_per_step * args.steps / elapsed
+        bytes_per_spectrum = 4 * hop + 4 * (n_fft // 2 + 1)
+        bytes_per_launch = len(my_channels) * F * bytes_per_spectrum
+        achieved = bytes_per_launch / (kernel_ms_max * 1e-3) / 1e9
+        result = {
+            "metric": "spectra/sec (1024-pt STFT)" if n_fft == 1024 else f"spectra/sec ({n_fft}-pt STFT)",
+            "value": value,
+            "unit": "spectra/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"rolling spectrogram: {n_fft}-pt Hann STFT, hop {hop}, "
+                                   f"{'dB + A-weighting + colour LUT -> u32 pixels' if kind == 3 else args.kind}, "
+                                   f"{cpg} ch/GPU x 2^{args.log2_samples} samples @ 48 kHz "
+                                   f"(BASELINE configs[1])",
+                       "channels": n_channels, "spectra_per_step": spectra_per_step,
+                       "parallelism": f"channel-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "stft_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(n_fft, hop, F),
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "kernel_ms": kernel_ms_max},
+            "digest": float(digest_all.sum().item()),
+        }
+        if world == 1 and args.cpu_budget > 0:
+            result["cpu_baseline"] = cpu_baseline(host_x[0], n_fft, hop, consts["weight"], consts["lut"], args.cpu_budget)
+        print(json.dumps(result), flush=True)
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

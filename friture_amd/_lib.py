@@ -1,0 +1,98 @@
+"""ctypes binding of libfriture_hip.so (include/friture_hip.h).
+
+The library is built in-tree by `python -m friture_amd.build`.  Loading fails loudly when it is
+missing; there is no fallback implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import sys
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint32, c_void_p
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libfriture_hip.so"
+
+FRT_STFT_PSD, FRT_STFT_DB, FRT_STFT_NORM, FRT_STFT_IMAGE = 0, 1, 2, 3
+
+
+class FritureHipError(RuntimeError):
+    """A C-ABI call returned a negative status (the message is frt_last_error())."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libfriture_hip status {status}: {message}")
+        self.status = status
+
+
+# name -> (restype, argtypes); kept in one table so that tests can check the export list
+SIGNATURES = {
+    "frt_init": (c_int, [c_int, POINTER(c_int), POINTER(c_int64)]),
+    "frt_last_error": (c_char_p, []),
+    "frt_version": (c_char_p, []),
+    "frt_is_device_pointer": (c_int, [c_void_p]),
+    "frt_stft_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int]),
+    "frt_stft_destroy": (None, [c_void_p]),
+    "frt_stft_set_stream": (c_int, [c_void_p, c_void_p]),
+    "frt_stft_set_epilogue": (c_int, [c_void_p, POINTER(c_double), c_double, c_double, POINTER(c_uint32)]),
+    "frt_stft_run": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_void_p, POINTER(c_int64)]),
+    "frt_stft_psd": (c_int, [c_void_p, POINTER(c_float), c_int64, POINTER(c_float), POINTER(c_int64)]),
+    "frt_stft_image": (c_int, [c_void_p, POINTER(c_float), c_int64, POINTER(c_uint32), POINTER(c_int64)]),
+    "frt_stft_analyzelive_f64": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double)]),
+    "frt_stft_frames_for": (c_int64, [c_void_p, c_int64]),
+    "frt_stft_set_run_length": (c_int, [c_void_p, c_int]),
+}
+
+_lib = None
+_initialised = False
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the library (no GPU needed) and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m friture_amd.build` "
+                          "(friture_amd has no CPU fallback)")
+    # If torch is (going to be) used in this process its bundled HIP runtime must be the one the
+    # library binds to, otherwise device pointers would belong to a different runtime instance.
+    if "torch" not in sys.modules and os.environ.get("FRITURE_AMD_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise FritureHipError(status, load().frt_last_error().decode(errors="replace"))
+
+
+def init(device: int | None = None) -> ctypes.CDLL:
+    """Load the library and bind the process to one gfx950 device (LOCAL_RANK by default)."""
+    global _initialised
+    lib = load()
+    if not _initialised:
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+            if "torch" in sys.modules:
+                import torch
+                if torch.cuda.is_available():
+                    device = torch.cuda.current_device()
+        check(lib.frt_init(device, None, None))
+        _initialised = True
+    return lib
+
+
+def device_info(device: int = 0) -> tuple[int, int]:
+    lib = load()
+    ncu, hbm = c_int(0), c_int64(0)
+    check(lib.frt_init(device, ctypes.byref(ncu), ctypes.byref(hbm)))
+    return ncu.value, hbm.value

@@ -69,6 +69,7 @@ stft_kernel(const StftArgs a) {
     using CIN = cpx<TIN>;
 
     __shared__ C lds[GPB * lds_padded_size(M)];
+    __shared__ uint32_t lut_lds[256];                // colour words: gathered per bin, keep them on-chip
 
     const int tid = threadIdx.x;
     const int grp = tid / TPF;
@@ -84,6 +85,11 @@ stft_kernel(const StftArgs a) {
     long long nfr = a.n_frames - f0;
     if (nfr > a.run) nfr = a.run;
     if (!group_ok) nfr = 0;
+
+    if (a.kind == FRT_STFT_IMAGE) {
+        for (int t = threadIdx.x; t < 256; t += BLOCK) lut_lds[t] = a.lut[t];
+        __syncthreads();
+    }
 
     const TIN* xc = (const TIN*)a.x + chan * a.x_stride;
     T* outc = (T*)a.out + chan * a.out_cstride;
@@ -243,7 +249,7 @@ stft_kernel(const StftArgs a) {
                         uint32_t* prow = (uint32_t*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
                         auto pix = [&](T vv) -> uint32_t {
                             vv = fmin(fmax(vv, (T)0), (T)1);   // NaN -> 0
-                            return a.lut[(int)(vv * (T)255)];
+                            return lut_lds[(int)(vv * (T)255)];
                         };
 #pragma unroll
                         for (int j = 0; j < 8; ++j) prow[i + j * TPF] = pix(res[j]);

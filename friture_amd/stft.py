@@ -1,0 +1,125 @@
+"""Batched STFT engine: host-side driver of kernel K1 (frt_stft_* in include/friture_hip.h).
+
+Mirrors what the reference's STFT drivers do one frame at a time — Spectrum_Widget.handle_new_data
+(friture/spectrum.py:125-184) and Spectrogram_Widget.handle_new_data
+(friture/spectrogram.py:131-177): frame extraction at hop = int(N (1 - overlap)),
+audioproc.analyzelive per frame, then 10 log10(P + 1e-30) + weighting, normalisation to the
+[spec_min, spec_max] range and the colour look-up — as one kernel launch over all channels and
+frames of a batch.  Inputs may be numpy arrays (staged through device memory) or torch CUDA
+tensors (kernels are enqueued on torch's current stream and the result stays in HBM).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import FRT_STFT_DB, FRT_STFT_IMAGE, FRT_STFT_NORM, FRT_STFT_PSD
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+class StftEngine:
+    def __init__(self, fft_size: int, hop: int, n_channels: int = 1, precision: int = 32):
+        lib = _lib.init()
+        self._lib = lib
+        self.fft_size, self.hop, self.n_channels, self.precision = int(fft_size), int(hop), int(n_channels), precision
+        self.n_bins = self.fft_size // 2 + 1
+        self._h = ctypes.c_void_p()
+        _lib.check(lib.frt_stft_create(ctypes.byref(self._h), self.fft_size, self.hop, self.n_channels, precision))
+        self._has_lut = False
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.frt_stft_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- configuration --------------------------------------------------------------------
+    def set_epilogue(self, weight_db=None, spec_min: float = -140.0, spec_max: float = 0.0, lut=None):
+        """weight_db: N/2+1 dB offsets (A/B/C curve) or None; lut: 256 uint32 colour words or None."""
+        wp = None
+        if weight_db is not None:
+            w = np.ascontiguousarray(weight_db, np.float64)
+            if w.shape != (self.n_bins,):
+                raise ValueError(f"weight_db must have {self.n_bins} entries")
+            wp = w.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        lp = None
+        if lut is not None:
+            l = np.ascontiguousarray(lut, np.uint32)
+            if l.shape != (256,):
+                raise ValueError("lut must have 256 entries")
+            lp = l.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+        _lib.check(self._lib.frt_stft_set_epilogue(self._h, wp, float(spec_min), float(spec_max), lp))
+        self._has_lut = lut is not None
+
+    def set_run_length(self, frames: int):
+        _lib.check(self._lib.frt_stft_set_run_length(self._h, int(frames)))
+
+    def frames_for(self, n_samples: int) -> int:
+        return int(self._lib.frt_stft_frames_for(self._h, int(n_samples)))
+
+    # ---- execution ------------------------------------------------------------------------
+    def run(self, kind: int, x, out=None):
+        """x: [C, T] (or [T] when n_channels == 1).  Returns [C, F, N/2+1] of the output kind."""
+        in_dtype = np.float32 if self.precision == 32 else np.float64
+        if _is_torch(x):
+            return self._run_torch(kind, x, out)
+        x = np.ascontiguousarray(x, in_dtype)
+        if x.ndim == 1:
+            x = x[None, :]
+        if x.shape[0] != self.n_channels:
+            raise ValueError(f"expected {self.n_channels} channels, got {x.shape[0]}")
+        T = x.shape[1]
+        F = self.frames_for(T)
+        out_dtype = np.uint32 if kind == FRT_STFT_IMAGE else in_dtype
+        if out is None:
+            out = np.empty((self.n_channels, F, self.n_bins), out_dtype)
+        nf = ctypes.c_int64(0)
+        _lib.check(self._lib.frt_stft_run(self._h, kind, x.ctypes.data, T, T, out.ctypes.data, ctypes.byref(nf)))
+        return out
+
+    def _run_torch(self, kind, x, out):
+        import torch
+        want = torch.float32 if self.precision == 32 else torch.float64
+        if not x.is_cuda:
+            raise ValueError("torch inputs must be CUDA (HIP) tensors; pass numpy arrays for host data")
+        if x.dtype != want or not x.is_contiguous():
+            raise ValueError(f"expected a contiguous {want} tensor")
+        if x.dim() == 1:
+            x = x[None, :]
+        if x.shape[0] != self.n_channels:
+            raise ValueError(f"expected {self.n_channels} channels, got {x.shape[0]}")
+        T = x.shape[1]
+        F = self.frames_for(T)
+        if out is None:
+            odt = torch.int32 if kind == FRT_STFT_IMAGE else want      # torch has no uint32 arithmetic; same bits
+            out = torch.empty((self.n_channels, F, self.n_bins), dtype=odt, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(self._lib.frt_stft_set_stream(self._h, ctypes.c_void_p(stream)))
+        nf = ctypes.c_int64(0)
+        _lib.check(self._lib.frt_stft_run(self._h, kind, ctypes.c_void_p(x.data_ptr()), T, x.stride(0),
+                                          ctypes.c_void_p(out.data_ptr()), ctypes.byref(nf)))
+        return out
+
+    def psd(self, x, out=None):
+        return self.run(FRT_STFT_PSD, x, out)
+
+    def db(self, x, out=None):
+        return self.run(FRT_STFT_DB, x, out)
+
+    def norm(self, x, out=None):
+        return self.run(FRT_STFT_NORM, x, out)
+
+    def image(self, x, out=None):
+        if not self._has_lut:
+            raise ValueError("image output needs set_epilogue(lut=...)")
+        return self.run(FRT_STFT_IMAGE, x, out)

@@ -1,0 +1,30 @@
+"""The product never routes through the oracle or any CPU fallback."""
+import re
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def product_sources():
+    for p in (ROOT / "friture_amd").rglob("*"):
+        if p.suffix in {".py", ".hip", ".h", ".cpp"} and "lib" not in p.relative_to(ROOT / "friture_amd").parts[:1]:
+            yield p
+
+
+def test_product_does_not_import_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|oracle[./]dsp|refshim|/root/reference", re.M)
+    offenders = [str(p) for p in product_sources() if pat.search(p.read_text())]
+    assert not offenders, offenders
+
+
+def test_no_compat_layers_in_kernels():
+    pat = re.compile(r"__HIP_PLATFORM_AMD__|__CUDACC__|cuda_runtime|hipify|triton", re.I)
+    offenders = [str(p) for p in product_sources() if p.suffix in {".hip", ".h", ".cpp"} and pat.search(p.read_text())]
+    assert not offenders, offenders
+
+
+def test_runtime_entry_points_do_not_read_the_reference_checkout():
+    for name in ("bench.py", "__graft_entry__.py"):
+        p = ROOT / name
+        if p.exists():
+            assert "/root/reference" not in p.read_text().replace("when `/root/reference`", "")

@@ -1,0 +1,193 @@
+"""K1 parity: HIP STFT -> PSD / dB / image against the oracle and the reference's golden vectors.
+
+Tolerances (BASELINE.json north_star: "within 1e-5 relative on the PSD"; metric defined in
+SURVEY.md §8d): per frame max|gpu - ref| / max|ref| <= 1e-5 and relative L2 <= 1e-5 for the
+float32 path; 1e-12 for the float64 path.  Colour words are integers: exact, except where the
+normalised value sits within float32 rounding of a LUT bin edge.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_l2, rel_max, synth
+from oracle import dsp
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-5
+TOL64 = 1e-12
+
+
+def per_frame_err(gpu, ref):
+    gpu, ref = np.asarray(gpu, np.float64), np.asarray(ref, np.float64)
+    num = np.max(np.abs(gpu - ref), axis=-1)
+    return float(np.max(num / np.max(ref, axis=-1)))
+
+
+@pytest.fixture(scope="module")
+def engine_cls(hip):
+    from friture_amd.stft import StftEngine
+    return StftEngine
+
+
+@pytest.mark.parametrize("key,n_fft,hop", [("N32_hop16_noise", 32, 16), ("N256_hop64_tone", 256, 64),
+                                           ("N1024_hop512_noise", 1024, 512), ("N1024_hop256_tone", 1024, 256),
+                                           ("N4096_hop1024_noise", 4096, 1024), ("N16384_hop8192_tone", 16384, 8192)])
+def test_psd_against_reference_golden(golden, engine_cls, key, n_fft, hop):
+    g = golden("psd")
+    x, ref = g[key + "_x"], g[key + "_psd"]
+    got = engine_cls(n_fft, hop, 1, 32).psd(x)[0]
+    assert got.shape == ref.shape
+    assert per_frame_err(got, ref) <= TOL32 and rel_l2(got, ref) <= TOL32
+    got64 = engine_cls(n_fft, hop, 1, 64).psd(x.astype(np.float64))[0]
+    assert per_frame_err(got64, ref) <= TOL64
+
+
+@pytest.mark.parametrize("n_fft", [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("overlap", [0.5, 0.75])
+def test_psd_all_sizes_against_oracle(engine_cls, n_fft, overlap):
+    hop = int(n_fft * (1 - overlap))
+    frames = 37 if n_fft <= 2048 else 9
+    T = n_fft + hop * (frames - 1) + 5
+    x = np.stack([synth("noise", T, 42), synth("tone", T, 123), synth("chirp", T, 7)])
+    got = engine_cls(n_fft, hop, 3, 32).psd(x)
+    assert got.shape == (3, frames, n_fft // 2 + 1)
+    for c in range(3):
+        ref = dsp.stft_psd(x[c].astype(np.float64), n_fft, hop)
+        assert per_frame_err(got[c], ref) <= TOL32, (c, per_frame_err(got[c], ref))
+        assert rel_l2(got[c], ref) <= TOL32
+
+
+@pytest.mark.parametrize("n_fft,hop", [(1024, 384), (1024, 513), (1024, 1), (256, 1000), (2048, 777), (16384, 16384)])
+def test_psd_generic_hops(engine_cls, n_fft, hop):
+    """hops that are not N/2 or N/4 (re-load path), odd hops (scalar loads), hop > N (gaps)."""
+    frames = 11
+    T = n_fft + hop * (frames - 1)
+    x = synth("noise", T, 3)[None, :]
+    got = engine_cls(n_fft, hop, 1, 32).psd(x)[0]
+    ref = dsp.stft_psd(x[0].astype(np.float64), n_fft, hop)
+    assert got.shape == ref.shape and per_frame_err(got, ref) <= TOL32
+
+
+def test_edge_cases(engine_cls):
+    e = engine_cls(1024, 512, 2, 32)
+    # fewer samples than one frame: no spectra (the reference's `realizable` is 0, spectrum.py:138-142)
+    assert e.psd(np.zeros((2, 1023), np.float32)).shape == (2, 0, 513)
+    assert e.psd(np.zeros((2, 0), np.float32)).shape == (2, 0, 513)
+    # exactly one frame, and a ragged tail that does not complete another frame
+    x = np.stack([synth("noise", 1024 + 511, 1), synth("tone", 1024 + 511, 2)])
+    got = e.psd(x)
+    assert got.shape == (2, 1, 513)
+    for c in range(2):
+        assert per_frame_err(got[c], dsp.stft_psd(x[c].astype(np.float64), 1024, 512)) <= TOL32
+    # silence: PSD exactly zero, dB = 10 log10(1e-30) = -300
+    z = engine_cls(1024, 512, 1, 32)
+    assert np.all(z.psd(np.zeros((1, 4096), np.float32)) == 0)
+    assert np.allclose(z.db(np.zeros((1, 4096), np.float32)), -300.0, atol=1e-3)
+    # full-scale square wave: no overflow, still within tolerance
+    sq = np.sign(np.sin(np.arange(8192) * 0.3)).astype(np.float32)[None, :]
+    assert per_frame_err(z.psd(sq)[0], dsp.stft_psd(sq[0].astype(np.float64), 1024, 512)) <= TOL32
+    with pytest.raises(ValueError):
+        e.psd(np.zeros((3, 4096), np.float32))
+    from friture_amd._lib import FritureHipError
+    with pytest.raises(FritureHipError):
+        engine_cls(1000, 500, 1, 32)          # not a power of two
+    with pytest.raises(ValueError):
+        e.image(x)                            # no LUT configured
+
+
+def test_run_length_invariance(engine_cls):
+    """The register-shift walk must give the same spectra whatever the run length."""
+    x = synth("noise", 1024 + 512 * 200, 9)[None, :]
+    outs = []
+    for run in (1, 3, 8, 64):
+        e = engine_cls(1024, 512, 1, 32)
+        e.set_run_length(run)
+        outs.append(e.psd(x))
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+
+
+def test_db_norm_image_against_golden(golden, engine_cls):
+    g = golden("image")
+    x, A, lut = g["x"], g["weight"], g["lut"]
+    smin, smax = float(g["spec_min"]), float(g["spec_max"])
+    e = engine_cls(1024, 512, 1, 32)
+    e.set_epilogue(A, smin, smax, lut)
+    ref_norm = g["norm"].T                       # reference is (bins, frames)
+    ref_db = ref_norm * (smax - smin) + smin
+    db = e.db(x)[0]
+    norm = e.norm(x)[0]
+    psd_ref = dsp.stft_psd(x.astype(np.float64), 1024, 512)
+    strong = psd_ref > 1e-6 * psd_ref.max(axis=1, keepdims=True)   # dB of near-cancelled bins is ill-conditioned in f32
+    assert np.max(np.abs(db - ref_db)[strong]) < 1e-3
+    assert np.max(np.abs(norm - ref_norm)[strong]) < 1e-5
+    # bins -60 dB and more below the frame maximum: float32 PSD error (1e-7 of the maximum) dominates
+    assert np.max(np.abs(db - ref_db)) < 5.0
+    img = e.image(x)[0]
+    ref_img = g["image"].T
+    mismatch = img != ref_img
+    frac = (np.clip(ref_norm, 0, 1) * 255) % 1.0
+    near_edge = (frac < 2e-2) | (frac > 1 - 2e-2)
+    assert not np.any(mismatch & strong & ~near_edge), int(np.sum(mismatch & strong & ~near_edge))
+    assert np.mean(mismatch[strong]) < 2e-3
+    # float64 instance: pixel-exact everywhere but at exact bin edges
+    e64 = engine_cls(1024, 512, 1, 64)
+    e64.set_epilogue(A, smin, smax, lut)
+    img64 = e64.image(x.astype(np.float64))[0]
+    assert np.mean(img64 != ref_img) < 1e-4
+    assert np.max(np.abs(e64.norm(x.astype(np.float64))[0] - ref_norm)) < 1e-9
+
+
+def test_audioproc_dropin(golden, hip):
+    """friture_amd.audioproc.audioproc against reference outputs of friture.audioproc.audioproc."""
+    from friture_amd.audioproc import audioproc
+    g = golden("psd")
+    p = audioproc()
+    for key, n_fft, hop in [("N1024_hop512_noise", 1024, 512), ("N32_hop16_noise", 32, 16),
+                            ("N16384_hop8192_tone", 16384, 8192)]:
+        p.set_fftsize(n_fft)
+        x = g[key + "_x"].astype(np.float64)
+        for f in range(2):
+            got = p.analyzelive(x[f * hop:f * hop + n_fft])
+            assert got.dtype == np.float64 and rel_max(got, g[key + "_psd"][f]) <= TOL64
+        assert np.array_equal(p.window, dsp.hann_symmetric(n_fft))
+    p.set_fftsize(1024)
+    assert np.array_equal(p.get_freq_scale(), g["N1024_freq"])
+    for got, want in zip(p.get_freq_weighting(), (g["N1024_A"], g["N1024_B"], g["N1024_C"])):
+        assert np.array_equal(got, want)
+    assert p.size_sq == 1024.0 ** 2
+    spec = np.fft.rfft(np.ones(1024))
+    assert np.array_equal(p.norm_square(spec), (spec * spec.conjugate()).real / 1024.0 ** 2)
+    with pytest.raises(ValueError):
+        p.analyzelive(np.zeros(1000))
+
+
+def test_device_resident_full_size_properties(engine_cls):
+    """BASELINE configs[1] size (1 ch, T = 2^26, N = 1024, hop 512 -> 131 071 spectra) on torch
+    CUDA tensors, checked through size-independent properties: Parseval per frame, agreement of a
+    random sample of frames with the oracle, and linearity in amplitude."""
+    import torch
+    T = 1 << 26
+    gen = torch.Generator(device="cuda").manual_seed(42)
+    x = 0.25 * torch.randn((1, T), generator=gen, device="cuda", dtype=torch.float32)
+    e = engine_cls(1024, 512, 1, 32)
+    psd = e.psd(x)
+    torch.cuda.synchronize()
+    F = e.frames_for(T)
+    assert psd.shape == (1, F, 513) and F == 131071
+    # Parseval: sum_n (x w)^2 = (P0 + 2 sum_{0<k<N/2} Pk + P_{N/2}) * N   (P = |X|^2 / N^2)
+    w = torch.tensor(dsp.hann_symmetric(1024), device="cuda")
+    frames = x[0].unfold(0, 1024, 512).double() * w
+    lhs = (frames ** 2).sum(dim=1)
+    p = psd[0].double()
+    rhs = (p[:, 0] + 2 * p[:, 1:512].sum(dim=1) + p[:, 512]) * 1024.0
+    assert float(((lhs - rhs).abs() / lhs).max()) < 1e-5
+    # sampled frames against the oracle
+    xs = x[0].cpu().numpy()
+    rng = np.random.default_rng(0)
+    for f in list(rng.integers(0, F, 64)) + [0, F - 1]:
+        ref = dsp.psd_frame(xs[f * 512:f * 512 + 1024].astype(np.float64), dsp.hann_symmetric(1024))
+        assert rel_max(psd[0, f].cpu().numpy(), ref) <= TOL32
+    # linearity: PSD(2x) = 4 PSD(x) exactly in binary floating point
+    psd2 = e.psd(2.0 * x)
+    assert torch.equal(psd2, 4.0 * psd)
