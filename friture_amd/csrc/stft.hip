@@ -44,6 +44,9 @@ struct StftArgs {
     double psd_scale;      // 1 / N^2
     double norm_off;       // -spec_min
     double norm_scale;     // 1 / (spec_max - spec_min)
+#ifdef FRT_ABLATE
+    int ablate;            // experiment switches: 1 no stores, 2 no loads, 4 no FFT, 8 no unpack shuffles
+#endif
 };
 
 template <typename T> __device__ __forceinline__ T db10(T p);
@@ -58,7 +61,13 @@ __device__ __forceinline__ T shfl_t(T v, int lane) { return __shfl(v, lane, 64);
 
 // TIN: sample type in HBM; T: arithmetic type; SHIFT: register slots a hop advances (0 = reload all)
 template <typename TIN, typename T, int LOG2M, int SHIFT>
-__global__ void __launch_bounds__((Pow2Plan<LOG2M>::TPF < 256 ? 256 : Pow2Plan<LOG2M>::TPF))
+__global__ void
+#if defined(FRT_WAVE_MIN_WAVES)
+__launch_bounds__((Pow2Plan<LOG2M>::TPF < 256 ? 256 : Pow2Plan<LOG2M>::TPF),
+                  (Pow2Plan<LOG2M>::TPF <= 64 ? FRT_WAVE_MIN_WAVES : 1))
+#else
+__launch_bounds__((Pow2Plan<LOG2M>::TPF < 256 ? 256 : Pow2Plan<LOG2M>::TPF))
+#endif
 stft_kernel(const StftArgs a) {
     using P = Pow2Plan<LOG2M>;
     constexpr int M = P::M, N = 2 * M, TPF = P::TPF;
@@ -139,6 +148,11 @@ stft_kernel(const StftArgs a) {
         for (int j = 0; j < 8; ++j) raw[j] = load_slot(f0, j);
     }
 
+    // Drain the one-off loads (tables, first frame) here.  Without this the compiler's s_waitcnt
+    // placement inside the loop has to assume they may still be in flight on the first trip and
+    // emits vmcnt(0) at the top of every iteration, which would serialise the prefetch below.
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), other counters untouched
+
     const int nloop = a.run;                          // uniform trip count keeps barriers aligned
     for (int g = 0; g < nloop; ++g) {
         const bool valid = g < nfr;
@@ -148,7 +162,11 @@ stft_kernel(const StftArgs a) {
             break;
         }
         // prefetch the new slots of the next frame
+#ifdef FRT_ABLATE
+        if (g + 1 < nfr && !(a.ablate & 2)) {
+#else
         if (g + 1 < nfr) {
+#endif
 #pragma unroll
             for (int t = 0; t < NEW; ++t) nxt[t] = load_slot(f0 + g + 1, 8 - NEW + t);
         }
@@ -168,6 +186,10 @@ stft_kernel(const StftArgs a) {
             v[j] = {raw[j].x * wj.x, raw[j].y * wj.y};
         }
 
+#ifdef FRT_ABLATE
+        if (a.ablate & 4) {
+        } else
+#endif
         if constexpr (HOIST) {
             fft_pow2_forward<T, LOG2M, WAVE>(v, buf, i, twr);
         } else {
@@ -177,6 +199,12 @@ stft_kernel(const StftArgs a) {
 
         // ---- conjugate-symmetric unpack: X[k] = ((A+B) - i w^k (A-B))/2, A = Z[k], B = conj Z[M-k]
         C part[8];
+#ifdef FRT_ABLATE
+        if (a.ablate & 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[j] = v[7 - j];
+        } else
+#endif
         if constexpr (WAVE) {
             const int lane = tid & 63;
             const int src = lane - i + ((TPF - i) & (TPF - 1));
@@ -214,6 +242,25 @@ stft_kernel(const StftArgs a) {
         T d0 = v[0].x - v[0].y;
         T res_last = d0 * d0 * (T)a.psd_scale;
 
+        // Advance the register window by one hop *before* the stores are issued: the wait for the
+        // prefetched samples then sits behind a whole transform (latency hidden) and ahead of this
+        // frame's stores, so it never has to wait for store acknowledgements.
+        if (g + 1 < nfr) {
+#pragma unroll
+            for (int j = 0; j < 8 - NEW; ++j) raw[j] = raw[j + NEW];
+#pragma unroll
+            for (int t = 0; t < NEW; ++t) raw[8 - NEW + t] = nxt[t];
+        }
+
+
+#ifdef FRT_ABLATE
+        if (a.ablate & 1) {
+            T acc = res_last;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += res[j];
+            if (acc == (T)-12345.678) outc[0] = acc;     // keeps the results live, never true
+        } else
+#endif
         if (valid) {
             T* row = outc + (f0 + g) * (M + 1);
             if (a.kind == FRT_STFT_PSD) {
@@ -259,13 +306,6 @@ stft_kernel(const StftArgs a) {
             }
         }
 
-        // advance the register window by one hop
-        if (g + 1 < nfr) {
-#pragma unroll
-            for (int j = 0; j < 8 - NEW; ++j) raw[j] = raw[j + NEW];
-#pragma unroll
-            for (int t = 0; t < NEW; ++t) raw[8 - NEW + t] = nxt[t];
-        }
     }
 }
 
@@ -444,6 +484,9 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     a.psd_scale = 1.0 / ((double)N * (double)N);
     a.norm_off = -h->spec_min;
     a.norm_scale = 1.0 / (h->spec_max - h->spec_min);
+#ifdef FRT_ABLATE
+    a.ablate = getenv("FRT_ABLATE") ? atoi(getenv("FRT_ABLATE")) : 0;
+#endif
 
     // slots of 2*TPF samples a hop advances; the register-shift kernels need hop = s*N/8, s in {2,4}
     int shift = 0;

@@ -1,0 +1,44 @@
+"""Condense rocprofv3 output (rocpd .db from --kernel-trace --stats, CSV from --pmc passes) into
+small text summaries that are committed under profiles/.
+
+    python tools/prof_summary.py stats <results.db> > profiles/rNN_kernel_stats.txt
+    python tools/prof_summary.py pmc <dir-with-pass-subdirs> <kernel-substring> > profiles/rNN_pmc.txt
+"""
+import collections
+import csv
+import glob
+import os
+import sqlite3
+import sys
+
+
+def stats(db_path):
+    db = sqlite3.connect(db_path)
+    cur = db.cursor()
+    print(f"# rocprofv3 --kernel-trace --stats  ({os.path.basename(db_path)})")
+    print("# name | calls | total_us | avg_us | min_us | max_us | % | vgpr | sgpr | lds_bytes | grid | workgroup")
+    total = cur.execute("select sum(duration) from kernels").fetchone()[0]
+    q = ("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), vgpr_count, sgpr_count, "
+         "lds_size, grid_x, workgroup_x from kernels group by name order by sum(duration) desc")
+    for name, n, tot, avg, mn, mx, vg, sg, lds, grid, wg in cur.execute(q):
+        short = name if len(name) < 100 else name[:97] + "..."
+        print(f"{short} | {n} | {tot/1e3:.1f} | {avg/1e3:.2f} | {mn/1e3:.2f} | {mx/1e3:.2f} | {100*tot/total:.1f} | "
+              f"{vg} | {sg} | {lds} | {grid} | {wg}")
+
+
+def pmc(root, needle):
+    print(f"# rocprofv3 --pmc passes under {root}; kernels matching '{needle}'; mean over dispatches")
+    for d in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(d)):
+            if needle in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in sorted(acc.items()):
+            print(f"{os.path.basename(os.path.dirname(d)):8s} {k:28s} dispatches={len(v):3d} mean={sum(v)/len(v):.6g}")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2])
+    else:
+        pmc(sys.argv[2], sys.argv[3])
