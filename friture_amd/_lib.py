@@ -40,6 +40,21 @@ SIGNATURES = {
     "frt_stft_analyzelive_f64": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double)]),
     "frt_stft_frames_for": (c_int64, [c_void_p, c_int64]),
     "frt_stft_set_run_length": (c_int, [c_void_p, c_int]),
+    "frt_octbank_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int] + [POINTER(c_double)] * 6),
+    "frt_octbank_destroy": (None, [c_void_p]),
+    "frt_octbank_set_stream": (c_int, [c_void_p, c_void_p]),
+    "frt_octbank_reset": (c_int, [c_void_p]),
+    "frt_octbank_set_chunk": (c_int, [c_void_p, c_int]),
+    "frt_octbank_packed_length": (c_int64, [c_void_p, c_int]),
+    "frt_octbank_filter": (c_int, [c_void_p, c_void_p, c_int, c_void_p, POINTER(c_int)]),
+    "frt_octbank_state_length": (c_int, [c_void_p]),
+    "frt_octbank_get_state": (c_int, [c_void_p, POINTER(c_double)]),
+    "frt_octbank_set_state": (c_int, [c_void_p, POINTER(c_double)]),
+    "frt_octbank_energies": (c_int, [c_void_p, c_void_p, c_int64, c_int, POINTER(c_double), POINTER(c_double), c_int,
+                                     c_void_p]),
+    "frt_decimate_multiple": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, POINTER(c_int)]),
+    "frt_lfilter_f64": (c_int, [POINTER(c_double), POINTER(c_double), c_int, POINTER(c_double), c_int, POINTER(c_double),
+                                POINTER(c_double), POINTER(c_double)]),
 }
 
 _lib = None

@@ -1,0 +1,678 @@
+// iir.hip — K2/K4: exact IIR octave filter bank with decimation, band energies, and the
+// stand-alone decimation chain, for gfx950.  Built with -ffp-contract=off: the recurrences replay
+// the reference's IEEE double operations one for one.
+//
+// Reference semantics (paths relative to the reference checkout):
+//   direct form II transposed, carried state                       friture/signal/lfilter.py:131-139
+//       y[k]  = z[0] + b[0] x[k]
+//       z[n]  = z[n+1] + x[k] b[n+1] - y[k] a[n+1]
+//       z[-1] = x[k] b[-1] - y[k] a[-1]
+//   decimate = 12th-order elliptic low-pass, keep samples 0, 2, 4, ...   friture/signal/decimate.py:27-42
+//   octave bank: per octave j the bpo top-octave band-passes (4th order) run on the j-times
+//   decimated signal, bands are filled from the top (dec = 2^j)          friture/filter.py:86-118
+//   band energy of a block: alpha * sum_i (1-alpha)^(n-1-i) y_i^2 + previous (1-alpha)^n
+//                                   friture/signal/exp_smoothing.py:40-56, friture/octavespectrum.py:104
+//
+// Kernel shape.  A recurrence is serial in time, so the parallel axes are channels, filters, the
+// *state index inside a filter*, and — for long batches — time chunks.
+//   * One 16-lane DPP row per filter: lane s of the row owns state z[s] and the coefficient pair
+//     (b[s+1], a[s+1]).  Per sample: the row leader forms y = z[0] + b[0] x, `row_newbcast:0`
+//     hands y to the row, `row_shl:1` hands z[s+1] to lane s, and every lane updates its state
+//     with exactly the reference's operations.  The loop-carried dependency is add -> broadcast
+//     -> mul -> sub, whatever the filter order; a wavefront carries four filters.
+//   * One launch per octave stage; grid = (time chunk, filter group, channel).
+//   * Sequential mode (one chunk) starts from the carried state and is bit-identical to the
+//     reference.  Time-parallel mode runs every chunk twice: pass 1 from a zero state to get the
+//     chunk's zero-state end state, a short scan z_{q+1} = A^L z_q + s_q over the chunks (A^L is
+//     computed on the host), then pass 2 from the true initial state of each chunk.  That is the
+//     same linear recurrence evaluated in a different association order: results agree with the
+//     sequential ones to rounding (1e-15 relative), and the parallelism is C x filters x chunks.
+#include <cmath>
+
+#include "common.h"
+
+namespace frt {
+
+constexpr int kStates = 16;        // one DPP row per filter
+constexpr int kMaxOrder = 15;
+constexpr int kCoefStride = 2 * (kMaxOrder + 1);   // b[0..15], a[0..15]
+constexpr int kMaxFilters = 25;    // 24 band-passes + decimator
+constexpr int kNOctave = 9;
+
+struct IirStageArgs {
+    const void* x;             // [C][x_stride] stage input
+    long long x_stride;
+    int n;                     // samples per channel in this stage
+    int in_f32;                // stage-0 input is float
+    const double* coef;        // [nfilt][kCoefStride]
+    const int* order;          // [nfilt]
+    int nfilt;
+    int dec_filter;            // index of the decimator among the filters, or -1
+    double* state;             // [C][nfilt][kStates] carried state of this stage
+    int chunk;                 // samples per chunk (multiple of 64)
+    int nchunks;
+    int pass;                  // 0 sequential, 1 zero-state scan pass, 2 output pass from chunk_init
+    double* chunk_end;         // [C][nfilt][nchunks][kStates] pass 1 result
+    const double* chunk_init;  // [C][nfilt][nchunks][kStates] pass 2 initial states
+    double* y;                 // band outputs (packed per channel) or null
+    long long y_cstride;
+    long long y_off[kMaxFilters];   // offset of each filter's band inside a channel's packed row
+    double* xnext;             // [C][xnext_stride] decimated output or null
+    long long xnext_stride;
+    double* eblock;            // [C][nblocks][nbands] zero-state block energies or null
+    int eblock_len;            // samples of this stage per energy block (power of two)
+    int eblock_shift;          // log2(eblock_len)
+    int nblocks;
+    int nbands;
+    int band_index[kMaxFilters];    // global band index of each filter (-1 for the decimator)
+    const double* alpha;       // [nbands]
+};
+
+__device__ __forceinline__ double dpp_row_bcast0(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150, 0xF, 0xF, false);   // row_newbcast:0
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double dpp_row_shl1(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x101, 0xF, 0xF, true);    // row_shl:1, zero fill
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x101, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(64) iir_stage_kernel(const IirStageArgs a) {
+    __shared__ double stage_y[4][64];
+
+    const int lane = threadIdx.x;
+    const int r = lane >> 4, s = lane & 15;
+    const int q = blockIdx.x, g = blockIdx.y, c = blockIdx.z;
+    const int f = 4 * g + r;
+    const bool fvalid = f < a.nfilt;
+    const int fc = fvalid ? f : 0;
+    const int ord = fvalid ? a.order[fc] : 0;
+    const bool is_last = s == ord - 1;
+    const bool live = fvalid && s < ord;
+    const bool leader = fvalid && s == 0;
+
+    const double* cf = a.coef + (size_t)fc * kCoefStride;
+    const double b0 = cf[0];
+    const double bn = live ? cf[s + 1] : 0.0;
+    const double an = live ? cf[kMaxOrder + 1 + s + 1] : 0.0;
+
+    const size_t sidx = ((size_t)c * a.nfilt + fc) * kStates + s;
+    double z = 0.0;
+    if (live) {
+        if (a.pass == 0) z = a.state[sidx];
+        else if (a.pass == 2) z = a.chunk_init[(((size_t)c * a.nfilt + fc) * a.nchunks + q) * kStates + s];
+    }
+
+    const int band = fvalid ? a.band_index[fc] : -1;
+    const bool do_energy = a.eblock != nullptr && band >= 0 && a.pass != 1;
+    const double alpha = do_energy ? a.alpha[band] : 0.0;
+    const double decay = 1.0 - alpha;
+    double acc = 0.0;
+
+    const bool write_y = a.pass != 1 && a.y != nullptr;
+    const bool write_dec = a.pass != 1 && a.xnext != nullptr;
+
+    const long long start = (long long)q * a.chunk;
+    long long stop = start + a.chunk;
+    if (stop > a.n) stop = a.n;
+
+    for (long long base = start; base < stop; base += 64) {
+        const int cnt = (int)((stop - base) < 64 ? (stop - base) : 64);
+        double xv = 0.0;
+        if (lane < cnt) {
+            const long long idx = (long long)c * a.x_stride + base + lane;
+            xv = a.in_f32 ? (double)((const float*)a.x)[idx] : ((const double*)a.x)[idx];
+        }
+        for (int k = 0; k < cnt; ++k) {
+            const double x = readlane_f64(xv, k);
+            const double y0 = z + b0 * x;
+            const double y = dpp_row_bcast0(y0);
+            const double zn = dpp_row_shl1(z);
+            const double xb = x * bn;
+            const double t = is_last ? xb : zn + xb;
+            z = t - y * an;
+            if (do_energy) {
+                // zero-state block energy: alpha * sum_i decay^(n-1-i) y_i^2, restarted per block
+                const long long gi = base + k;
+                if ((gi & (a.eblock_len - 1)) == 0) acc = 0.0;
+                acc = acc * decay + y * y;
+                if (leader && ((gi + 1) & (a.eblock_len - 1)) == 0)
+                    a.eblock[((size_t)c * a.nblocks + (gi >> a.eblock_shift)) * a.nbands + band] = alpha * acc;
+            }
+            if (leader) stage_y[r][k] = y;
+        }
+        if (write_y || write_dec) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int ff = 4 * g + rr;
+                if (ff >= a.nfilt) break;
+                if (ff == a.dec_filter) {
+                    if (write_dec && lane < 32 && 2 * lane < cnt)
+                        a.xnext[(long long)c * a.xnext_stride + (base >> 1) + lane] = stage_y[rr][2 * lane];
+                } else if (write_y && lane < cnt) {
+                    a.y[(long long)c * a.y_cstride + a.y_off[ff] + base + lane] = stage_y[rr][lane];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+
+    if (live) {
+        if (a.pass == 1) a.chunk_end[(((size_t)c * a.nfilt + fc) * a.nchunks + q) * kStates + s] = z;
+        else if (q == a.nchunks - 1) a.state[sidx] = z;
+    }
+}
+
+// z_{q+1} = A^L z_q + s_q over the chunks of one (channel, filter); 16 lanes per filter.
+// power: [nfilt][16][16] row-major A^L; chunk_end -> chunk_init (may not alias).
+__global__ void __launch_bounds__(64) iir_scan_kernel(const double* __restrict__ power, const double* __restrict__ state,
+                                                      const double* __restrict__ chunk_end, double* __restrict__ chunk_init,
+                                                      int nfilt, int nchunks, int total_filters) {
+    const int gid = blockIdx.x * 4 + (threadIdx.x >> 4);     // (channel, filter) pair
+    const int s = threadIdx.x & 15;
+    if (gid >= total_filters) return;
+    const int f = gid % nfilt;
+    double m[kStates];
+#pragma unroll
+    for (int t = 0; t < kStates; ++t) m[t] = power[((size_t)f * kStates + s) * kStates + t];
+    double z = state[(size_t)gid * kStates + s];
+    const int row0 = (threadIdx.x & 63) & ~15;
+    for (int q = 0; q < nchunks; ++q) {
+        const size_t o = ((size_t)gid * nchunks + q) * kStates + s;
+        chunk_init[o] = z;
+        double acc = chunk_end[o];
+#pragma unroll
+        for (int t = 0; t < kStates; ++t) acc += m[t] * __shfl(z, row0 + t, 64);
+        z = acc;
+    }
+}
+
+// sp_blk = E_blk + sp_{blk-1} * (1-alpha)^n  (exp_smoothing.py:52-54), optional dB + weighting.
+__global__ void energy_scan_kernel(const double* __restrict__ eblock, const double* __restrict__ decay_n,
+                                   double* __restrict__ smooth, void* __restrict__ out, int out_f32, int nblocks, int nbands,
+                                   int total, const double* __restrict__ weight_db, int as_db) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;    // (channel, band)
+    if (gid >= total) return;
+    const int c = gid / nbands, k = gid - c * nbands;
+    double prev = smooth[gid];
+    const double d = decay_n[k];
+    for (int b = 0; b < nblocks; ++b) {
+        const size_t o = ((size_t)c * nblocks + b) * nbands + k;
+        const double sp = eblock[o] + prev * d;
+        prev = sp;
+        double v = sp;
+        if (as_db) v = 10.0 * log10(sp + 1e-30) + (weight_db ? weight_db[k] : 0.0);
+        if (out_f32) ((float*)out)[o] = (float)v;
+        else ((double*)out)[o] = v;
+    }
+    smooth[gid] = prev;
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+
+// A^L for the DF2T state recurrence z' = A z (zero input): A[n][n+1] = 1, A[n][0] -= a[n+1].
+static void transition_power(const double* a_coef, int order, long long L, double* out /*16x16*/) {
+    const int d = kStates;
+    std::vector<long double> A(d * d, 0.0L), R(d * d, 0.0L), T(d * d);
+    for (int n = 0; n < order; ++n) {
+        if (n + 1 < order) A[n * d + n + 1] = 1.0L;
+        A[n * d + 0] -= (long double)a_coef[n + 1];
+    }
+    for (int n = 0; n < d; ++n) R[n * d + n] = 1.0L;
+    auto mul = [&](std::vector<long double>& X, const std::vector<long double>& Y) {
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+                long double acc = 0;
+                for (int k = 0; k < d; ++k) acc += X[i * d + k] * Y[k * d + j];
+                T[i * d + j] = acc;
+            }
+        X = T;
+    };
+    while (L > 0) {
+        if (L & 1) mul(R, A);
+        L >>= 1;
+        if (L) {
+            std::vector<long double> A2 = A;
+            mul(A2, A);
+            A = A2;
+        }
+    }
+    for (int i = 0; i < d * d; ++i) out[i] = (double)R[i];
+}
+
+}  // namespace frt
+
+using namespace frt;
+
+struct frt_octbank {
+    int bpo = 0, n_channels = 0, mode = 0, nbands = 0, nfilt = 0;
+    int chunk0 = 0;                         // 0 = sequential (bit exact); else samples per chunk at octave 0
+    hipStream_t stream = nullptr;
+    std::vector<double> h_coef;             // [nfilt][kCoefStride]
+    std::vector<int> h_order;
+    DeviceBuffer coef, order, state;        // state: [9][C][nfilt][16]
+    DeviceBuffer xin, ypacked, xbuf[kNOctave], chunk_end, chunk_init, power;
+    DeviceBuffer eblock, alpha, decay_n, smooth, weight, eout;
+    int power_chunk0 = -1;
+    size_t stage_state_elems() const { return (size_t)n_channels * nfilt * kStates; }
+};
+
+static void stage_lengths(int n, int* len) {
+    len[0] = n;
+    for (int j = 1; j < kNOctave; ++j) len[j] = (len[j - 1] + 1) / 2;     // x[::2]
+}
+
+extern "C" int64_t frt_octbank_packed_length(const frt_octbank* h, int n) {
+    if (!h || n < 0) return 0;
+    int len[kNOctave];
+    stage_lengths(n, len);
+    int64_t total = 0;
+    for (int j = 0; j < kNOctave; ++j) total += (int64_t)len[j] * h->bpo;
+    return total;
+}
+
+extern "C" int frt_octbank_state_length(const frt_octbank* h) { return h ? kNOctave * (4 * h->bpo + 12) : 0; }
+
+extern "C" int frt_octbank_create(frt_octbank** out, int bands_per_octave, int n_channels, int mode, const double* boct,
+                                  const double* aoct, const double* bdec, const double* adec, const double* boct_fir,
+                                  const double* bdec_fir) {
+    FRT_REQUIRE(out, "frt_octbank_create: null handle pointer");
+    *out = nullptr;
+    FRT_REQUIRE(bands_per_octave >= 0 && bands_per_octave <= 24, "frt_octbank_create: bands_per_octave %d not in [0, 24]",
+                bands_per_octave);
+    FRT_REQUIRE(n_channels >= 1, "frt_octbank_create: n_channels %d < 1", n_channels);
+    FRT_REQUIRE(mode == 0, "frt_octbank_create: mode %d is not available in this build (0 = exact IIR)", mode);
+    FRT_REQUIRE(bdec && adec && (bands_per_octave == 0 || (boct && aoct)), "frt_octbank_create: null coefficients");
+    (void)boct_fir;
+    (void)bdec_fir;
+    frt_octbank* h = new frt_octbank();
+    h->bpo = bands_per_octave;
+    h->n_channels = n_channels;
+    h->mode = mode;
+    h->nbands = kNOctave * bands_per_octave;
+    h->nfilt = bands_per_octave + 1;
+    h->h_coef.assign((size_t)h->nfilt * kCoefStride, 0.0);
+    h->h_order.assign(h->nfilt, 0);
+    for (int i = 0; i < bands_per_octave; ++i) {       // 4th-order band-passes, 5 + 5 coefficients
+        for (int t = 0; t < 5; ++t) {
+            h->h_coef[(size_t)i * kCoefStride + t] = boct[i * 5 + t];
+            h->h_coef[(size_t)i * kCoefStride + kMaxOrder + 1 + t] = aoct[i * 5 + t];
+        }
+        h->h_order[i] = 4;
+    }
+    for (int t = 0; t < 13; ++t) {                       // 12th-order decimator, 13 + 13 coefficients
+        h->h_coef[(size_t)bands_per_octave * kCoefStride + t] = bdec[t];
+        h->h_coef[(size_t)bands_per_octave * kCoefStride + kMaxOrder + 1 + t] = adec[t];
+    }
+    h->h_order[bands_per_octave] = 12;
+    int rc;
+    if ((rc = upload(h->coef, h->h_coef)) || (rc = upload(h->order, h->h_order)) ||
+        (rc = h->state.reserve(kNOctave * h->stage_state_elems() * sizeof(double)))) {
+        frt_octbank_destroy(h);
+        return rc;
+    }
+    if (hipMemset(h->state.ptr, 0, h->state.bytes) != hipSuccess) {
+        set_last_error("frt_octbank_create: hipMemset failed");
+        frt_octbank_destroy(h);
+        return FRT_ERR_HIP;
+    }
+    *out = h;
+    return FRT_OK;
+}
+
+extern "C" void frt_octbank_destroy(frt_octbank* h) {
+    if (!h) return;
+    DeviceBuffer* bufs[] = {&h->coef, &h->order, &h->state, &h->xin, &h->ypacked, &h->chunk_end, &h->chunk_init, &h->power,
+                            &h->eblock, &h->alpha, &h->decay_n, &h->smooth, &h->weight, &h->eout};
+    for (auto* b : bufs) b->release();
+    for (auto& b : h->xbuf) b.release();
+    delete h;
+}
+
+extern "C" int frt_octbank_set_stream(frt_octbank* h, void* s) {
+    FRT_REQUIRE(h, "frt_octbank_set_stream: null handle");
+    h->stream = (hipStream_t)s;
+    return FRT_OK;
+}
+
+extern "C" int frt_octbank_set_chunk(frt_octbank* h, int chunk0) {
+    FRT_REQUIRE(h, "frt_octbank_set_chunk: null handle");
+    FRT_REQUIRE(chunk0 == 0 || (chunk0 > 0 && chunk0 % 16384 == 0),
+                "frt_octbank_set_chunk: chunk %d must be 0 (sequential) or a multiple of 16384", chunk0);
+    h->chunk0 = chunk0;
+    return FRT_OK;
+}
+
+extern "C" int frt_octbank_reset(frt_octbank* h) {
+    FRT_REQUIRE(h, "frt_octbank_reset: null handle");
+    FRT_HIP_CHECK(hipMemsetAsync(h->state.ptr, 0, h->state.bytes, h->stream));
+    if (h->smooth.ptr) FRT_HIP_CHECK(hipMemsetAsync(h->smooth.ptr, 0, h->smooth.bytes, h->stream));
+    return FRT_OK;
+}
+
+// State exchange in the reference's order (filter.py:121-133): per channel, per octave j the band
+// states i = bpo-1 .. 0 (4 doubles each) followed by the decimator's 12.
+static int state_copy(frt_octbank* h, double* user, bool to_user) {
+    const size_t per_stage = h->stage_state_elems();
+    std::vector<double> dev(kNOctave * per_stage);
+    FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (to_user) FRT_HIP_CHECK(hipMemcpy(dev.data(), h->state.ptr, dev.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const int slen = frt_octbank_state_length(h);
+    for (int c = 0; c < h->n_channels; ++c) {
+        double* u = user + (size_t)c * slen;
+        int pos = 0;
+        for (int j = 0; j < kNOctave; ++j) {
+            for (int i = h->bpo - 1; i >= -1; --i) {
+                const int f = i >= 0 ? i : h->bpo;
+                const int ord = h->h_order[f];
+                double* d = &dev[j * per_stage + ((size_t)c * h->nfilt + f) * kStates];
+                for (int s = 0; s < ord; ++s) {
+                    if (to_user) u[pos + s] = d[s];
+                    else d[s] = u[pos + s];
+                }
+                pos += ord;
+            }
+        }
+    }
+    if (!to_user) FRT_HIP_CHECK(hipMemcpy(h->state.ptr, dev.data(), dev.size() * sizeof(double), hipMemcpyHostToDevice));
+    return FRT_OK;
+}
+
+extern "C" int frt_octbank_get_state(frt_octbank* h, double* z) {
+    FRT_REQUIRE(h && z, "frt_octbank_get_state: null argument");
+    return state_copy(h, z, true);
+}
+
+extern "C" int frt_octbank_set_state(frt_octbank* h, const double* z) {
+    FRT_REQUIRE(h && z, "frt_octbank_set_state: null argument");
+    std::vector<double> zero(kNOctave * h->stage_state_elems(), 0.0);
+    FRT_HIP_CHECK(hipMemcpy(h->state.ptr, zero.data(), zero.size() * sizeof(double), hipMemcpyHostToDevice));
+    return state_copy(h, const_cast<double*>(z), false);
+}
+
+static int ensure_powers(frt_octbank* h) {
+    if (h->power_chunk0 == h->chunk0) return FRT_OK;
+    std::vector<double> p((size_t)kNOctave * h->nfilt * kStates * kStates);
+    for (int j = 0; j < kNOctave; ++j)
+        for (int f = 0; f < h->nfilt; ++f)
+            transition_power(&h->h_coef[(size_t)f * kCoefStride + kMaxOrder + 1], h->h_order[f], h->chunk0 >> j,
+                             &p[((size_t)j * h->nfilt + f) * kStates * kStates]);
+    int rc = upload(h->power, p);
+    if (rc) return rc;
+    h->power_chunk0 = h->chunk0;
+    return FRT_OK;
+}
+
+// Runs the nine octave stages on device buffers.  d_x: stage-0 input; d_y (nullable): packed band
+// outputs; energies (nullable eblock): zero-state block energies for blocks of `eblock0` input samples.
+static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_stride, int n, double* d_y, int64_t y_cstride,
+                      double* d_eblock, int eblock0, int nblocks) {
+    int len[kNOctave];
+    stage_lengths(n, len);
+    const bool parallel = h->chunk0 > 0 && n >= 2 * h->chunk0;
+    int nchunks = 1;
+    if (parallel) {
+        nchunks = (n + h->chunk0 - 1) / h->chunk0;
+        int rc = ensure_powers(h);
+        if (rc) return rc;
+        const size_t ws = (size_t)h->n_channels * h->nfilt * nchunks * kStates * sizeof(double);
+        if ((rc = h->chunk_end.reserve(ws)) || (rc = h->chunk_init.reserve(ws))) return rc;
+    }
+    for (int j = 1; j < kNOctave; ++j) {
+        int rc = h->xbuf[j].reserve((size_t)h->n_channels * len[j] * sizeof(double));
+        if (rc) return rc;
+    }
+    // packed offsets: band k (low band first) has length len[j], j = 8 - k / bpo
+    std::vector<long long> band_off(h->nbands + 1, 0);
+    for (int k = 0; k < h->nbands; ++k) band_off[k + 1] = band_off[k] + len[kNOctave - 1 - k / h->bpo];
+
+    for (int j = 0; j < kNOctave; ++j) {
+        IirStageArgs a{};
+        a.x = j == 0 ? d_x : h->xbuf[j].ptr;
+        a.x_stride = j == 0 ? x_stride : len[j];
+        a.n = len[j];
+        a.in_f32 = j == 0 ? in_f32 : 0;
+        a.coef = h->coef.as<double>();
+        a.order = h->order.as<int>();
+        a.nfilt = h->nfilt;
+        a.dec_filter = h->bpo;
+        a.state = h->state.as<double>() + (size_t)j * h->stage_state_elems();
+        a.chunk = parallel ? (h->chunk0 >> j) : ((len[j] + 63) / 64 * 64);
+        if (a.chunk < 64) a.chunk = 64;
+        a.nchunks = parallel ? nchunks : 1;
+        a.chunk_end = h->chunk_end.as<double>();
+        a.chunk_init = h->chunk_init.as<double>();
+        a.y = d_y;
+        a.y_cstride = y_cstride;
+        for (int i = 0; i < h->bpo; ++i) {
+            const int k = (kNOctave - 1 - j) * h->bpo + i;
+            a.y_off[i] = band_off[k];
+            a.band_index[i] = k;
+        }
+        a.y_off[h->bpo] = 0;
+        a.band_index[h->bpo] = -1;
+        // the reference also runs the last octave's decimator (its state is carried), output unused
+        a.xnext = j + 1 < kNOctave ? h->xbuf[j + 1].as<double>() : nullptr;
+        a.xnext_stride = j + 1 < kNOctave ? len[j + 1] : 0;
+        a.eblock = d_eblock;
+        a.eblock_len = d_eblock ? (eblock0 >> j) : 1;
+        a.eblock_shift = 0;
+        while ((1 << a.eblock_shift) < a.eblock_len) ++a.eblock_shift;
+        a.nblocks = nblocks;
+        a.nbands = h->nbands;
+        a.alpha = h->alpha.as<double>();
+        if (a.n == 0) continue;
+        const dim3 grid(a.nchunks, (h->nfilt + 3) / 4, h->n_channels);
+        if (!parallel) {
+            a.pass = 0;
+            hipLaunchKernelGGL(iir_stage_kernel, grid, dim3(64), 0, h->stream, a);
+        } else {
+            a.pass = 1;
+            hipLaunchKernelGGL(iir_stage_kernel, grid, dim3(64), 0, h->stream, a);
+            const int total = h->n_channels * h->nfilt;
+            hipLaunchKernelGGL(iir_scan_kernel, dim3((total + 3) / 4), dim3(64), 0, h->stream,
+                               h->power.as<double>() + (size_t)j * h->nfilt * kStates * kStates, a.state,
+                               h->chunk_end.as<double>(), h->chunk_init.as<double>(), h->nfilt, a.nchunks, total);
+            a.pass = 2;
+            hipLaunchKernelGGL(iir_stage_kernel, grid, dim3(64), 0, h->stream, a);
+        }
+        FRT_HIP_CHECK(hipGetLastError());
+    }
+    return FRT_OK;
+}
+
+extern "C" int frt_octbank_filter(frt_octbank* h, const double* x, int n, double* y_packed, int* dec_out) {
+    FRT_REQUIRE(h && h->bpo >= 1, "frt_octbank_filter: needs a handle with bands");
+    FRT_REQUIRE(n >= 0, "frt_octbank_filter: n %d < 0", n);
+    if (dec_out)      // band k: dec = 2^(8 - k / bpo)  (octavefilters.py:60-63)
+        for (int k = 0; k < h->nbands; ++k) dec_out[k] = 1 << (kNOctave - 1 - k / h->bpo);
+    if (n == 0) {
+        set_last_error("Filter input is too small");      // decimate.py:33-34
+        return FRT_ERR_TOO_SMALL;
+    }
+    FRT_REQUIRE(x && y_packed, "frt_octbank_filter: null buffer");
+    const int64_t plen = frt_octbank_packed_length(h, n);
+    const bool dx = is_device_pointer(x), dy = is_device_pointer(y_packed);
+    FRT_REQUIRE(dx == dy, "frt_octbank_filter: input and output must both be host or both be device memory");
+    if (dx) return run_stages(h, x, 0, n, n, y_packed, plen, nullptr, 0, 0);
+    int rc;
+    if ((rc = h->xin.reserve((size_t)h->n_channels * n * sizeof(double))) ||
+        (rc = h->ypacked.reserve((size_t)h->n_channels * plen * sizeof(double))))
+        return rc;
+    FRT_HIP_CHECK(hipMemcpyAsync(h->xin.ptr, x, (size_t)h->n_channels * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if ((rc = run_stages(h, h->xin.ptr, 0, n, n, h->ypacked.as<double>(), plen, nullptr, 0, 0))) return rc;
+    FRT_HIP_CHECK(hipMemcpyAsync(y_packed, h->ypacked.ptr, (size_t)h->n_channels * plen * sizeof(double), hipMemcpyDeviceToHost,
+                                 h->stream));
+    FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return FRT_OK;
+}
+
+extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, int block, const double* alphas,
+                                    const double* weight_db, int as_db, float* energy_out) {
+    FRT_REQUIRE(h && h->bpo >= 1, "frt_octbank_energies: needs a handle with bands");
+    FRT_REQUIRE(block >= 256 && (block & (block - 1)) == 0, "frt_octbank_energies: block %d must be a power of two >= 256", block);
+    FRT_REQUIRE(n > 0 && n % block == 0 && n < (1ll << 31), "frt_octbank_energies: n must be a positive multiple of block");
+    FRT_REQUIRE(h->chunk0 == 0 || h->chunk0 % block == 0, "frt_octbank_energies: chunk must be a multiple of block");
+    FRT_REQUIRE(x && alphas && energy_out, "frt_octbank_energies: null buffer");
+    const int nblocks = (int)(n / block);
+    const size_t ecount = (size_t)h->n_channels * nblocks * h->nbands;
+    int rc;
+    std::vector<double> al(alphas, alphas + h->nbands), dn(h->nbands);
+    for (int k = 0; k < h->nbands; ++k)      // (1 - alpha)^n with n = block / dec samples of the band
+        dn[k] = std::pow(1.0 - al[k], (double)(block >> (kNOctave - 1 - k / h->bpo)));
+    if ((rc = upload(h->alpha, al)) || (rc = upload(h->decay_n, dn)) || (rc = h->eblock.reserve(ecount * sizeof(double)))) return rc;
+    if (weight_db) {
+        std::vector<double> w(weight_db, weight_db + h->nbands);
+        if ((rc = upload(h->weight, w))) return rc;
+    }
+    if (!h->smooth.ptr) {
+        if ((rc = h->smooth.reserve((size_t)h->n_channels * h->nbands * sizeof(double)))) return rc;
+        FRT_HIP_CHECK(hipMemsetAsync(h->smooth.ptr, 0, h->smooth.bytes, h->stream));
+    }
+    const bool dx = is_device_pointer(x), dout = is_device_pointer(energy_out);
+    FRT_REQUIRE(dx == dout, "frt_octbank_energies: input and output must both be host or both be device memory");
+    const void* d_x = x;
+    float* d_out = energy_out;
+    if (!dx) {
+        if ((rc = h->xin.reserve((size_t)h->n_channels * n * sizeof(float))) || (rc = h->eout.reserve(ecount * sizeof(float)))) return rc;
+        FRT_HIP_CHECK(hipMemcpyAsync(h->xin.ptr, x, (size_t)h->n_channels * n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        d_x = h->xin.ptr;
+        d_out = h->eout.as<float>();
+    }
+    if ((rc = run_stages(h, d_x, 1, n, (int)n, nullptr, 0, h->eblock.as<double>(), block, nblocks))) return rc;
+    const int total = h->n_channels * h->nbands;
+    hipLaunchKernelGGL(energy_scan_kernel, dim3((total + 63) / 64), dim3(64), 0, h->stream, h->eblock.as<double>(),
+                       h->decay_n.as<double>(), h->smooth.as<double>(), (void*)d_out, 1, nblocks, h->nbands, total,
+                       weight_db ? h->weight.as<double>() : nullptr, as_db);
+    FRT_HIP_CHECK(hipGetLastError());
+    if (!dx) {
+        FRT_HIP_CHECK(hipMemcpyAsync(energy_out, d_out, ecount * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
+    return FRT_OK;
+}
+
+// ---- G2: stand-alone decimation chain (decimate_multiple, friture/signal/decimate.py:45-71) -------
+// A handle with bands_per_octave = 0 carries only the decimator; `n_stages` of its nine stages run.
+extern "C" int frt_decimate_multiple(frt_octbank* h, int n_stages, const double* x, int n, double* out, int* n_out) {
+    FRT_REQUIRE(h && h->bpo == 0, "frt_decimate_multiple: needs a handle created with bands_per_octave = 0");
+    FRT_REQUIRE(n_stages >= 1 && n_stages < kNOctave, "frt_decimate_multiple: n_stages %d not in [1, 8]", n_stages);
+    FRT_REQUIRE(n >= 0, "frt_decimate_multiple: n < 0");
+    int len[kNOctave];
+    stage_lengths(n, len);
+    if (n_out) *n_out = len[n_stages];
+    if (n == 0) return FRT_OK;                  // decimate.py:56-57: empty input is passed through
+    FRT_REQUIRE(x && out, "frt_decimate_multiple: null buffer");
+    const bool dx = is_device_pointer(x), dout = is_device_pointer(out);
+    FRT_REQUIRE(dx == dout, "frt_decimate_multiple: input and output must both be host or both be device memory");
+    int rc;
+    const void* d_x = x;
+    if (!dx) {
+        if ((rc = h->xin.reserve((size_t)h->n_channels * n * sizeof(double)))) return rc;
+        FRT_HIP_CHECK(hipMemcpyAsync(h->xin.ptr, x, (size_t)h->n_channels * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        d_x = h->xin.ptr;
+    }
+    for (int j = 1; j <= n_stages; ++j)
+        if ((rc = h->xbuf[j].reserve((size_t)h->n_channels * len[j] * sizeof(double)))) return rc;
+    for (int j = 0; j < n_stages; ++j) {
+        IirStageArgs a{};
+        a.x = j == 0 ? d_x : h->xbuf[j].ptr;
+        a.x_stride = len[j];
+        a.n = len[j];
+        a.coef = h->coef.as<double>();
+        a.order = h->order.as<int>();
+        a.nfilt = 1;
+        a.dec_filter = 0;
+        a.state = h->state.as<double>() + (size_t)j * h->stage_state_elems();
+        a.chunk = (len[j] + 63) / 64 * 64;
+        a.nchunks = 1;
+        a.pass = 0;
+        a.band_index[0] = -1;
+        a.xnext = h->xbuf[j + 1].as<double>();
+        a.xnext_stride = len[j + 1];
+        hipLaunchKernelGGL(iir_stage_kernel, dim3(1, 1, h->n_channels), dim3(64), 0, h->stream, a);
+        FRT_HIP_CHECK(hipGetLastError());
+    }
+    const size_t obytes = (size_t)h->n_channels * len[n_stages] * sizeof(double);
+    FRT_HIP_CHECK(hipMemcpyAsync(out, h->xbuf[n_stages].ptr, obytes, dx ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    if (!dx) FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return FRT_OK;
+}
+
+// ---- lfilter_float64_1D (friture/signal/lfilter.py:85-147): one filter, explicit state in / out ----
+extern "C" int frt_lfilter_f64(const double* b, const double* a, int n_coef, const double* x, int n, const double* zi,
+                               double* y, double* zf) {
+    FRT_REQUIRE(b && a && n_coef >= 1 && n_coef <= kMaxOrder + 1, "frt_lfilter_f64: 1 <= len(b) = len(a) <= %d required",
+                kMaxOrder + 1);
+    FRT_REQUIRE(n >= 0 && (n == 0 || (x && y)), "frt_lfilter_f64: bad buffers");
+    FRT_REQUIRE(n_coef == 1 || (zi && zf), "frt_lfilter_f64: state vectors required");
+    const int order = n_coef - 1;
+    if (order == 0) {                                   // lfilter.py:140-142: pure gain
+        for (int k = 0; k < n; ++k) y[k] = x[k] * b[0];
+        return FRT_OK;
+    }
+    if (n == 0) {
+        for (int s = 0; s < order; ++s) zf[s] = zi[s];
+        return FRT_OK;
+    }
+    std::vector<double> coef(kCoefStride, 0.0), st(kStates, 0.0);
+    for (int t = 0; t < n_coef; ++t) {
+        coef[t] = b[t];
+        coef[kMaxOrder + 1 + t] = a[t];
+    }
+    for (int s = 0; s < order; ++s) st[s] = zi[s];
+    DeviceBuffer dcoef, dorder, dstate, dx, dy;
+    std::vector<int> ord(1, order);
+    int rc;
+    auto cleanup = [&]() { dcoef.release(); dorder.release(); dstate.release(); dx.release(); dy.release(); };
+    if ((rc = upload(dcoef, coef)) || (rc = upload(dorder, ord)) || (rc = upload(dstate, st)) ||
+        (rc = dx.reserve((size_t)n * sizeof(double))) || (rc = dy.reserve((size_t)n * sizeof(double)))) {
+        cleanup();
+        return rc;
+    }
+    hipError_t e = hipMemcpy(dx.ptr, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+    IirStageArgs s{};
+    s.x = dx.ptr;
+    s.x_stride = n;
+    s.n = n;
+    s.coef = dcoef.as<double>();
+    s.order = dorder.as<int>();
+    s.nfilt = 1;
+    s.dec_filter = -1;
+    s.state = dstate.as<double>();
+    s.chunk = (n + 63) / 64 * 64;
+    s.nchunks = 1;
+    s.pass = 0;
+    s.y = dy.as<double>();
+    s.y_cstride = n;
+    s.band_index[0] = -1;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(iir_stage_kernel, dim3(1, 1, 1), dim3(64), 0, nullptr, s);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(y, dy.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(st.data(), dstate.ptr, kStates * sizeof(double), hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) {
+        set_last_error("frt_lfilter_f64: %s", hipGetErrorString(e));
+        return FRT_ERR_HIP;
+    }
+    for (int t = 0; t < order; ++t) zf[t] = st[t];
+    return FRT_OK;
+}

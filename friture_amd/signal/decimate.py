@@ -1,0 +1,76 @@
+"""friture/signal/decimate.py:27-84 on the GPU: decimate, decimate_multiple, decimate_multiple_filtic.
+
+Same functional interface as the reference (filter states are passed in and returned).  The chain
+of `Ndec` low-pass + take-every-other stages runs as `Ndec` launches of the IIR stage kernel on a
+decimator-only bank handle (frt_decimate_multiple); handles are cached per coefficient set.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from .. import _lib
+from .lfilter import lfilter_float64_1D
+
+_DP = ctypes.POINTER(ctypes.c_double)
+_handles: dict = {}
+
+
+def _chain_handle(bdec, adec):
+    key = (bdec.tobytes(), adec.tobytes())
+    h = _handles.get(key)
+    if h is None:
+        lib = _lib.init()
+        h = ctypes.c_void_p()
+        _lib.check(lib.frt_octbank_create(ctypes.byref(h), 0, 1, 0, None, None, bdec.ctypes.data_as(_DP),
+                                          adec.ctypes.data_as(_DP), None, None))
+        _handles[key] = h
+    return h
+
+
+def decimate(bdec, adec, x, zi=None):
+    if len(x) == 0:
+        raise Exception("Filter input is too small")
+    if zi is None:
+        zi = np.zeros(max(len(bdec), len(adec)) - 1, dtype=np.float64)
+    x_dec, zf = lfilter_float64_1D(bdec, adec, x, zi)
+    return x_dec[::2], zf
+
+
+def decimate_multiple(Ndec, bdec, adec, x, zis):
+    """Decimate Ndec times by 2; zis is a list of Ndec state vectors (or None for zero state,
+    in which case no state is returned)."""
+    x = np.ascontiguousarray(x, np.float64)
+    if x.size == 0:
+        return x, zis
+    bdec = np.ascontiguousarray(bdec, np.float64)
+    adec = np.ascontiguousarray(adec, np.float64)
+    if len(bdec) != 13 or len(adec) != 13 or Ndec > 8:
+        # not the bank's 12th-order decimator: chain single-filter calls
+        out, zfs = x, []
+        for i in range(Ndec):
+            out, zf = decimate(bdec, adec, out, None if zis is None else zis[i])
+            zfs.append(zf)
+        return out, (None if zis is None else zfs)
+    lib = _lib.init()
+    h = _chain_handle(bdec, adec)
+    slen = lib.frt_octbank_state_length(h)
+    state = np.zeros(slen, np.float64)
+    if zis is not None:
+        for j, z in zip(range(Ndec), zis):
+            state[12 * j:12 * (j + 1)] = z
+    _lib.check(lib.frt_octbank_set_state(h, state.ctypes.data_as(_DP)))
+    n_out = ctypes.c_int(0)
+    out = np.empty(len(x), np.float64)      # upper bound
+    _lib.check(lib.frt_decimate_multiple(h, int(Ndec), x.ctypes.data, len(x), out.ctypes.data, ctypes.byref(n_out)))
+    out = out[:n_out.value].copy()
+    if zis is None:
+        return out, None
+    _lib.check(lib.frt_octbank_get_state(h, state.ctypes.data_as(_DP)))
+    return out, [state[12 * j:12 * (j + 1)].copy() for j in range(Ndec)]
+
+
+def decimate_multiple_filtic(Ndec, bdec, adec):
+    """Zero initial conditions for the subsampler."""
+    return [np.zeros(max(len(bdec), len(adec)) - 1) for _ in range(Ndec)]

@@ -88,6 +88,60 @@ int64_t frt_stft_frames_for(const frt_stft* h, int64_t T);
 /* Tuning hook (bench / tests): frames a workgroup lane-group processes back to back; 0 = auto. */
 int frt_stft_set_run_length(frt_stft* h, int frames_per_run);
 
+/* ---- K2 / K4: octave filter bank with decimation, band energies -------------------------------
+ * mode 0 replaces the exact IIR bank octave_filter_bank_decimation (friture/filter.py:86-118) built
+ * on lfilter_float64_1D (friture/signal/lfilter.py:85-147) and decimate
+ * (friture/signal/decimate.py:27-42): 9 octaves, `bands_per_octave` 4th-order band-passes per
+ * octave on the j-times decimated signal, 12th-order elliptic decimator between octaves, carried
+ * state.  Sequential mode is bit-identical to the reference; the time-parallel mode
+ * (frt_octbank_set_chunk) evaluates the same recurrences chunk-wise and agrees to rounding.
+ * mode 1 (the FFT overlap-add bank of Octave_Filters.filter, friture/octavefilters.py:49-58 /
+ * friture/filter.py:136-247) is served by frt_olabank_* below.
+ *
+ * Band order everywhere is the reference's list order: band k = 0 is the lowest band
+ * (dec = 256), band 9*bpo-1 the highest (dec = 1); dec[k] = 2^(8 - k / bpo). */
+typedef struct frt_octbank frt_octbank;
+
+/* boct/aoct: [bands_per_octave][5]; bdec/adec: [13] (friture/generated_filters.py PARAMS);
+ * boct_fir/bdec_fir are only used by mode 1 and may be NULL.  bands_per_octave = 0 creates a
+ * decimator-only handle for frt_decimate_multiple. */
+int frt_octbank_create(frt_octbank** h, int bands_per_octave, int n_channels, int mode, const double* boct,
+                       const double* aoct, const double* bdec, const double* adec, const double* boct_fir,
+                       const double* bdec_fir);
+void frt_octbank_destroy(frt_octbank* h);
+int frt_octbank_set_stream(frt_octbank* h, void* hip_stream);
+/* zero every carried state (octave_filter_bank_decimation_filtic, friture/filter.py:121-133) */
+int frt_octbank_reset(frt_octbank* h);
+/* 0 (default): sequential in time, bit-identical to the reference.  chunk0 > 0 (multiple of 16384):
+ * batches of at least 2*chunk0 samples are processed time-parallel in chunks of chunk0 samples. */
+int frt_octbank_set_chunk(frt_octbank* h, int chunk0);
+/* doubles per channel in the packed output for n input samples: sum over bands of ceil(n / dec) */
+int64_t frt_octbank_packed_length(const frt_octbank* h, int n);
+/* x: [n_channels][n]; y_packed: [n_channels][packed_length], band k stored after band k-1;
+ * dec_out: [9*bpo] or NULL.  n = 0 -> FRT_ERR_TOO_SMALL ("Filter input is too small",
+ * friture/signal/decimate.py:33-34). */
+int frt_octbank_filter(frt_octbank* h, const double* x, int n, double* y_packed, int* dec_out);
+/* carried filter states per channel in the reference's zis/zfs order (friture/filter.py:121-133):
+ * per octave the band states i = bpo-1..0 (4 doubles each) then the decimator's 12. */
+int frt_octbank_state_length(const frt_octbank* h);
+int frt_octbank_get_state(frt_octbank* h, double* z /* [n_channels][state_length] */);
+int frt_octbank_set_state(frt_octbank* h, const double* z);
+/* Band energies of OctaveSpectrum_Widget.handle_new_data (friture/octavespectrum.py:101-121) for a
+ * whole batch: x float [n_channels][n] is cut in blocks of `block` samples (power of two >= 256, the
+ * widget's chunk), per block and band sp = alpha*sum_i (1-alpha)^(m-1-i) y_i^2 + sp_prev*(1-alpha)^m
+ * (friture/signal/exp_smoothing.py:40-56; m = block/dec), carried across blocks and calls.
+ * energy_out: float [n_channels][n/block][9*bpo]; as_db != 0 stores 10 log10(sp + 1e-30) + weight_db[k]
+ * (weight_db may be NULL) instead of sp.  The band signals themselves are not written. */
+int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, int block, const double* alphas,
+                         const double* weight_db, int as_db, float* energy_out);
+/* decimate_multiple (friture/signal/decimate.py:45-71) with carried state: n_stages chained
+ * decimations by 2 of x [n_channels][n] -> out [n_channels][*n_out].  Needs a bands_per_octave = 0 handle. */
+int frt_decimate_multiple(frt_octbank* h, int n_stages, const double* x, int n, double* out, int* n_out);
+/* lfilter_float64_1D (friture/signal/lfilter.py:85-147): direct form II transposed IIR of one host
+ * signal with explicit state; len(b) = len(a) = n_coef <= 16, zi/zf hold n_coef-1 doubles. */
+int frt_lfilter_f64(const double* b, const double* a, int n_coef, const double* x, int n, const double* zi,
+                    double* y, double* zf);
+
 #ifdef __cplusplus
 }
 #endif

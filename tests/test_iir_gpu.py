@@ -1,0 +1,150 @@
+"""K2/K4/G2 parity: exact IIR octave bank, decimation chain, band energies.
+
+Sequential mode must be *bit-identical* to the reference (golden fixtures recorded from
+friture.filter.octave_filter_bank_decimation and friture.signal.decimate) — float64, same IEEE
+operations in the same order.  The time-parallel mode re-associates the linear recurrence; the 12th-order
+direct-form decimator amplifies rounding by ~1e4 (its DF2T states are much larger than its output), so
+the two modes agree to ~1e-10 of the *input* scale after nine cascaded stages; bands that a tone
+barely excites have a small maximum, so the per-band gate is 1e-7 of the band maximum.  Band energies (the metric's band-energy vector): |E/E_ref - 1| <= 1e-5.
+"""
+import numpy as np
+import pytest
+
+from conftest import synth
+from oracle import dsp
+
+pytestmark = pytest.mark.gpu
+
+
+def f64(x):
+    return np.asarray(x, np.float32).astype(np.float64)
+
+
+@pytest.fixture(scope="module")
+def tabs(hip):
+    return dsp.load_filter_tables()
+
+
+def test_lfilter_bit_exact(golden, tabs):
+    from friture_amd.signal.lfilter import lfilter_float64_1D
+    x = f64(golden("iir")["x_dec"])[:700]
+    y, zf = lfilter_float64_1D(tabs["bdec"], tabs["adec"], x, np.zeros(12))
+    yo, zo = dsp.lfilter_df2t(tabs["bdec"], tabs["adec"], x, np.zeros(12))
+    assert np.array_equal(y, yo) and np.array_equal(zf, zo)
+    # restart from the carried state, band-pass filter, ragged length
+    b, a = tabs["boct_3"][1], tabs["aoct_3"][1]
+    y1, z1 = lfilter_float64_1D(b, a, x[:333], np.zeros(4))
+    y2, z2 = lfilter_float64_1D(b, a, x[333:], z1)
+    yo, zo = dsp.lfilter_df2t(b, a, x, np.zeros(4))
+    assert np.array_equal(np.concatenate([y1, y2]), yo) and np.array_equal(z2, zo)
+    # pure gain and empty input (lfilter.py:140-142)
+    y, zf = lfilter_float64_1D(np.array([0.5]), np.array([1.0]), x[:5], np.zeros(0))
+    assert np.array_equal(y, 0.5 * x[:5])
+    with pytest.raises(AssertionError):
+        lfilter_float64_1D(b, a[:4], x, np.zeros(4))
+
+
+def test_decimate_multiple_against_golden(golden, tabs):
+    from friture_amd.signal import decimate as D
+    g = golden("iir")
+    x = f64(g["x_dec"])
+    zs = D.decimate_multiple_filtic(2, tabs["bdec"], tabs["adec"])
+    for c in range(4):
+        y, zs = D.decimate_multiple(2, tabs["bdec"], tabs["adec"], x[c * 512:(c + 1) * 512], zs)
+        assert np.array_equal(y, g[f"dec2_{c}"])
+    y, zf = D.decimate(tabs["bdec"], tabs["adec"], x[:101])
+    yo, zo = dsp.decimate(tabs["bdec"], tabs["adec"], x[:101])
+    assert np.array_equal(y, yo) and np.array_equal(zf, zo) and len(y) == 51
+    with pytest.raises(Exception, match="too small"):
+        D.decimate(tabs["bdec"], tabs["adec"], np.zeros(0))
+    e, z = D.decimate_multiple(2, tabs["bdec"], tabs["adec"], np.zeros(0), None)
+    assert e.size == 0 and z is None
+
+
+@pytest.mark.parametrize("bpo", [1, 3, 6, 12, 24])
+def test_iir_bank_against_golden(golden, tabs, bpo):
+    from friture_amd import filter as F
+    g = golden("iir")
+    boct, aoct = list(tabs[f"boct_{bpo}"]), list(tabs[f"aoct_{bpo}"])
+    zs = F.octave_filter_bank_decimation_filtic(tabs["bdec"], tabs["adec"], boct, aoct)
+    x = f64(g[f"bank{bpo}_x"])
+    for blk in range(2):
+        y, dec, zs = F.octave_filter_bank_decimation(tabs["bdec"], tabs["adec"], boct, aoct, x[blk * 1024:(blk + 1) * 1024], zs)
+        assert np.array_equal(np.array([np.sum(v ** 2) for v in y]), g[f"bank{bpo}_energy_{blk}"])
+        if bpo == 3:
+            for k in range(27):
+                assert np.array_equal(y[k], g[f"bank3_y_{blk}_{k}"])
+    assert np.array_equal(np.array(dec), g[f"bank{bpo}_dec"])
+    assert np.array_equal(np.concatenate(zs), g[f"bank{bpo}_zf"])
+
+
+def test_iir_bank_ragged_blocks_and_channels(tabs):
+    """odd block lengths (x[::2] keeps ceil(n/2) samples), several channels, against the oracle"""
+    from friture_amd.filter import IirBank
+    bpo = 3
+    boct, aoct = list(tabs[f"boct_{bpo}"]), list(tabs[f"aoct_{bpo}"])
+    bank = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, n_channels=3)
+    x = np.stack([synth("noise", 3000, 1), synth("tone", 3000, 2), synth("chirp", 3000, 3)]).astype(np.float64)
+    zs = [dsp.iir_bank_filtic(tabs["bdec"], tabs["adec"], boct, aoct) for _ in range(3)]
+    pos = 0
+    for n in (1000, 777, 1, 1222):
+        got, dec = bank.filter(x[:, pos:pos + n])
+        for c in range(3):
+            ref, dref, zs[c] = dsp.iir_bank(tabs["bdec"], tabs["adec"], boct, aoct, x[c, pos:pos + n], zs[c])
+            assert dec == dref
+            for k in range(27):
+                assert np.array_equal(got[c][k], ref[k]), (n, c, k)
+        pos += n
+    with pytest.raises(Exception, match="too small"):
+        bank.filter(np.zeros((3, 0)))
+
+
+def test_time_parallel_mode_matches_sequential(tabs):
+    from friture_amd.filter import IirBank
+    bpo = 3
+    boct, aoct = list(tabs[f"boct_{bpo}"]), list(tabs[f"aoct_{bpo}"])
+    n = 5 * 16384 + 4096
+    x = np.stack([synth("noise", n, 5), synth("tone", n, 6)]).astype(np.float64)
+    seq = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, 2)
+    par = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, 2)
+    par.set_chunk(16384)
+    # warm both with a first block so that the scan starts from a non-zero carried state
+    seq.filter(x[:, :4096])
+    par.filter(x[:, :4096])
+    ys, _ = seq.filter(x[:, 4096:])
+    yp, _ = par.filter(x[:, 4096:])
+    for c in range(2):
+        for k in range(27):
+            err = np.max(np.abs(yp[c][k] - ys[c][k])) / np.max(np.abs(ys[c][k]))
+            assert err < 1e-7, (c, k, err)
+    assert np.max(np.abs(par.get_state() - seq.get_state())) < 1e-9 * np.max(np.abs(seq.get_state()))
+
+
+@pytest.mark.parametrize("bpo,chunk", [(3, 0), (3, 16384), (24, 16384)])
+def test_band_energies(tabs, bpo, chunk):
+    """frt_octbank_energies against the oracle's widget restatement: filter, y^2, exp smoothing."""
+    from friture_amd.filter import IirBank
+    boct, aoct = list(tabs[f"boct_{bpo}"]), list(tabs[f"aoct_{bpo}"])
+    nblocks = 48 if chunk else 6
+    n = 1024 * nblocks
+    C = 2
+    x32 = np.stack([synth("noise", n, 11), synth("chirp", n, 12)])
+    alphas, kernels = dsp.band_smoothing_setup(bpo, 0.125)
+    bank = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, C)
+    bank.set_chunk(chunk)
+    got = bank.energies(x32, 1024, alphas)
+    assert got.shape == (C, nblocks, 9 * bpo)
+    for c in range(C if bpo == 3 else 1):
+        zs = dsp.iir_bank_filtic(tabs["bdec"], tabs["adec"], boct, aoct)
+        prev = [0.0] * (9 * bpo)
+        for blk in range(nblocks):
+            y, _, zs = dsp.iir_bank(tabs["bdec"], tabs["adec"], boct, aoct, x32[c, blk * 1024:(blk + 1) * 1024].astype(np.float64), zs)
+            prev = dsp.band_energies(y, kernels, alphas, prev)
+            ref = np.array(prev)
+            assert np.max(np.abs(got[c, blk] / ref - 1)) <= 1e-5, (c, blk)
+    # dB read-out with A weighting (octavespectrum.py:114-121)
+    fi, _, _ = dsp.octave_frequencies(9 * bpo, bpo)
+    A = dsp.band_weighting(fi)[0]
+    bank.reset()
+    db = bank.energies(x32, 1024, alphas, weight_db=A, as_db=True)
+    assert np.max(np.abs(db - (10 * np.log10(got.astype(np.float64) + 1e-30) + A))) < 1e-3
