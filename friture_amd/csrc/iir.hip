@@ -30,14 +30,10 @@
 #include <cmath>
 
 #include "common.h"
+#include "octbank.h"
 
 namespace frt {
 
-constexpr int kStates = 16;        // one DPP row per filter
-constexpr int kMaxOrder = 15;
-constexpr int kCoefStride = 2 * (kMaxOrder + 1);   // b[0..15], a[0..15]
-constexpr int kMaxFilters = 25;    // 24 band-passes + decimator
-constexpr int kNOctave = 9;
 
 struct IirStageArgs {
     const void* x;             // [C][x_stride] stage input
@@ -260,24 +256,6 @@ static void transition_power(const double* a_coef, int order, long long L, doubl
 
 using namespace frt;
 
-struct frt_octbank {
-    int bpo = 0, n_channels = 0, mode = 0, nbands = 0, nfilt = 0;
-    int chunk0 = 0;                         // 0 = sequential (bit exact); else samples per chunk at octave 0
-    hipStream_t stream = nullptr;
-    std::vector<double> h_coef;             // [nfilt][kCoefStride]
-    std::vector<int> h_order;
-    DeviceBuffer coef, order, state;        // state: [9][C][nfilt][16]
-    DeviceBuffer xin, ypacked, xbuf[kNOctave], chunk_end, chunk_init, power;
-    DeviceBuffer eblock, alpha, decay_n, smooth, weight, eout;
-    int power_chunk0 = -1;
-    size_t stage_state_elems() const { return (size_t)n_channels * nfilt * kStates; }
-};
-
-static void stage_lengths(int n, int* len) {
-    len[0] = n;
-    for (int j = 1; j < kNOctave; ++j) len[j] = (len[j - 1] + 1) / 2;     // x[::2]
-}
-
 extern "C" int64_t frt_octbank_packed_length(const frt_octbank* h, int n) {
     if (!h || n < 0) return 0;
     int len[kNOctave];
@@ -297,10 +275,10 @@ extern "C" int frt_octbank_create(frt_octbank** out, int bands_per_octave, int n
     FRT_REQUIRE(bands_per_octave >= 0 && bands_per_octave <= 24, "frt_octbank_create: bands_per_octave %d not in [0, 24]",
                 bands_per_octave);
     FRT_REQUIRE(n_channels >= 1, "frt_octbank_create: n_channels %d < 1", n_channels);
-    FRT_REQUIRE(mode == 0, "frt_octbank_create: mode %d is not available in this build (0 = exact IIR)", mode);
+    FRT_REQUIRE(mode == 0 || mode == 1, "frt_octbank_create: mode %d unknown (0 = exact IIR, 1 = FFT overlap-add)", mode);
+    FRT_REQUIRE(mode == 0 || (boct_fir && bdec_fir && bands_per_octave >= 1),
+                "frt_octbank_create: mode 1 needs the FIR taps and at least one band per octave");
     FRT_REQUIRE(bdec && adec && (bands_per_octave == 0 || (boct && aoct)), "frt_octbank_create: null coefficients");
-    (void)boct_fir;
-    (void)bdec_fir;
     frt_octbank* h = new frt_octbank();
     h->bpo = bands_per_octave;
     h->n_channels = n_channels;
@@ -332,12 +310,17 @@ extern "C" int frt_octbank_create(frt_octbank** out, int bands_per_octave, int n
         frt_octbank_destroy(h);
         return FRT_ERR_HIP;
     }
+    if (mode == 1 && (rc = frt_ola_create(h, boct_fir, bdec_fir))) {
+        frt_octbank_destroy(h);
+        return rc;
+    }
     *out = h;
     return FRT_OK;
 }
 
 extern "C" void frt_octbank_destroy(frt_octbank* h) {
     if (!h) return;
+    frt_ola_destroy(h);
     DeviceBuffer* bufs[] = {&h->coef, &h->order, &h->state, &h->xin, &h->ypacked, &h->chunk_end, &h->chunk_init, &h->power,
                             &h->eblock, &h->alpha, &h->decay_n, &h->smooth, &h->weight, &h->eout};
     for (auto* b : bufs) b->release();
@@ -362,6 +345,10 @@ extern "C" int frt_octbank_set_chunk(frt_octbank* h, int chunk0) {
 extern "C" int frt_octbank_reset(frt_octbank* h) {
     FRT_REQUIRE(h, "frt_octbank_reset: null handle");
     FRT_HIP_CHECK(hipMemsetAsync(h->state.ptr, 0, h->state.bytes, h->stream));
+    if (h->ola) {
+        int rc = frt_ola_reset(h);
+        if (rc) return rc;
+    }
     if (h->smooth.ptr) FRT_HIP_CHECK(hipMemsetAsync(h->smooth.ptr, 0, h->smooth.bytes, h->stream));
     return FRT_OK;
 }
@@ -510,13 +497,16 @@ extern "C" int frt_octbank_filter(frt_octbank* h, const double* x, int n, double
     const int64_t plen = frt_octbank_packed_length(h, n);
     const bool dx = is_device_pointer(x), dy = is_device_pointer(y_packed);
     FRT_REQUIRE(dx == dy, "frt_octbank_filter: input and output must both be host or both be device memory");
-    if (dx) return run_stages(h, x, 0, n, n, y_packed, plen, nullptr, 0, 0);
+    if (h->mode == 1) FRT_REQUIRE(n <= 1024, "frt_octbank_filter: the FFT bank takes blocks of at most 1024 samples (got %d)", n);
+    if (dx) return h->mode == 1 ? frt_ola_filter(h, x, n, y_packed, plen) : run_stages(h, x, 0, n, n, y_packed, plen, nullptr, 0, 0);
     int rc;
     if ((rc = h->xin.reserve((size_t)h->n_channels * n * sizeof(double))) ||
         (rc = h->ypacked.reserve((size_t)h->n_channels * plen * sizeof(double))))
         return rc;
     FRT_HIP_CHECK(hipMemcpyAsync(h->xin.ptr, x, (size_t)h->n_channels * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if ((rc = run_stages(h, h->xin.ptr, 0, n, n, h->ypacked.as<double>(), plen, nullptr, 0, 0))) return rc;
+    rc = h->mode == 1 ? frt_ola_filter(h, h->xin.as<double>(), n, h->ypacked.as<double>(), plen)
+                      : run_stages(h, h->xin.ptr, 0, n, n, h->ypacked.as<double>(), plen, nullptr, 0, 0);
+    if (rc) return rc;
     FRT_HIP_CHECK(hipMemcpyAsync(y_packed, h->ypacked.ptr, (size_t)h->n_channels * plen * sizeof(double), hipMemcpyDeviceToHost,
                                  h->stream));
     FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -526,6 +516,7 @@ extern "C" int frt_octbank_filter(frt_octbank* h, const double* x, int n, double
 extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, int block, const double* alphas,
                                     const double* weight_db, int as_db, float* energy_out) {
     FRT_REQUIRE(h && h->bpo >= 1, "frt_octbank_energies: needs a handle with bands");
+    FRT_REQUIRE(h->mode == 0, "frt_octbank_energies: batch energies run on the exact IIR bank (mode 0)");
     FRT_REQUIRE(block >= 256 && (block & (block - 1)) == 0, "frt_octbank_energies: block %d must be a power of two >= 256", block);
     FRT_REQUIRE(n > 0 && n % block == 0 && n < (1ll << 31), "frt_octbank_energies: n must be a positive multiple of block");
     FRT_REQUIRE(h->chunk0 == 0 || h->chunk0 % block == 0, "frt_octbank_energies: chunk must be a multiple of block");

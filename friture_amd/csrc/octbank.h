@@ -1,0 +1,49 @@
+// octbank.h — the octave-bank handle shared by the exact IIR path (iir.hip) and the FFT
+// overlap-add path (ola.hip).
+#pragma once
+#include "common.h"
+#include "fft_mixed.h"
+
+namespace frt {
+constexpr int kStates = 16;        // one DPP row per filter
+constexpr int kMaxOrder = 15;
+constexpr int kCoefStride = 2 * (kMaxOrder + 1);   // b[0..15], a[0..15]
+constexpr int kMaxFilters = 25;    // 24 band-passes + decimator
+constexpr int kNOctave = 9;        // friture/filter.py:7
+constexpr int kFirLength = 512;    // friture/octavefilters.py:35
+constexpr int kTail = kFirLength - 1;
+
+inline void stage_lengths(int n, int* len) {
+    len[0] = n;
+    for (int j = 1; j < kNOctave; ++j) len[j] = (len[j - 1] + 1) / 2;     // x[::2]
+}
+}  // namespace frt
+
+// overlap-add state of mode 1 (ola.hip)
+struct frt_ola_state {
+    int fft_size[frt::kNOctave];
+    frt::MixedPlan plan[frt::kNOctave];
+    frt::DeviceBuffer tw[frt::kNOctave], twl[frt::kNOctave], H[frt::kNOctave];
+    frt::DeviceBuffer pending;          // [9][C][nfilt][511]
+};
+
+struct frt_octbank {
+    int bpo = 0, n_channels = 0, mode = 0, nbands = 0, nfilt = 0;
+    int chunk0 = 0;                         // 0 = sequential (bit exact); else samples per chunk at octave 0
+    hipStream_t stream = nullptr;
+    std::vector<double> h_coef;             // [nfilt][kCoefStride]
+    std::vector<int> h_order;
+    frt::DeviceBuffer coef, order, state;        // state: [9][C][nfilt][16]
+    frt::DeviceBuffer xin, ypacked, xbuf[frt::kNOctave], chunk_end, chunk_init, power;
+    frt::DeviceBuffer eblock, alpha, decay_n, smooth, weight, eout;
+    int power_chunk0 = -1;
+    frt_ola_state* ola = nullptr;
+    size_t stage_state_elems() const { return (size_t)n_channels * nfilt * frt::kStates; }
+};
+
+
+// implemented in ola.hip
+int frt_ola_create(frt_octbank* h, const double* boct_fir, const double* bdec_fir);
+void frt_ola_destroy(frt_octbank* h);
+int frt_ola_reset(frt_octbank* h);
+int frt_ola_filter(frt_octbank* h, const double* d_x, int n, double* d_y, int64_t y_cstride);
