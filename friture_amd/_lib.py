@@ -16,6 +16,12 @@ LIB_PATH = Path(__file__).resolve().parent / "lib" / "libfriture_hip.so"
 FRT_STFT_PSD, FRT_STFT_DB, FRT_STFT_NORM, FRT_STFT_IMAGE = 0, 1, 2, 3
 
 
+class DelayReadout(ctypes.Structure):
+    """frt_delay_readout of include/friture_hip.h"""
+    _fields_ = [("argmax", c_int), ("correlation_pct", c_int), ("delay_ms", c_double), ("distance_m", c_double),
+                ("extremum", c_double)]
+
+
 class FritureHipError(RuntimeError):
     """A C-ABI call returned a negative status (the message is frt_last_error())."""
 
@@ -53,6 +59,11 @@ SIGNATURES = {
     "frt_octbank_energies": (c_int, [c_void_p, c_void_p, c_int64, c_int, POINTER(c_double), POINTER(c_double), c_int,
                                      c_void_p]),
     "frt_decimate_multiple": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, POINTER(c_int)]),
+    "frt_gcc_create": (c_int, [POINTER(c_void_p), c_int, c_int]),
+    "frt_gcc_destroy": (None, [c_void_p]),
+    "frt_gcc_set_stream": (c_int, [c_void_p, c_void_p]),
+    "frt_gcc_phat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "frt_gcc_readout": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_void_p, c_void_p]),
     "frt_lfilter_f64": (c_int, [POINTER(c_double), POINTER(c_double), c_int, POINTER(c_double), c_int, POINTER(c_double),
                                 POINTER(c_double), POINTER(c_double)]),
 }

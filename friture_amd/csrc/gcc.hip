@@ -1,0 +1,413 @@
+// gcc.hip — K5: generalised cross-correlation with phase transform (GCC-PHAT) and the delay
+// read-out, for gfx950.
+//
+// Reference semantics:
+//   generalized_cross_correlation(d0, d1)                     friture/signal/correlation.py:24-43
+//       d0 -= mean(d0); d1 -= mean(d1)          (in place on the caller's arrays)
+//       w = numpy.hanning(L);  D0 = rfft(d0 w);  D1 = rfft(d1 w)
+//       G = conj(D0) D1;  W = 1 / (1e-10 max|G| + |G|);  Xcorr = irfft(W G)
+//   read-out (Delay_Estimator_Widget.handle_new_data)          friture/delay_estimator.py:134-176
+//       smoothed = 0.3 Xcorr + 0.7 old;  i = argmax |smoothed|;  delay_ms = 1e3 i / rate (wrapped);
+//       confidence from |smoothed[i]| / (3 std(smoothed))
+//
+// Kernel shape: one workgroup of 1024 threads per channel pair / window, float64.  A real
+// transform of length L is a complex transform of length M = L/2; M = R * M2 is split DIT-wise
+// into R interleaved sub-transforms of length M2 <= 6144 so that one sub-transform (96 KB of
+// complex doubles) fits in LDS next to nothing else; sub-spectra and the cross spectrum pass
+// through an HBM scratch slab owned by the workgroup (L2 resident: 64 bytes per complex point of
+// M).  The default L = 24000 = 2 * 2 * 6000 (friture/delay_estimator.py:114-115) runs R = 2.
+#include <cmath>
+
+#include "common.h"
+#include "fft_mixed.h"
+
+namespace frt {
+
+constexpr int kGccThreads = 1024;
+constexpr int kGccMaxM2 = 6144;
+constexpr int kGccMaxB = 3;            // ceil((6144 / 2) / 1024)
+constexpr int kGccMaxR = 4;
+
+struct GccArgs {
+    const double* d0;      // [pairs][L]
+    const double* d1;
+    double* xcorr;         // [pairs][L]
+    int* argmax;           // [pairs] or null
+    double* means;         // [pairs][2] or null
+    const double* window;  // [L] numpy.hanning(L)
+    const double* twm;     // [M] exp(-2 pi i t / M)
+    const double* tw2;     // [M2] exp(-2 pi i t / M2)
+    const double* twl;     // [M+1] exp(-2 pi i k / L)
+    double* scratch;       // [pairs][4 M + 2] complex
+    MixedPlan plan;        // for M2
+    int L, M, M2, R;
+};
+
+template <typename T>
+__device__ T block_sum(T v, T* red) {
+    const int tid = threadIdx.x;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    T s = 0;
+    for (int w = 0; w < kGccThreads / 64; ++w) s += red[w];
+    return s;
+}
+
+__device__ double block_max(double v, double* red) {
+    const int tid = threadIdx.x;
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = red[0];
+    for (int w = 1; w < kGccThreads / 64; ++w) s = fmax(s, red[w]);
+    return s;
+}
+
+__global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) {
+    using C = cpx<double>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    C* buf = (C*)smem;                                  // M2 points
+    double* red = (double*)(buf + a.M2);                // 16 doubles + 16 ints
+    int* redi = (int*)(red + 16);
+
+    const int tid = threadIdx.x;
+    const int pair = blockIdx.x;
+    const int L = a.L, M = a.M, M2 = a.M2, R = a.R;
+    const double* sig[2] = {a.d0 + (size_t)pair * L, a.d1 + (size_t)pair * L};
+    C* S = (C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2);   // [2][M] sub-spectra
+    C* G = S + 2 * (size_t)M;                                    // [M+1] cross spectrum
+    C* Zi = G + (M + 1);                                         // [M] packed inverse input
+    const C* twm = (const C*)a.twm;
+    const C* twl = (const C*)a.twl;
+
+    // ---- means -----------------------------------------------------------------------------------
+    double mean[2];
+    for (int s = 0; s < 2; ++s) {
+        double acc = 0.0;
+        for (int t = tid; t < L; t += kGccThreads) acc += sig[s][t];
+        mean[s] = block_sum(acc, red) / (double)L;
+    }
+    if (tid == 0 && a.means) {
+        a.means[2 * pair] = mean[0];
+        a.means[2 * pair + 1] = mean[1];
+    }
+
+    // ---- forward sub-transforms: S[s][r][k'] = FFT_M2( z_s[R m + r] ) -------------------------------
+    for (int s = 0; s < 2; ++s)
+        for (int r = 0; r < R; ++r) {
+            for (int m = tid; m < M2; m += kGccThreads) {
+                const int t = 2 * (R * m + r);
+                buf[m] = {(sig[s][t] - mean[s]) * a.window[t], (sig[s][t + 1] - mean[s]) * a.window[t + 1]};
+            }
+            __syncthreads();
+            fft_mixed_forward<double, kGccMaxB>(buf, (const C*)a.tw2, a.plan, tid, kGccThreads);
+            for (int k = tid; k < M2; k += kGccThreads) S[((size_t)s * R + r) * M2 + k] = buf[k];
+            __syncthreads();
+        }
+    __threadfence_block();
+    __syncthreads();
+
+    // Z_s[k] = sum_r W_M^{r k} S[s][r][k mod M2]
+    auto zfull = [&](int s, int k) -> C {
+        const int kp = k % M2;
+        C acc = S[((size_t)s * R) * M2 + kp];
+        for (int r = 1; r < R; ++r) acc = acc + cmul(twm[(int)(((long long)r * k) % M)], S[((size_t)s * R + r) * M2 + kp]);
+        return acc;
+    };
+    auto unpack = [&](int s, int k) -> C {          // D_s[k], k = 0..M
+        const C A = zfull(s, k == M ? 0 : k);
+        const C B = cconj(zfull(s, k == 0 ? 0 : M - k));
+        const C Sm = A + B, D = A - B;
+        const C t = cmul(twl[k], D);
+        return {0.5 * (Sm.x + t.y), 0.5 * (Sm.y - t.x)};
+    };
+
+    // ---- cross spectrum and its maximum magnitude ------------------------------------------------------
+    double gmax = 0.0;
+    for (int k = tid; k <= M; k += kGccThreads) {
+        const C g = cmul(cconj(unpack(0, k)), unpack(1, k));
+        G[k] = g;
+        gmax = fmax(gmax, sqrt(g.x * g.x + g.y * g.y));
+    }
+    gmax = block_max(gmax, red);
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- PHAT weighting and packing for the inverse real transform ---------------------------------------
+    auto weighted = [&](int k) -> C {
+        C g = G[k];
+        const double w = 1.0 / (1e-10 * gmax + sqrt(g.x * g.x + g.y * g.y));
+        g = {g.x * w, g.y * w};
+        if (k == 0 || k == M) g.y = 0.0;            // irfft ignores the imaginary part of the edge bins
+        return g;
+    };
+    for (int k = tid; k < M; k += kGccThreads) {
+        const C A = weighted(k);
+        const C B = cconj(weighted(M - k));
+        const C Sm = A + B, D = A - B;
+        const C t = cmul(cconj(twl[k]), D);
+        Zi[k] = {0.5 * (Sm.x - t.y), 0.5 * (Sm.y + t.x)};
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- inverse sub-transforms: z[R m + r] = (1/M) IFFT_M2( W_M^{-r k'} sum_q W_R^{-r q} Zi[k' + q M2] ) ---
+    double* out = a.xcorr + (size_t)pair * L;
+    const double inv = 1.0 / (double)M;
+    double best = -1.0;
+    int besti = 0;
+    for (int r = 0; r < R; ++r) {
+        for (int k = tid; k < M2; k += kGccThreads) {
+            C acc = Zi[k];
+            for (int q = 1; q < R; ++q) {
+                // W_R^{-r q} = conj(W_M^{(r q mod R) M2})
+                const C wq = cconj(twm[(int)(((long long)((r * q) % R) * M2) % M)]);
+                acc = acc + cmul(wq, Zi[k + q * M2]);
+            }
+            acc = cmul(cconj(twm[(int)(((long long)r * k) % M)]), acc);
+            buf[k] = cconj(acc);                   // conj trick: ifft(u) = conj(fft(conj u)) / n
+        }
+        __syncthreads();
+        fft_mixed_forward<double, kGccMaxB>(buf, (const C*)a.tw2, a.plan, tid, kGccThreads);
+        for (int m = tid; m < M2; m += kGccThreads) {
+            const int t = 2 * (R * m + r);
+            const double re = buf[m].x * inv, im = -buf[m].y * inv;
+            out[t] = re;
+            out[t + 1] = im;
+            if (fabs(re) > best || (fabs(re) == best && t < besti)) { best = fabs(re); besti = t; }
+            if (fabs(im) > best || (fabs(im) == best && t + 1 < besti)) { best = fabs(im); besti = t + 1; }
+        }
+        __syncthreads();
+    }
+
+    // ---- argmax |xcorr| (first index on ties, as numpy.argmax) ---------------------------------------------
+    if (a.argmax) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_down(best, o, 64);
+            const int oi = __shfl_down(besti, o, 64);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { red[tid >> 6] = best; redi[tid >> 6] = besti; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < kGccThreads / 64; ++w)
+                if (red[w] > best || (red[w] == best && redi[w] < besti)) { best = red[w]; besti = redi[w]; }
+            a.argmax[pair] = besti;
+        }
+    }
+}
+
+// Smoothing + statistics of the read-out: sm = alpha x + (1 - alpha) old (or x when old is null);
+// per pair: argmax |sm|, sm[argmax], std(sm) (two-pass, as numpy.std).
+__global__ void __launch_bounds__(kGccThreads) gcc_readout_kernel(const double* __restrict__ x, const double* __restrict__ old,
+                                                                  double* __restrict__ sm, int L, double alpha,
+                                                                  int* __restrict__ argmax, double* __restrict__ stats) {
+    __shared__ double red[16];
+    __shared__ int redi[16];
+    const int tid = threadIdx.x, pair = blockIdx.x;
+    const double* xp = x + (size_t)pair * L;
+    const double* op = old ? old + (size_t)pair * L : nullptr;
+    double* sp = sm + (size_t)pair * L;
+    double best = -1.0, acc = 0.0;
+    int besti = 0;
+    for (int t = tid; t < L; t += kGccThreads) {
+        const double v = op ? alpha * xp[t] + (1.0 - alpha) * op[t] : xp[t];
+        sp[t] = v;
+        acc += v;
+        if (fabs(v) > best) { best = fabs(v); besti = t; }
+    }
+    const double mean = block_sum(acc, red) / (double)L;
+    double var = 0.0;
+    for (int t = tid; t < L; t += kGccThreads) {
+        const double d = sp[t] - mean;
+        var += d * d;
+    }
+    var = block_sum(var, red) / (double)L;
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_down(best, o, 64);
+        const int oi = __shfl_down(besti, o, 64);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = best; redi[tid >> 6] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kGccThreads / 64; ++w)
+            if (red[w] > best || (red[w] == best && redi[w] < besti)) { best = red[w]; besti = redi[w]; }
+        argmax[pair] = besti;
+        stats[2 * pair] = sp[besti];
+        stats[2 * pair + 1] = sqrt(var);
+    }
+}
+
+}  // namespace frt
+
+using namespace frt;
+
+struct frt_gcc {
+    int L = 0, M = 0, M2 = 0, R = 1, n_pairs = 0;
+    MixedPlan plan{};
+    hipStream_t stream = nullptr;
+    DeviceBuffer window, twm, tw2, twl, scratch;
+    DeviceBuffer in0, in1, out, argmax, means, old, sm, stats;
+    size_t lds_bytes = 0;
+};
+
+extern "C" void frt_gcc_destroy(frt_gcc* h) {
+    if (!h) return;
+    DeviceBuffer* bufs[] = {&h->window, &h->twm, &h->tw2, &h->twl, &h->scratch, &h->in0, &h->in1,
+                            &h->out, &h->argmax, &h->means, &h->old, &h->sm, &h->stats};
+    for (auto* b : bufs) b->release();
+    delete h;
+}
+
+extern "C" int frt_gcc_create(frt_gcc** out, int length, int n_pairs) {
+    FRT_REQUIRE(out, "frt_gcc_create: null handle pointer");
+    *out = nullptr;
+    FRT_REQUIRE(length >= 4 && length % 2 == 0, "frt_gcc_create: length %d must be even and >= 4", length);
+    FRT_REQUIRE(n_pairs >= 1, "frt_gcc_create: n_pairs %d < 1", n_pairs);
+    frt_gcc* h = new frt_gcc();
+    h->L = length;
+    h->M = length / 2;
+    h->n_pairs = n_pairs;
+    int R = 1;
+    while (h->M / R > kGccMaxM2 && R < kGccMaxR && h->M % (2 * R) == 0) R *= 2;
+    h->R = R;
+    h->M2 = h->M / R;
+    if (h->M2 > kGccMaxM2 || !make_mixed_plan(h->M2, &h->plan)) {
+        set_last_error("frt_gcc_create: length %d is not supported (L/2 = R * M2 with R <= %d, M2 <= %d and 5-smooth)",
+                       length, kGccMaxR, kGccMaxM2);
+        delete h;
+        return FRT_ERR_UNSUPPORTED;
+    }
+    // numpy.hanning(L) = 0.5 - 0.5 cos(2 pi n / (L - 1))
+    std::vector<double> win(length);
+    const double pi = 3.14159265358979323846;
+    for (int n = 0; n < length; ++n) win[n] = 0.5 - 0.5 * std::cos(2.0 * pi * n / (length - 1));
+    int rc;
+    if ((rc = upload(h->window, win)) || (rc = upload(h->twm, make_twiddles<double>(h->M))) ||
+        (rc = upload(h->tw2, make_twiddles<double>(h->M2))) || (rc = upload(h->twl, make_twiddles<double>(length, h->M + 1))) ||
+        (rc = h->scratch.reserve((size_t)n_pairs * (4 * (size_t)h->M + 2) * 2 * sizeof(double)))) {
+        frt_gcc_destroy(h);
+        return rc;
+    }
+    h->lds_bytes = (size_t)h->M2 * 16 + 16 * sizeof(double) + 16 * sizeof(int);
+    if (hipFuncSetAttribute((const void*)gcc_phat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
+        set_last_error("frt_gcc_create: cannot reserve %zu bytes of LDS", h->lds_bytes);
+        frt_gcc_destroy(h);
+        return FRT_ERR_HIP;
+    }
+    *out = h;
+    return FRT_OK;
+}
+
+extern "C" int frt_gcc_set_stream(frt_gcc* h, void* s) {
+    FRT_REQUIRE(h, "frt_gcc_set_stream: null handle");
+    h->stream = (hipStream_t)s;
+    return FRT_OK;
+}
+
+extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, double* xcorr_out, int* argmax_out, double* means_out) {
+    FRT_REQUIRE(h && d0 && d1 && xcorr_out, "frt_gcc_phat: null argument");
+    const bool dev = is_device_pointer(d0);
+    FRT_REQUIRE(dev == is_device_pointer(d1) && dev == is_device_pointer(xcorr_out),
+                "frt_gcc_phat: buffers must all be host or all be device memory");
+    const size_t bytes = (size_t)h->n_pairs * h->L * sizeof(double);
+    GccArgs a{};
+    int rc;
+    if ((rc = h->argmax.reserve(h->n_pairs * sizeof(int))) || (rc = h->means.reserve(h->n_pairs * 2 * sizeof(double)))) return rc;
+    if (dev) {
+        a.d0 = d0;
+        a.d1 = d1;
+        a.xcorr = xcorr_out;
+    } else {
+        if ((rc = h->in0.reserve(bytes)) || (rc = h->in1.reserve(bytes)) || (rc = h->out.reserve(bytes))) return rc;
+        FRT_HIP_CHECK(hipMemcpyAsync(h->in0.ptr, d0, bytes, hipMemcpyHostToDevice, h->stream));
+        FRT_HIP_CHECK(hipMemcpyAsync(h->in1.ptr, d1, bytes, hipMemcpyHostToDevice, h->stream));
+        a.d0 = h->in0.as<double>();
+        a.d1 = h->in1.as<double>();
+        a.xcorr = h->out.as<double>();
+    }
+    a.argmax = h->argmax.as<int>();
+    a.means = h->means.as<double>();
+    a.window = h->window.as<double>();
+    a.twm = h->twm.as<double>();
+    a.tw2 = h->tw2.as<double>();
+    a.twl = h->twl.as<double>();
+    a.scratch = h->scratch.as<double>();
+    a.plan = h->plan;
+    a.L = h->L;
+    a.M = h->M;
+    a.M2 = h->M2;
+    a.R = h->R;
+    hipLaunchKernelGGL(gcc_phat_kernel, dim3(h->n_pairs), dim3(kGccThreads), h->lds_bytes, h->stream, a);
+    FRT_HIP_CHECK(hipGetLastError());
+    if (!dev) FRT_HIP_CHECK(hipMemcpyAsync(xcorr_out, h->out.ptr, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (argmax_out) {
+        const bool adev = is_device_pointer(argmax_out);
+        FRT_HIP_CHECK(hipMemcpyAsync(argmax_out, h->argmax.ptr, h->n_pairs * sizeof(int),
+                                     adev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    }
+    if (means_out) {
+        const bool mdev = is_device_pointer(means_out);
+        FRT_HIP_CHECK(hipMemcpyAsync(means_out, h->means.ptr, h->n_pairs * 2 * sizeof(double),
+                                     mdev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    }
+    if (!dev || (argmax_out && !is_device_pointer(argmax_out)) || (means_out && !is_device_pointer(means_out)))
+        FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return FRT_OK;
+}
+
+extern "C" int frt_gcc_readout(frt_gcc* h, const double* xcorr, const double* old_smoothed, double alpha, double sample_rate,
+                               double delayrange_s, double* smoothed_out, frt_delay_readout* readout) {
+    FRT_REQUIRE(h && xcorr && smoothed_out && readout, "frt_gcc_readout: null argument");
+    FRT_REQUIRE(sample_rate > 0, "frt_gcc_readout: sample_rate must be positive");
+    const bool dev = is_device_pointer(xcorr);
+    FRT_REQUIRE(dev == is_device_pointer(smoothed_out) && (!old_smoothed || dev == is_device_pointer(old_smoothed)),
+                "frt_gcc_readout: buffers must all be host or all be device memory");
+    const size_t bytes = (size_t)h->n_pairs * h->L * sizeof(double);
+    int rc;
+    if ((rc = h->argmax.reserve(h->n_pairs * sizeof(int))) || (rc = h->stats.reserve(h->n_pairs * 2 * sizeof(double)))) return rc;
+    const double* dx = xcorr;
+    const double* dold = old_smoothed;
+    double* dsm = smoothed_out;
+    if (!dev) {
+        if ((rc = h->out.reserve(bytes)) || (rc = h->sm.reserve(bytes))) return rc;
+        FRT_HIP_CHECK(hipMemcpyAsync(h->out.ptr, xcorr, bytes, hipMemcpyHostToDevice, h->stream));
+        dx = h->out.as<double>();
+        dsm = h->sm.as<double>();
+        if (old_smoothed) {
+            if ((rc = h->old.reserve(bytes))) return rc;
+            FRT_HIP_CHECK(hipMemcpyAsync(h->old.ptr, old_smoothed, bytes, hipMemcpyHostToDevice, h->stream));
+            dold = h->old.as<double>();
+        }
+    }
+    hipLaunchKernelGGL(gcc_readout_kernel, dim3(h->n_pairs), dim3(kGccThreads), 0, h->stream, dx, dold, dsm, h->L, alpha,
+                       h->argmax.as<int>(), h->stats.as<double>());
+    FRT_HIP_CHECK(hipGetLastError());
+    if (!dev) FRT_HIP_CHECK(hipMemcpyAsync(smoothed_out, dsm, bytes, hipMemcpyDeviceToHost, h->stream));
+    std::vector<int> am(h->n_pairs);
+    std::vector<double> st(2 * h->n_pairs);
+    FRT_HIP_CHECK(hipMemcpyAsync(am.data(), h->argmax.ptr, am.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    FRT_HIP_CHECK(hipMemcpyAsync(st.data(), h->stats.ptr, st.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    for (int p = 0; p < h->n_pairs; ++p) {           // scalar tail of delay_estimator.py:141-176
+        frt_delay_readout& r = readout[p];
+        r.argmax = am[p];
+        r.extremum = st[2 * p];
+        const double peak_norm = std::fabs(st[2 * p]) / (3.0 * st[2 * p + 1]);
+        const double time = 2.0 * delayrange_s;
+        double delay_ms = 1e3 * (double)am[p] / sample_rate;
+        if (delay_ms > 1e3 * time / 2.0) delay_ms -= 1e3 * time;
+        r.delay_ms = delay_ms;
+        r.distance_m = delay_ms * 1e-3 * 340.0;
+        double x = peak_norm > 1.0 ? peak_norm - 1.0 : 0.0;
+        x = std::pow(0.12 * x, 3.0);
+        r.correlation_pct = (int)((x / (1.0 + x)) * 100.0);
+    }
+    return FRT_OK;
+}

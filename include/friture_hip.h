@@ -142,6 +142,34 @@ int frt_decimate_multiple(frt_octbank* h, int n_stages, const double* x, int n, 
 int frt_lfilter_f64(const double* b, const double* a, int n_coef, const double* x, int n, const double* zi,
                     double* y, double* zf);
 
+/* ---- K5: GCC-PHAT cross-correlation and the delay read-out --------------------------------------
+ * frt_gcc_phat replaces generalized_cross_correlation (friture/signal/correlation.py:24-43): mean
+ * removal, numpy.hanning window, two real FFTs, conj(D0) D1, PHAT weight 1/(1e-10 max|G| + |G|),
+ * inverse real FFT.  length must be even with length/2 = R * M2, R in {1, 2, 4}, M2 <= 6144 and
+ * 5-smooth (the default window of 24000 samples, friture/delay_estimator.py:114-115, qualifies).
+ * The reference subtracts the means in place on its arguments; means_out lets a binding reproduce
+ * that side effect. */
+typedef struct frt_gcc frt_gcc;
+int frt_gcc_create(frt_gcc** h, int length, int n_pairs);
+void frt_gcc_destroy(frt_gcc* h);
+int frt_gcc_set_stream(frt_gcc* h, void* hip_stream);
+/* d0, d1, xcorr_out: [n_pairs][length] doubles; argmax_out: [n_pairs] index of max |xcorr| or NULL;
+ * means_out: [n_pairs][2] or NULL. */
+int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, double* xcorr_out, int* argmax_out, double* means_out);
+
+/* Peak read-out of Delay_Estimator_Widget.handle_new_data (friture/delay_estimator.py:134-176). */
+typedef struct frt_delay_readout {
+    int argmax;           /* index of max |smoothed|                                   :141-142 */
+    int correlation_pct;  /* int(100 x/(1+x)), x = (0.12 max(0, peak/(3 std) - 1))^3    :171-176 */
+    double delay_ms;      /* 1e3 argmax / rate, minus the window when past its half     :148-152 */
+    double distance_m;    /* delay * 340 m/s                                            :167-168 */
+    double extremum;      /* smoothed[argmax] (its sign is the polarity)                :146     */
+} frt_delay_readout;
+/* smoothed_out = alpha * xcorr + (1 - alpha) * old_smoothed (or xcorr when old_smoothed is NULL),
+ * [n_pairs][length]; readout: [n_pairs] host structs. */
+int frt_gcc_readout(frt_gcc* h, const double* xcorr, const double* old_smoothed, double alpha, double sample_rate,
+                    double delayrange_s, double* smoothed_out, frt_delay_readout* readout);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,118 @@
+"""K5 / G1-G3 parity: GCC-PHAT and the delay read-out against reference golden vectors and the oracle.
+
+float64 on both sides with a different FFT factorisation: max|xcorr - ref| / max|ref| <= 1e-9 (the
+north_star bar is 1e-5), identical argmax."""
+import numpy as np
+import pytest
+
+from conftest import rel_max
+from oracle import dsp
+
+pytestmark = pytest.mark.gpu
+
+
+def f64(x):
+    return np.asarray(x, np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("L", [2400, 24000])
+def test_gcc_against_golden(golden, hip, L):
+    from friture_amd.signal.correlation import generalized_cross_correlation
+    g = golden("gcc")
+    d0, d1 = f64(g[f"L{L}_d0"]), f64(g[f"L{L}_d1"])
+    keep0, keep1 = d0.copy(), d1.copy()
+    x = generalized_cross_correlation(d0, d1)
+    assert x.shape == (L,) and int(np.argmax(np.abs(x))) == int(g[f"L{L}_argmax"]) == 37
+    if L == 2400:
+        assert rel_max(x, g["L2400_xcorr"]) <= 1e-9
+    else:
+        scale = g["L24000_xcorr_norms"][0]
+        assert np.max(np.abs(x[:128] - g["L24000_xcorr_head"])) <= 1e-9 * scale
+        got = np.array([np.max(np.abs(x)), np.sqrt(np.sum(x ** 2)), np.std(x)])
+        assert np.max(np.abs(got / g["L24000_xcorr_norms"] - 1)) < 1e-9
+    # the in-place mean removal of the reference (correlation.py:27-28)
+    assert np.allclose(d0, keep0 - keep0.mean(), rtol=0, atol=1e-15)
+    assert np.allclose(d1, keep1 - keep1.mean(), rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("L", [4, 6, 30, 1024, 540, 12288, 16384, 49152])
+def test_gcc_lengths_against_oracle(hip, L):
+    """radix mix, the R = 1 / 2 / 4 splits, tiny windows"""
+    from friture_amd.signal.correlation import GccPhat
+    rng = np.random.default_rng(L)
+    d0 = 0.25 * rng.standard_normal((3, L))
+    lag = min(5, L // 4)
+    d1 = np.roll(d0, lag, axis=1) + 0.02 * rng.standard_normal((3, L))
+    d1[2] = -d1[2]                                  # inverted polarity: negative peak
+    x, am = GccPhat(L, 3).correlate(d0, d1)
+    for p in range(3):
+        ref, _, _ = dsp.gcc_phat(d0[p], d1[p])
+        assert rel_max(x[p], ref) <= 1e-9, (L, p, rel_max(x[p], ref))
+        assert am[p] == int(np.argmax(np.abs(ref)))
+    if L >= 30:
+        assert list(am) == [lag] * 3 and x[2, lag] < 0 < x[0, lag]
+
+
+def test_gcc_errors(hip):
+    from friture_amd._lib import FritureHipError
+    from friture_amd.signal.correlation import GccPhat, generalized_cross_correlation
+    with pytest.raises(FritureHipError):
+        GccPhat(2 * 7 * 1024, 1)         # 7 is not a supported radix
+    with pytest.raises(FritureHipError):
+        GccPhat(1001, 1)                 # odd length
+    with pytest.raises(ValueError):
+        generalized_cross_correlation(np.zeros(100), np.zeros(98))
+
+
+def test_readout_against_oracle(hip):
+    from friture_amd.signal.correlation import GccPhat
+    L, rate, rng_s = 24000, 12000.0, 1.0
+    rng = np.random.default_rng(1)
+    g = GccPhat(L, 2)
+    d0 = 0.25 * rng.standard_normal((2, L))
+    d1 = np.stack([np.roll(d0[0], 37), -np.roll(d0[1], L - 50)]) + 0.05 * rng.standard_normal((2, L))
+    x, _ = g.correlate(d0, d1)
+    old = None
+    for it in range(3):
+        sm, ro = g.readout(x, old, rate, rng_s)
+        for p in range(2):
+            ref = dsp.delay_readout(x[p], None if old is None else old[p], rate, rng_s)
+            assert np.max(np.abs(sm[p] - ref["smoothed"])) <= 1e-15
+            assert ro[p].argmax == ref["argmax"] and ro[p].correlation_pct == ref["correlation_pct"]
+            assert abs(ro[p].delay_ms - ref["delay_ms"]) < 1e-9 and abs(ro[p].extremum - ref["extremum"]) < 1e-12
+            assert abs(ro[p].distance_m - ref["distance_m"]) < 1e-9
+        old = sm
+        x = x * 0.9
+    assert abs(ro[0].delay_ms - 1e3 * 37 / rate) < 1e-9 and ro[0].extremum > 0
+    assert abs(ro[1].delay_ms + 1e3 * 50 / rate) < 1e-9 and ro[1].extremum < 0      # wrapped negative delay, inverted
+
+
+def test_delay_estimator_chain_against_oracle(hip):
+    """The whole widget body on 2-channel 48 kHz chunks vs the same chain built from the oracle."""
+    from friture_amd.delay_estimator import DelayEstimator
+    rng = np.random.default_rng(3)
+    n = 512 * 60
+    a = (0.25 * rng.standard_normal(n)).astype(np.float32).astype(np.float64)
+    b = np.roll(a, 4 * 21) + 0.01 * rng.standard_normal(n)        # 21 samples at 12 kHz
+    est = DelayEstimator(delayrange_s=0.25)                       # window 6000, hop 3000 decimated samples
+    t = dsp.load_filter_tables()
+    z0, z1 = dsp.decimate_multiple_filtic(2, t["bdec"], t["adec"]), dsp.decimate_multiple_filtic(2, t["bdec"], t["adec"])
+    r0, r1 = dsp.MirrorRing(), dsp.MirrorRing()
+    old, old_index, ref = None, 0, None
+    for c in range(60):
+        chunk = np.stack([a[c * 512:(c + 1) * 512], b[c * 512:(c + 1) * 512]])
+        est.handle_new_data(chunk)
+        y0, z0 = dsp.decimate_multiple(2, t["bdec"], t["adec"], chunk[0], z0)
+        y1, z1 = dsp.decimate_multiple(2, t["bdec"], t["adec"], chunk[1], z1)
+        r0.push(y0[None, :])
+        r1.push(y1[None, :])
+        while r0.offset - old_index >= 3000:
+            old_index += 3000
+            w0, w1 = r0.data_indexed(old_index, 6000)[0], r1.data_indexed(old_index, 6000)[0]
+            xc, m0, m1 = dsp.gcc_phat(w0, w1)
+            w0[:], w1[:] = m0, m1                                   # the reference de-means the ring views in place
+            ref = dsp.delay_readout(xc, old, 12000.0, 0.25)
+            old = ref["smoothed"]
+    assert ref is not None and abs(est.delay_ms - ref["delay_ms"]) < 1e-9 and abs(est.delay_ms - 1.75) < 1e-9
+    assert est.correlation == ref["correlation_pct"] and abs(est.Xcorr_extremum - ref["extremum"]) < 1e-9
+    assert np.max(np.abs(est.old_Xcorr - ref["smoothed"])) < 1e-9

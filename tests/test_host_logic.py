@@ -1,0 +1,56 @@
+"""Host-side mirrors that need no GPU: ring buffer, band labels, tables."""
+import numpy as np
+import pytest
+
+from oracle import dsp
+
+
+def test_ringbuffer_matches_reference(golden):
+    from friture_amd.ringbuffer import RingBuffer
+    g = golden("ring")
+    ring = RingBuffer()
+    for step in range(6):
+        ring.push(g[f"blk{step}"], 0.0)
+        ln = min(ring.offset, 4096)
+        assert np.array_equal(ring.data_indexed(ring.offset - 100, ln - 100), g[f"win{step}"])
+    assert np.array_equal(ring.data(256), ring.data_indexed(ring.offset, 256))
+    assert np.array_equal(ring.data_older(100, 50), ring.data_indexed(ring.offset - 50, 100))
+
+
+def test_ringbuffer_errors_and_growth():
+    from friture_amd.ringbuffer import RingBuffer
+    ring, ref = RingBuffer(), dsp.MirrorRing()
+    rng = np.random.default_rng(0)
+    for n in (300, 9900, 25000, 7):
+        blk = rng.standard_normal((2, n))
+        ring.push(blk, 1.0)
+        ref.push(blk)
+        assert ring.buffer_length == ref.buffer_length and ring.offset == ref.offset
+        assert np.array_equal(ring.data(min(ring.offset, 5000)), ref.data(min(ref.offset, 5000)))
+    assert ring.data_time(ring.offset - 480) == 1.0 - 0.01
+
+
+def test_nominal_labels(golden):
+    from friture_amd.octavefilters import nominal_labels
+    g = golden("ola")
+    for bpo in (1, 3, 6, 12, 24):
+        fi, _, _ = dsp.octave_frequencies(9 * bpo, bpo)
+        assert nominal_labels(fi, bpo) == list(g[f"bands{bpo}_nominal"])
+    with pytest.raises(Exception, match="Unknown bandsperoctave"):
+        nominal_labels(dsp.octave_frequencies(45, 5)[0], 5)
+
+
+def test_tables_match_reference(golden):
+    from friture_amd import palette, tables
+    from friture_amd.filter import octave_frequencies
+    g = golden("psd")
+    assert np.array_equal(tables.rfft_frequencies(1024), g["N1024_freq"])
+    for got, want in zip(tables.weighting_db(g["N1024_freq"], 1e-50), (g["N1024_A"], g["N1024_B"], g["N1024_C"])):
+        assert np.array_equal(got, want)
+    assert np.array_equal(palette.cmr_lut(), golden("image")["lut"])
+    o = golden("ola")
+    for bpo in (1, 3, 24):
+        fi, flo, fhi = octave_frequencies(9 * bpo, bpo)
+        assert np.array_equal(fi, o[f"bands{bpo}_fi"]) and np.array_equal(flo, o[f"bands{bpo}_flow"])
+        assert np.array_equal(fhi, o[f"bands{bpo}_fhigh"])
+        assert np.array_equal(tables.weighting_db(fi)[0], o[f"bands{bpo}_A"])
