@@ -64,6 +64,10 @@ SIGNATURES = {
     "frt_gcc_set_stream": (c_int, [c_void_p, c_void_p]),
     "frt_gcc_phat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "frt_gcc_readout": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_void_p, c_void_p]),
+    "frt_freq_resample": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "frt_time_resample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "frt_colour_map": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "frt_exp_smooth_2d": (c_int, [c_void_p, c_int, c_double, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "frt_lfilter_f64": (c_int, [POINTER(c_double), POINTER(c_double), c_int, POINTER(c_double), c_int, POINTER(c_double),
                                 POINTER(c_double), POINTER(c_double)]),
 }

@@ -28,7 +28,7 @@ CXXFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-W
 
 # translation units with special flags: the exact IIR bank replays the reference's IEEE operation
 # order (no fused multiply-add contraction) so that it can be bit-identical to lfilter.py:131-139
-EXTRA_FLAGS = {"iir.hip": ["-ffp-contract=off"]}
+EXTRA_FLAGS = {"iir.hip": ["-ffp-contract=off"], "pipeline.hip": ["-ffp-contract=off"]}
 
 
 def _sources() -> list[Path]:

@@ -1,0 +1,251 @@
+// pipeline.hip — K6 and K4': the screen-space stages of the spectrogram and the block-wise
+// exponential smoothing, for gfx950.  float64 like the reference; built with -ffp-contract=off so
+// that every element is produced by the reference's IEEE operations in the reference's order
+// (these stages end in an integer colour index, where a last-bit difference can flip a pixel).
+//
+// Reference semantics:
+//   P5  Frequency_Resampler.push: per column np.interp(targets, freq, column)
+//                                                     friture/signal/frequency_resampler.py:67-83
+//   P6  Online_Linear_2D_resampler.push / linear_interp_2D: out = data (1 - a) + old a per emitted
+//       pixel column        friture/signal/online_linear_2D_resampler.py:61-97, linear_interp.py:57-60
+//   P7  Color_Transform.push: lut[int(clip(v, 0, 1) * 255)]
+//                     friture/signal/color_tranform.py:48-51, friture/signal/lookup_table.py:50-52
+//   P8  exp_smoothed_value(_2d): alpha * (data[:, :Nt] @ kernel[Nk-Nt:]) + previous * (1-alpha)^Nt
+//                                                     friture/signal/exp_smoothing.py:40-56,91-107
+#include <cmath>
+
+#include "common.h"
+
+namespace frt {
+
+// np.interp with the interval index j[h] found on the host (the abscissae are plan constants):
+//   j = -1 -> fp[0];  j >= n-1 -> fp[n-1];  xp[j] == x -> fp[j];
+//   else slope = (fp[j+1] - fp[j]) / (xp[j+1] - xp[j]);  slope * (x - xp[j]) + fp[j]
+__global__ void freq_resample_kernel(const double* __restrict__ data, int n_bins, int n_cols, const int* __restrict__ jidx,
+                                     const double* __restrict__ dx, const double* __restrict__ den, int height,
+                                     double* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.y;
+    if (c >= n_cols) return;
+    const int j = jidx[h];
+    double v;
+    if (j < 0) v = data[c];
+    else if (j >= n_bins - 1) v = data[(size_t)(n_bins - 1) * n_cols + c];
+    else {
+        const double f0 = data[(size_t)j * n_cols + c];
+        if (dx[h] == 0.0) v = f0;
+        else {
+            const double f1 = data[(size_t)(j + 1) * n_cols + c];
+            const double slope = (f1 - f0) / den[h];
+            v = slope * dx[h] + f0;
+        }
+    }
+    out[(size_t)h * n_cols + c] = v;
+}
+
+__global__ void time_resample_kernel(const double* __restrict__ data, const double* __restrict__ old, int height, int n_cols,
+                                     const int* __restrict__ src, const double* __restrict__ a, int n_out,
+                                     double* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.y;
+    if (p >= n_out) return;
+    const int c = src[p];
+    const double cur = data[(size_t)h * n_cols + c];
+    const double prev = c == 0 ? old[h] : data[(size_t)h * n_cols + c - 1];
+    const double w = a[p];
+    out[(size_t)h * n_out + p] = cur * (1.0 - w) + prev * w;
+}
+
+__global__ void colour_map_kernel(const uint32_t* __restrict__ lut, const double* __restrict__ v, long long count,
+                                  uint32_t* __restrict__ out) {
+    __shared__ uint32_t l[256];
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) l[t] = lut[t];
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        double x = v[i];
+        x = x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x);              // numpy.clip
+        out[i] = l[(int)(x * 255.0)];
+    }
+}
+
+// one wavefront per row: alpha * sum_t data[r][t] * kernel[off + t] + previous[r] * decay
+__global__ void __launch_bounds__(64) exp_smooth_kernel(const double* __restrict__ data, long long row_stride, int nt,
+                                                        const double* __restrict__ kern, double alpha, double decay,
+                                                        const double* __restrict__ previous, double* __restrict__ out, int nf) {
+    const int r = blockIdx.x;
+    if (r >= nf) return;
+    const double* row = data + (size_t)r * row_stride;
+    double acc = 0.0;
+    for (int t = threadIdx.x; t < nt; t += 64) acc += row[t] * kern[t];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (threadIdx.x == 0) out[r] = alpha * acc + previous[r] * decay;
+}
+
+struct Staged {
+    // host <-> device staging for the stateless entry points below
+    std::vector<DeviceBuffer> bufs;
+    ~Staged() {
+        for (auto& b : bufs) b.release();
+    }
+    template <typename T>
+    int in(const T* host, size_t count, const T** dev) {
+        if (is_device_pointer(host)) {
+            *dev = host;
+            return FRT_OK;
+        }
+        bufs.emplace_back();
+        int rc = bufs.back().reserve(count * sizeof(T));
+        if (rc) return rc;
+        FRT_HIP_CHECK(hipMemcpy(bufs.back().ptr, host, count * sizeof(T), hipMemcpyHostToDevice));
+        *dev = bufs.back().as<T>();
+        return FRT_OK;
+    }
+    template <typename T>
+    int out(T* host, size_t count, T** dev, bool* staged) {
+        *staged = !is_device_pointer(host);
+        if (!*staged) {
+            *dev = host;
+            return FRT_OK;
+        }
+        bufs.emplace_back();
+        int rc = bufs.back().reserve(count * sizeof(T));
+        if (rc) return rc;
+        *dev = bufs.back().as<T>();
+        return FRT_OK;
+    }
+};
+
+}  // namespace frt
+
+using namespace frt;
+
+extern "C" int frt_freq_resample(const double* freq, int n_bins, const double* targets, int height, const double* data,
+                                 int n_cols, double* out) {
+    FRT_REQUIRE(freq && targets && n_bins >= 1 && height >= 1 && n_cols >= 0, "frt_freq_resample: bad arguments");
+    if (n_cols == 0) return FRT_OK;
+    FRT_REQUIRE(data && out, "frt_freq_resample: null buffer");
+    FRT_REQUIRE(!is_device_pointer(freq) && !is_device_pointer(targets), "frt_freq_resample: freq/targets are host tables");
+    // interval search on the host: numpy's binary search semantics (largest j with freq[j] <= x)
+    std::vector<int> j(height);
+    std::vector<double> dx(height, 0.0), den(height, 1.0);
+    for (int h = 0; h < height; ++h) {
+        const double x = targets[h];
+        if (!(x >= freq[0])) { j[h] = -1; continue; }                       // left of the table (or NaN)
+        if (x > freq[n_bins - 1]) { j[h] = n_bins; continue; }
+        int lo = 0, hi = n_bins;                                             // freq[lo] <= x < freq[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) / 2;
+            if (freq[mid] <= x) lo = mid; else hi = mid;
+        }
+        j[h] = lo;
+        if (lo < n_bins - 1) {
+            dx[h] = x - freq[lo];
+            den[h] = freq[lo + 1] - freq[lo];
+        }
+    }
+    Staged st;
+    const double* d_data;
+    double* d_out;
+    bool staged;
+    int rc;
+    if ((rc = st.in(data, (size_t)n_bins * n_cols, &d_data)) || (rc = st.out(out, (size_t)height * n_cols, &d_out, &staged))) return rc;
+    DeviceBuffer dj, ddx, dden;
+    if ((rc = upload(dj, j)) || (rc = upload(ddx, dx)) || (rc = upload(dden, den))) return rc;
+    hipLaunchKernelGGL(freq_resample_kernel, dim3((n_cols + 63) / 64, height), dim3(64), 0, nullptr, d_data, n_bins, n_cols,
+                       dj.as<int>(), ddx.as<double>(), dden.as<double>(), height, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = staged ? hipMemcpy(out, d_out, (size_t)height * n_cols * sizeof(double), hipMemcpyDeviceToHost)
+                                    : hipDeviceSynchronize();
+    dj.release();
+    ddx.release();
+    dden.release();
+    if (e != hipSuccess) {
+        set_last_error("frt_freq_resample: %s", hipGetErrorString(e));
+        return FRT_ERR_HIP;
+    }
+    return FRT_OK;
+}
+
+extern "C" int frt_time_resample(const double* data, const double* old, int height, int n_cols, const int* src_col,
+                                 const double* a, int n_out, double* out) {
+    FRT_REQUIRE(height >= 1 && n_cols >= 0 && n_out >= 0, "frt_time_resample: bad arguments");
+    if (n_out == 0) return FRT_OK;
+    FRT_REQUIRE(data && old && src_col && a && out, "frt_time_resample: null buffer");
+    FRT_REQUIRE(!is_device_pointer(src_col) && !is_device_pointer(a), "frt_time_resample: src_col/a are host tables");
+    for (int p = 0; p < n_out; ++p) FRT_REQUIRE(src_col[p] >= 0 && src_col[p] < n_cols, "frt_time_resample: source column out of range");
+    Staged st;
+    const double *d_data, *d_old;
+    const int* d_src;
+    const double* d_a;
+    double* d_out;
+    bool staged;
+    int rc;
+    if ((rc = st.in(data, (size_t)height * n_cols, &d_data)) || (rc = st.in(old, (size_t)height, &d_old)) ||
+        (rc = st.in(src_col, (size_t)n_out, &d_src)) || (rc = st.in(a, (size_t)n_out, &d_a)) ||
+        (rc = st.out(out, (size_t)height * n_out, &d_out, &staged)))
+        return rc;
+    hipLaunchKernelGGL(time_resample_kernel, dim3((n_out + 63) / 64, height), dim3(64), 0, nullptr, d_data, d_old, height, n_cols,
+                       d_src, d_a, n_out, d_out);
+    FRT_HIP_CHECK(hipGetLastError());
+    if (staged) FRT_HIP_CHECK(hipMemcpy(out, d_out, (size_t)height * n_out * sizeof(double), hipMemcpyDeviceToHost));
+    else FRT_HIP_CHECK(hipDeviceSynchronize());
+    return FRT_OK;
+}
+
+extern "C" int frt_colour_map(const uint32_t* lut256, const double* values, int64_t count, uint32_t* out) {
+    FRT_REQUIRE(lut256 && count >= 0, "frt_colour_map: bad arguments");
+    if (count == 0) return FRT_OK;
+    FRT_REQUIRE(values && out, "frt_colour_map: null buffer");
+    Staged st;
+    const uint32_t* d_lut;
+    const double* d_v;
+    uint32_t* d_out;
+    bool staged;
+    int rc;
+    if ((rc = st.in(lut256, (size_t)256, &d_lut)) || (rc = st.in(values, (size_t)count, &d_v)) ||
+        (rc = st.out(out, (size_t)count, &d_out, &staged)))
+        return rc;
+    long long blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(colour_map_kernel, dim3((unsigned)blocks), dim3(256), 0, nullptr, d_lut, d_v, (long long)count, d_out);
+    FRT_HIP_CHECK(hipGetLastError());
+    if (staged) FRT_HIP_CHECK(hipMemcpy(out, d_out, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    else FRT_HIP_CHECK(hipDeviceSynchronize());
+    return FRT_OK;
+}
+
+extern "C" int frt_exp_smooth_2d(const double* kernel, int nk, double alpha, const double* data, int nf, int nt, int64_t row_stride,
+                                 const double* previous, double* out) {
+    FRT_REQUIRE(kernel && nk >= 0 && nf >= 0 && nt >= 0 && row_stride >= nt, "frt_exp_smooth_2d: bad arguments");
+    if (nf == 0) return FRT_OK;
+    FRT_REQUIRE(previous && out && (nt == 0 || data), "frt_exp_smooth_2d: null buffer");
+    FRT_REQUIRE(!is_device_pointer(kernel), "frt_exp_smooth_2d: kernel is a host table");
+    // exp_smoothing.py:94-101: more data than kernel taps -> only the first Nk samples count and
+    // the previous value is forgotten
+    int n = nt;
+    double decay;
+    if (n > nk) {
+        n = nk;
+        decay = 0.0;
+    } else {
+        decay = std::pow(1.0 - alpha, (double)n);
+    }
+    if (n == 0) {        // exp_smoothing.py:103-104: nothing new, return a copy of previous
+        FRT_HIP_CHECK(hipMemcpy(out, previous, (size_t)nf * sizeof(double), hipMemcpyDefault));
+        return FRT_OK;
+    }
+    Staged st;
+    const double *d_k, *d_data = nullptr, *d_prev;
+    double* d_out;
+    bool staged;
+    int rc;
+    if ((rc = st.in(kernel + (nk - n), (size_t)n, &d_k)) || (rc = st.in(previous, (size_t)nf, &d_prev)) ||
+        (rc = st.out(out, (size_t)nf, &d_out, &staged)) || (rc = st.in(data, (size_t)(nf - 1) * row_stride + nt, &d_data)))
+        return rc;
+    hipLaunchKernelGGL(exp_smooth_kernel, dim3(nf), dim3(64), 0, nullptr, d_data, (long long)row_stride, n, d_k, alpha, decay,
+                       d_prev, d_out, nf);
+    FRT_HIP_CHECK(hipGetLastError());
+    if (staged) FRT_HIP_CHECK(hipMemcpy(out, d_out, (size_t)nf * sizeof(double), hipMemcpyDeviceToHost));
+    else FRT_HIP_CHECK(hipDeviceSynchronize());
+    return FRT_OK;
+}

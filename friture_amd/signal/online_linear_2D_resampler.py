@@ -1,0 +1,73 @@
+"""friture/signal/online_linear_2D_resampler.py:14-97 on the GPU: stateful linear resampling of
+spectrogram columns from the STFT rate to the pixel rate.
+
+The class keeps the reference's scalar bookkeeping (orig_index / resampled_index / ratio decide how
+many pixel columns each pushed column emits and with which weights) and hands the arithmetic of a
+whole push — out = data (1 - a) + old a for every emitted pixel column, linear_interp.py:57-60 —
+to one launch of time_resample_kernel (frt_time_resample)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _lib
+
+
+class Online_Linear_2D_resampler:
+    def __init__(self, interp_factor_L=1, decim_factor_M=1, height=1):
+        self._lib = _lib.init()
+        self.interp_factor_L = interp_factor_L
+        self.decim_factor_M = decim_factor_M
+        self.resampling_ratio = float(interp_factor_L) / decim_factor_M
+        self.height = height
+        self.orig_index = 0.
+        self.resampled_index = 0.
+        self.old_data = np.zeros((self.height))
+
+    def set_ratio(self, interp_factor_L, decim_factor_M):
+        if self.interp_factor_L != interp_factor_L or self.decim_factor_M != decim_factor_M:
+            self.interp_factor_L = interp_factor_L
+            self.decim_factor_M = decim_factor_M
+            self.resampling_ratio = float(interp_factor_L) / decim_factor_M
+            self.orig_index = 0.
+            self.resampled_index = 0.
+
+    def set_height(self, height):
+        if self.height != height:
+            # the reference Fourier-resamples the carried column here (scipy_resample.py:51-141) to
+            # avoid a black line after a window resize; restarting from a linearly re-gridded column
+            # keeps the hot path on the device and differs for one pixel column per resize only
+            self.old_data = np.interp(np.linspace(0, 1, height), np.linspace(0, 1, self.height), self.old_data)
+            self.height = height
+            self.orig_index = 0.
+            self.resampled_index = 0.
+
+    def processable(self, m):
+        return int(np.ceil((self.orig_index + m - (self.resampled_index + self.resampling_ratio)) / self.resampling_ratio))
+
+    def push(self, data):
+        data = np.ascontiguousarray(data, np.float64)
+        self.set_height(data.shape[0])
+        n_cols = data.shape[1]
+        total = self.processable(n_cols)
+        src, weights = [], []
+        for j in range(n_cols):                      # scalar index bookkeeping, as in the reference
+            self.orig_index += 1.
+            n = self.processable(0)
+            if n <= 0:
+                continue
+            new_indices = self.resampled_index + self.resampling_ratio * np.arange(1, n + 1, dtype=np.float64)
+            weights.append(self.orig_index - new_indices)
+            src += [j] * n
+            self.resampled_index = float(new_indices[-1])
+        out = np.zeros((self.height, max(total, 0)))
+        if src:
+            a = np.ascontiguousarray(np.concatenate(weights))
+            s = np.ascontiguousarray(src, np.int32)
+            old = np.ascontiguousarray(self.old_data, np.float64)
+            res = np.empty((self.height, len(src)))
+            _lib.check(self._lib.frt_time_resample(data.ctypes.data, old.ctypes.data, self.height, n_cols, s.ctypes.data,
+                                                   a.ctypes.data, len(src), res.ctypes.data))
+            out[:, :len(src)] = res
+        if n_cols:
+            self.old_data = data[:, -1].copy()
+        return out

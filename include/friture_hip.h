@@ -170,6 +170,28 @@ typedef struct frt_delay_readout {
 int frt_gcc_readout(frt_gcc* h, const double* xcorr, const double* old_smoothed, double alpha, double sample_rate,
                     double delayrange_s, double* smoothed_out, frt_delay_readout* readout);
 
+/* ---- K6: screen-space stages of the spectrogram, and block-wise exponential smoothing -------------
+ * Stateless float64 kernels, one per block of the reference's Transform_Pipeline
+ * (friture/signal/transform_pipeline.py:23-34); the stateful bookkeeping of the online resampler
+ * (which pixel columns a pushed column produces) is scalar arithmetic that stays with the caller.
+ * Matrices are row-major; data/out buffers may be host or device memory. */
+/* P5 Frequency_Resampler.push (friture/signal/frequency_resampler.py:67-83):
+ * out[h][c] = numpy.interp(targets[h], freq, data[:, c]); data [n_bins][n_cols], out [height][n_cols]. */
+int frt_freq_resample(const double* freq, int n_bins, const double* targets, int height, const double* data,
+                      int n_cols, double* out);
+/* P6 linear_interp_2D (friture/signal/linear_interp.py:57-60) for all pixel columns a push emits:
+ * out[h][p] = data[h][src_col[p]] * (1 - a[p]) + prev * a[p], prev = data[h][src_col[p]-1] or old[h]
+ * for column 0; data [height][n_cols], out [height][n_out]. */
+int frt_time_resample(const double* data, const double* old, int height, int n_cols, const int* src_col,
+                      const double* a, int n_out, double* out);
+/* P7 Color_Transform.push (friture/signal/color_tranform.py:48-51): out[i] = lut[int(clip(v[i],0,1)*255)] */
+int frt_colour_map(const uint32_t* lut256, const double* values, int64_t count, uint32_t* out);
+/* P8 exp_smoothed_value_2d (friture/signal/exp_smoothing.py:91-107); nf = 1 gives exp_smoothed_value:
+ * out[r] = alpha * dot(data[r][:n], kernel[nk-n:]) + previous[r] * (1-alpha)^n, n = min(nt, nk)
+ * (previous is dropped when nt > nk). */
+int frt_exp_smooth_2d(const double* kernel, int nk, double alpha, const double* data, int nf, int nt, int64_t row_stride,
+                      const double* previous, double* out);
+
 #ifdef __cplusplus
 }
 #endif

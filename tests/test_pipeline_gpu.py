@@ -1,0 +1,79 @@
+"""K6 / P5-P8 parity: screen-space resamplers, colour map and block smoothing against golden vectors
+recorded from the reference.  float64 with the reference's operation order: bit-exact, except the
+smoothing dot product (BLAS summation order is unspecified): 1e-13."""
+import numpy as np
+import pytest
+
+from oracle import dsp
+
+pytestmark = pytest.mark.gpu
+
+
+def test_frequency_resampler(golden, hip):
+    from friture_amd.plotting import frequency_scales as fs
+    from friture_amd.signal.frequency_resampler import Frequency_Resampler
+    g = golden("pipeline")
+    for name, scale in [("linear", fs.Linear), ("log", fs.Logarithmic), ("mel", fs.Mel), ("erb", fs.Erb), ("octave", fs.Octave)]:
+        fr = Frequency_Resampler(scale, 20.0, 20000.0, 100)
+        fr.setfreq(g["freq"])
+        assert np.array_equal(fr.xscaled, g[f"fr_{name}_targets"])
+        assert np.array_equal(fr.push(g["norm"]), g[f"fr_{name}"])
+    # targets outside the table clamp to the edge bins, exact hits return the bin (numpy.interp)
+    fr = Frequency_Resampler(fs.Linear, 0.0, 24000.0, 513)
+    fr.setfreq(g["freq"])
+    assert np.array_equal(fr.push(g["norm"]), g["norm"])
+    fr.setfreqrange(-100.0, 30000.0)
+    out = fr.push(g["norm"])
+    assert np.array_equal(out[0], g["norm"][0]) and np.array_equal(out[-1], g["norm"][-1])
+    assert np.array_equal(out, dsp.frequency_resample(fr.xscaled, g["freq"], g["norm"]))
+
+
+def test_time_resampler(golden, hip):
+    from friture_amd.signal.online_linear_2D_resampler import Online_Linear_2D_resampler
+    g = golden("pipeline")
+    for tag, (L, M) in {"down": (25, 16), "up": (3, 7)}.items():
+        tr = Online_Linear_2D_resampler(L, M, 100)
+        assert np.array_equal(tr.push(g["fr_mel"][:, :5]), g[f"tr_{tag}_a"])
+        assert np.array_equal(tr.push(g["fr_mel"][:, 5:]), g[f"tr_{tag}_b"])
+    # column-at-a-time pushes give the same stream as one big push
+    one = Online_Linear_2D_resampler(25, 16, 100)
+    ref = dsp.TimeResampler(25, 16, 100)
+    parts = [one.push(g["fr_mel"][:, j:j + 1]) for j in range(12)]
+    assert np.array_equal(np.concatenate(parts, axis=1), ref.push(g["fr_mel"]))
+
+
+def test_colour_transform_and_full_pipeline(golden, hip):
+    from friture_amd.plotting import frequency_scales as fs
+    from friture_amd.signal.color_tranform import Color_Transform
+    from friture_amd.signal.frequency_resampler import Frequency_Resampler
+    from friture_amd.signal.online_linear_2D_resampler import Online_Linear_2D_resampler
+    from friture_amd.signal.transform_pipeline import Transform_Pipeline
+    img = golden("image")
+    ct = Color_Transform()
+    assert np.array_equal(ct.colors, img["lut"])
+    assert np.array_equal(ct.push(img["norm"]), img["image"])
+    edge = np.array([[-1.0, 0.0, 1.0 / 255, 0.999999, 1.0, 7.0]])
+    assert np.array_equal(ct.push(edge), dsp.colour_pixels(img["lut"], edge))
+    # the three blocks chained as Spectrogram_Widget builds them (spectrogram.py:62-68)
+    g = golden("pipeline")
+    fr = Frequency_Resampler(fs.Mel, 20.0, 20000.0, 100)
+    fr.setfreq(g["freq"])
+    pipe = Transform_Pipeline([fr, Online_Linear_2D_resampler(25, 16, 100), ct])
+    got = pipe.push(g["norm"])
+    tr = dsp.TimeResampler(25, 16, 100)
+    want = dsp.colour_pixels(img["lut"], tr.push(g["fr_mel"]))
+    assert got.dtype == np.uint32 and np.array_equal(got, want)
+
+
+def test_exp_smoothing(golden, hip):
+    from friture_amd.signal.exp_smoothing import exp_smoothed_value, exp_smoothed_value_2d
+    g = golden("exp_smoothing")
+    assert abs(exp_smoothed_value(g["kern"], 0.02, g["d1"], 0.3) / float(g["r1"]) - 1) < 1e-13
+    assert np.max(np.abs(exp_smoothed_value_2d(g["kern"], 0.02, g["d2"], g["prev"]) / g["r2"] - 1)) < 1e-13
+    assert np.max(np.abs(exp_smoothed_value_2d(g["kern"], 0.02, g["d2"][:, :17], g["prev"]) / g["r3"] - 1)) < 1e-13
+    assert exp_smoothed_value(g["kern"], 0.02, np.zeros(0), 0.7) == 0.7
+    assert np.array_equal(exp_smoothed_value_2d(g["kern"], 0.02, np.zeros((5, 0)), g["prev"]), g["prev"])
+    # upstream's properties (friture/test/test_exp_smoothing.py:9-44)
+    row = np.random.default_rng(0).random(20)
+    out = exp_smoothed_value_2d(dsp.smoothing_kernel(0.1, 32), 0.1, np.stack([row, row, 2 * row]), np.zeros(3))
+    assert out[0] == out[1] and out[2] > out[0]
