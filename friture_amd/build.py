@@ -28,7 +28,10 @@ CXXFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-W
 
 # translation units with special flags: the exact IIR bank replays the reference's IEEE operation
 # order (no fused multiply-add contraction) so that it can be bit-identical to lfilter.py:131-139
-EXTRA_FLAGS = {"iir.hip": ["-ffp-contract=off"], "pipeline.hip": ["-ffp-contract=off"]}
+# stft.hip: packed fp32 VALU instructions (v_pk_fma_f32 ...) issue slower than the scalar pair they
+# replace on gfx950 (measured: +7 % kernel time), so SLP packing of the butterflies is off
+EXTRA_FLAGS = {"iir.hip": ["-ffp-contract=off"], "pipeline.hip": ["-ffp-contract=off"],
+               "stft.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources() -> list[Path]:

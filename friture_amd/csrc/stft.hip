@@ -34,6 +34,7 @@ struct StftArgs {
     const uint32_t* lut;   // [256] or null
     long long x_stride;    // elements between channels
     long long n_frames;    // frames per channel
+    long long frame_base;  // first frame this launch handles
     long long out_cstride; // elements between channels in out
     int hop;
     int run;               // frames per run
@@ -90,7 +91,7 @@ stft_kernel(const StftArgs a) {
     const int ggc = group_ok ? gg : 0;
     const int chan = ggc / a.runs_per_channel;
     const int run = ggc - chan * a.runs_per_channel;
-    const long long f0 = (long long)run * a.run;
+    const long long f0 = a.frame_base + (long long)run * a.run;
     long long nfr = a.n_frames - f0;
     if (nfr > a.run) nfr = a.run;
     if (!group_ok) nfr = 0;
@@ -109,8 +110,8 @@ stft_kernel(const StftArgs a) {
     // workgroup size caps their register budget (1024 threads -> 128 VGPRs).
     constexpr bool HOIST = WAVE;
     constexpr int NC = HOIST ? 8 : 1;
-    C win[NC], twu[NC];
-    T wdb[NC], wdb_last = 0;
+    C win[NC], twu[HOIST ? 4 : 1];
+    T wdb[NC], wdb_mid = 0;
     const T* wtab = (const T*)a.window;
     const C* twn = (const C*)a.twn;
     const T* wgt = (const T*)a.weight;
@@ -120,12 +121,16 @@ stft_kernel(const StftArgs a) {
         for (int j = 0; j < 8; ++j) {
             const int n = i + j * TPF;
             win[j] = {wtab[2 * n], wtab[2 * n + 1]};
-            twu[j] = twn[n];
-            wdb[j] = wgt ? wgt[n] : (T)0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                 // bins i + j TPF and M - i - j TPF (see the unpack)
+            twu[j] = twn[i + j * TPF];
+            wdb[j] = wgt ? wgt[i + j * TPF] : (T)0;
+            wdb[4 + j] = wgt ? wgt[M - i - j * TPF] : (T)0;
         }
         twr.load((const C*)a.tw, i);
     }
-    if (wgt) wdb_last = wgt[M];
+    if (wgt) wdb_mid = wgt[M / 2];
 
     const T psd_scale = (T)(0.25 * a.psd_scale);
     const T norm_off = (T)a.norm_off, norm_scale = (T)a.norm_scale;
@@ -197,36 +202,40 @@ stft_kernel(const StftArgs a) {
             fft_pow2_forward<T, LOG2M, WAVE>(v, buf, i, twt);
         }
 
-        // ---- conjugate-symmetric unpack: X[k] = ((A+B) - i w^k (A-B))/2, A = Z[k], B = conj Z[M-k]
-        C part[8];
+        // ---- conjugate-symmetric unpack, two bins at a time ------------------------------------------
+        // With A = Z[k], B = conj Z[M-k], t = w^k (A - B):  X[k] = ((A+B) - i t)/2 and
+        // X[M-k] = conj((A+B) + i t)/2, so one (A+B, t) serves both |X[k]|^2 and |X[M-k]|^2.  Thread i
+        // finishes k = i + j TPF for j = 0..3 (k < M/2) together with M - k; k = 0 yields bins 0 and M,
+        // and the self-paired bin M/2 is |Z[M/2]|^2 / N^2 (thread 0, slot 4).
+        C part[4];
 #ifdef FRT_ABLATE
         if (a.ablate & 8) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) part[j] = v[7 - j];
+            for (int j = 0; j < 4; ++j) part[j] = v[7 - j];
         } else
 #endif
         if constexpr (WAVE) {
             const int lane = tid & 63;
             const int src = lane - i + ((TPF - i) & (TPF - 1));
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                C o = v[7 - j];
-                C p = {shfl_t(o.x, src), shfl_t(o.y, src)};
-                C own = v[(8 - j) & 7];
-                part[j] = (i == 0) ? own : p;
+            for (int j = 0; j < 4; ++j) {
+                // Z[M-k] sits in slot 7-j of lane TPF-i; lane 0 pairs inside itself: slot (8-j) mod 8
+                const C mine = (i == 0) ? v[(8 - j) & 7] : v[7 - j];
+                part[j] = {shfl_t(mine.x, src), shfl_t(mine.y, src)};
             }
         } else {
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) buf[lds_pad(i + j * TPF)] = v[j];
+            for (int j = 4; j < 8; ++j) buf[lds_pad(i + j * TPF)] = v[j];
+            if (i == 0) buf[lds_pad(0)] = v[0];
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) part[j] = buf[lds_pad((M - (i + j * TPF)) & (M - 1))];
+            for (int j = 0; j < 4; ++j) part[j] = buf[lds_pad((M - (i + j * TPF)) & (M - 1))];
         }
 
-        T res[8];
+        T res[8];          // res[j] = P[i + j TPF], res[4 + j] = P[M - i - j TPF]
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
             C A = v[j], B = cconj(part[j]);
             C S = A + B, D = A - B;
             C tu;
@@ -236,11 +245,12 @@ stft_kernel(const StftArgs a) {
                 tu = twn[i + j * TPF + zero];
             }
             C t = cmul(tu, D);
-            T xr = S.x + t.y, xi = S.y - t.x;
-            res[j] = (xr * xr + xi * xi) * psd_scale;
+            T ar = S.x + t.y, ai = S.y - t.x;      // 2 X[k]
+            T br = S.x - t.y, bi = S.y + t.x;      // 2 conj X[M-k]
+            res[j] = (ar * ar + ai * ai) * psd_scale;
+            res[4 + j] = (br * br + bi * bi) * psd_scale;
         }
-        T d0 = v[0].x - v[0].y;
-        T res_last = d0 * d0 * (T)a.psd_scale;
+        T res_mid = (v[4].x * v[4].x + v[4].y * v[4].y) * (T)a.psd_scale;     // bin M/2, meaningful for i == 0
 
         // Advance the register window by one hop *before* the stores are issued: the wait for the
         // prefetched samples then sits behind a whole transform (latency hidden) and ahead of this
@@ -252,64 +262,65 @@ stft_kernel(const StftArgs a) {
             for (int t = 0; t < NEW; ++t) raw[8 - NEW + t] = nxt[t];
         }
 
-
 #ifdef FRT_ABLATE
         if (a.ablate & 1) {
-            T acc = res_last;
+            T acc = res_mid;
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc += res[j];
             if (acc == (T)-12345.678) outc[0] = acc;     // keeps the results live, never true
         } else
 #endif
         if (valid) {
+            // element offsets of the 8 (+1) bins inside the row
+            const int klo = i, khi = M - i;
             T* row = outc + (f0 + g) * (M + 1);
-            if (a.kind == FRT_STFT_PSD) {
+            auto store_all = [&](auto* r, auto conv) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) row[i + j * TPF] = res[j];
-                if (i == 0) row[M] = res_last;
+                for (int j = 0; j < 4; ++j) {
+                    r[klo + j * TPF] = conv(res[j]);
+                    r[khi - j * TPF] = conv(res[4 + j]);
+                }
+                if (i == 0) r[M / 2] = conv(res_mid);
+            };
+            if (a.kind == FRT_STFT_PSD) {
+                store_all(row, [](T x) { return x; });
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    T wj;
+                for (int j = 0; j < 4; ++j) {
+                    T wl, wh;
                     if constexpr (HOIST) {
-                        wj = wdb[j];
+                        wl = wdb[j];
+                        wh = wdb[4 + j];
                     } else {
-                        wj = wgt ? wgt[i + j * TPF + zero] : (T)0;
+                        wl = wgt ? wgt[klo + j * TPF + zero] : (T)0;
+                        wh = wgt ? wgt[khi - j * TPF + zero] : (T)0;
                     }
-                    res[j] = db10<T>(res[j]) + wj;
+                    res[j] = db10<T>(res[j]) + wl;
+                    res[4 + j] = db10<T>(res[4 + j]) + wh;
                 }
-                res_last = db10<T>(res_last) + wdb_last;
-                if (a.kind == FRT_STFT_DB) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) row[i + j * TPF] = res[j];
-                    if (i == 0) row[M] = res_last;
-                } else {
+                res_mid = db10<T>(res_mid) + wdb_mid;
+                if (a.kind >= FRT_STFT_NORM) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) res[j] = (res[j] + norm_off) * norm_scale;
-                    res_last = (res_last + norm_off) * norm_scale;
-                    if (a.kind == FRT_STFT_NORM) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) row[i + j * TPF] = res[j];
-                        if (i == 0) row[M] = res_last;
-                    } else {
-                        // colour words are 4 bytes whatever the arithmetic type
-                        uint32_t* prow = (uint32_t*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
-                        auto pix = [&](T vv) -> uint32_t {
-                            vv = fmin(fmax(vv, (T)0), (T)1);   // NaN -> 0
-                            return lut_lds[(int)(vv * (T)255)];
-                        };
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) prow[i + j * TPF] = pix(res[j]);
-                        if (i == 0) prow[M] = pix(res_last);
-                    }
+                    res_mid = (res_mid + norm_off) * norm_scale;
+                }
+                if (a.kind != FRT_STFT_IMAGE) {
+                    store_all(row, [](T x) { return x; });
+                } else {
+                    // colour words are 4 bytes whatever the arithmetic type
+                    uint32_t* prow = (uint32_t*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
+                    store_all(prow, [&](T vv) -> uint32_t {
+                        vv = fmin(fmax(vv, (T)0), (T)1);   // NaN -> 0
+                        return lut_lds[(int)(vv * (T)255)];
+                    });
                 }
             }
         }
-
     }
 }
 
 // ---- host side -----------------------------------------------------------------------------------
+
 
 template <typename TIN, typename T, int LOG2M, int SHIFT>
 static int launch_one(const StftArgs& a, int blocks, hipStream_t stream) {
@@ -426,8 +437,8 @@ extern "C" int frt_stft_set_stream(frt_stft* h, void* s) {
 }
 
 extern "C" int frt_stft_set_run_length(frt_stft* h, int r) {
-    FRT_REQUIRE(h && r >= 0, "frt_stft_set_run_length: bad argument");
-    h->run_length = r;
+    FRT_REQUIRE(h, "frt_stft_set_run_length: null handle");
+    h->run_length = r < 0 ? -r : r;
     return FRT_OK;
 }
 
@@ -508,7 +519,10 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     }
     if (run > F) run = (int)F;
     a.run = run;
-    a.runs_per_channel = (int)((F + run - 1) / run);
+    a.frame_base = 0;
+
+    const long long rest = F - a.frame_base;
+    a.runs_per_channel = (int)((rest + run - 1) / run);
     const long long groups = (long long)a.runs_per_channel * h->n_channels;
     FRT_REQUIRE(groups < (1ll << 31), "frt_stft_run: too many lane groups");
     a.n_groups = (int)groups;
