@@ -1,0 +1,106 @@
+"""The spectrum widget's processing chain (friture/spectrum.py:125-184) without its Qt shell.
+
+`SpectrumAnalyzer.handle_new_data(floatdata)` does what Spectrum_Widget's slot does per audio chunk:
+push into the ring, transform every realizable frame (one batched launch of the float64 STFT kernel
+over the contiguous ring window instead of a Python loop of analyzelive calls), exponential smoothing
+across the new frames, dB + weighting (or the dual-channel ratio), spectral peak and the harmonic
+product spectrum pitch — the last four fused in frt_spectrum_post.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib, tables
+from .audioproc import audioproc
+from .constants import SAMPLING_RATE
+from .ringbuffer import RingBuffer
+from .stft import StftEngine
+
+DEFAULT_FFT_SIZE = 8192         # spectrum_settings.py:27-37
+DEFAULT_RESPONSE_TIME = 0.025
+
+
+class SpectrumAnalyzer:
+    def __init__(self, fft_size: int = DEFAULT_FFT_SIZE, overlap: float = 3. / 4., weighting: int = 1,
+                 response_time: float = DEFAULT_RESPONSE_TIME, dual_channels: bool = False):
+        self._lib = _lib.init()
+        self.ringbuffer = RingBuffer()
+        self.proc = audioproc()
+        self.overlap = overlap
+        self.weighting = weighting
+        self.dual_channels = dual_channels
+        self.response_time = response_time
+        self.old_index = 0
+        self.setfftsize(fft_size)
+        self.fmax = self.fpitch = 0.0
+        self.dB_spectrogram = None
+
+    # ---- configuration (names of friture/spectrum.py) ----------------------------------------------
+    def setfftsize(self, fft_size):
+        self.fft_size = fft_size
+        self.proc.set_fftsize(fft_size)
+        self.freq = self.proc.get_freq_scale()
+        self.hop = int(fft_size * (1. - self.overlap))
+        self._engine = StftEngine(fft_size, self.hop, 1, 64)
+        self.update_weighting()
+        self.dispbuffers1 = np.zeros(len(self.freq))
+        self.dispbuffers2 = np.zeros(len(self.freq))
+        self.setresponsetime(self.response_time)
+
+    def setresponsetime(self, response_time):
+        self.response_time = response_time
+        w = 0.65
+        n = response_time * SAMPLING_RATE / (self.fft_size * (1. - self.overlap))
+        self.alpha = 1. - (1. - w) ** (1. / (n + 1))
+        self.kernel = (1. - self.alpha) ** np.arange(2 * 4096 - 1, -1, -1)
+
+    def setweighting(self, weighting):
+        self.weighting = weighting
+        self.update_weighting()
+
+    def update_weighting(self):
+        A, B, C = self.proc.get_freq_weighting()
+        self.w = {0: np.zeros(A.shape), 1: A, 2: B}.get(self.weighting, C)
+
+    # ---- the slot -------------------------------------------------------------------------------------
+    def handle_new_data(self, floatdata):
+        self.ringbuffer.push(floatdata, 0.)
+        index = self.ringbuffer.offset
+        available = index - self.old_index
+        if available < 0:
+            available = 0
+            self.old_index = index
+        needed = self.fft_size * (1. - self.overlap)
+        realizable = int(np.floor(available / needed))
+        if realizable <= 0:
+            return None
+        # frame i of the reference ends at old_index + i*hop: all frames form one contiguous window
+        span = self.fft_size + (realizable - 1) * self.hop
+        last = self.old_index + (realizable - 1) * self.hop
+        window = self.ringbuffer.data_indexed(last, span)
+        self.old_index += realizable * self.hop
+        sp1, db, peak, pitch = self._post(self._engine.psd(window[0:1, :].copy())[0], self.dispbuffers1, self.w, None)
+        self.dispbuffers1 = sp1
+        if self.dual_channels and window.shape[0] > 1:
+            sp2, db, peak, _ = self._post(self._engine.psd(window[1:2, :].copy())[0], self.dispbuffers2, None, sp1)
+            self.dispbuffers2 = sp2
+        self.dB_spectrogram = db
+        self.fmax = self.freq[peak]
+        self.fpitch = max(self.freq[pitch], 1e-20)
+        return self.freq, db, self.fmax, self.fpitch
+
+    def _post(self, psd, previous, weight, ref):
+        psd = np.ascontiguousarray(psd, np.float64)             # [frames, bins]
+        nf, nb = psd.shape
+        prev = np.ascontiguousarray(previous, np.float64)
+        sm, db = np.empty(nb), np.empty(nb)
+        peak, pitch = ctypes.c_int(0), ctypes.c_int(0)
+        wp = None if weight is None else np.ascontiguousarray(weight, np.float64)
+        rp = None if ref is None else np.ascontiguousarray(ref, np.float64)
+        _lib.check(self._lib.frt_spectrum_post(
+            psd.ctypes.data, 0, nf, nb, nb, self.kernel.ctypes.data, len(self.kernel), float(self.alpha), prev.ctypes.data,
+            None if wp is None else wp.ctypes.data, None if rp is None else rp.ctypes.data, sm.ctypes.data, db.ctypes.data,
+            ctypes.byref(peak), ctypes.byref(pitch)))
+        return sm, db, peak.value, pitch.value

@@ -192,6 +192,17 @@ int frt_colour_map(const uint32_t* lut256, const double* values, int64_t count, 
 int frt_exp_smooth_2d(const double* kernel, int nk, double alpha, const double* data, int nf, int nt, int64_t row_stride,
                       const double* previous, double* out);
 
+/* ---- spectrum widget post-processing (Spectrum_Widget.handle_new_data, friture/spectrum.py:156-182) --
+ * psd: the n_frames new PSD frames [n_frames][frame_stride] (float when psd_is_f32, else double; the
+ * frame-major slab frt_stft_run writes).  smoothed = exp_smoothed_value_2d(kernel, alpha, psd^T, previous);
+ * db = 10 log10(smoothed + 1e-30) + weight_db (or - 10 log10(ref_smoothed + 1e-30) in dual-channel mode);
+ * *peak_index_out = argmax(db); *pitch_index_out = argmax of the harmonic product spectrum
+ * s[:K] s[::2][:K] s[::3][:K], K = n_bins / 3, of smoothed (of ref_smoothed in dual-channel mode). */
+int frt_spectrum_post(const void* psd, int psd_is_f32, int n_frames, int n_bins, int64_t frame_stride,
+                      const double* kernel, int nk, double alpha, const double* previous, const double* weight_db,
+                      const double* ref_smoothed, double* smoothed_out, double* db_out, int* peak_index_out,
+                      int* pitch_index_out);
+
 #ifdef __cplusplus
 }
 #endif

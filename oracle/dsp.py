@@ -174,6 +174,26 @@ def exp_smoothed_value_2d(kernel, alpha, data, previous):
     return alpha * (data[:, :nt] @ kernel[nk - nt:nk]) + previous * decay
 
 
+def harmonic_product_spectrum(sp):
+    """sp[:K] * sp[::2][:K] * sp[::3][:K] with K = len(sp) // 3  — friture/spectrum.py:103-123."""
+    k = sp.shape[0] // 3
+    return sp[:k] * sp[::2][:k] * sp[::3][:k]
+
+
+def spectrum_readout(spn, kernel, alpha, previous, weight, freq, ref_smoothed=None):
+    """Post-processing of Spectrum_Widget.handle_new_data (friture/spectrum.py:156-182) for one channel.
+    spn: (bins, frames).  Returns dict(smoothed, db, peak_index, pitch_index, fmax, fpitch)."""
+    sp = exp_smoothed_value_2d(kernel, alpha, spn, previous)
+    if ref_smoothed is not None:
+        db = log_spectrum(sp) - log_spectrum(ref_smoothed)
+    else:
+        db = log_spectrum(sp) + weight
+    i = int(np.argmax(db))
+    hps = harmonic_product_spectrum(ref_smoothed if ref_smoothed is not None else sp)
+    p = int(np.argmax(hps))
+    return dict(smoothed=sp, db=db, peak_index=i, pitch_index=p, fmax=freq[i], fpitch=max(freq[p], 1e-20))
+
+
 # --------------------------------------------------------------------------------------------
 # O1 / G2: direct-form-II-transposed IIR, decimation, exact octave bank
 # --------------------------------------------------------------------------------------------

@@ -153,6 +153,34 @@ def main():
     same("exp 2d short", dsp.exp_smoothed_value_2d(kern, 0.02, d2[:, :17], prev), r3)
     np.savez_compressed(GOLD / "exp_smoothing.npz", kern=kern, d1=d1, d2=d2, prev=prev, r1=r1, r2=r2, r3=r3)
 
+    # ---- spectrum widget post-processing (smoothing, dB, peak, harmonic product spectrum) -------------
+    # Spectrum_Widget cannot be imported (QObject base); its pure method harmonic_product_spectrum is
+    # lifted out of the unmodified source text and executed as is.
+    print("spectrum widget read-out")
+    import ast
+    src = (Path(refshim.REFERENCE_ROOT) / "friture" / "spectrum.py").read_text()
+    fn = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "harmonic_product_spectrum")
+    ns = {"ones": np.ones}
+    exec(compile(ast.Module([fn], []), "friture/spectrum.py", "exec"), ns)
+    n_fft, hop, frames = 1024, 256, 9
+    xs = as_f32_f64(tone(123, n_fft + hop * (frames - 1), 440.0) + tone(5, n_fft + hop * (frames - 1), 880.0))
+    proc = audioproc()
+    proc.set_fftsize(n_fft)
+    spn = np.stack([proc.analyzelive(xs[f * hop:f * hop + n_fft]) for f in range(frames)], axis=1)
+    alpha = 1.0 - (1.0 - 0.65) ** (1.0 / (0.025 * 48000 / hop + 1))        # spectrum.py:196-222, 25 ms response
+    kern = (1.0 - alpha) ** np.arange(2 * 4096 - 1, -1, -1)
+    prev = np.zeros(513)
+    sp_ref = exp_smoothed_value_2d(kern, alpha, spn, prev)
+    hps_ref = ns["harmonic_product_spectrum"](None, sp_ref)
+    same("harmonic product spectrum", dsp.harmonic_product_spectrum(sp_ref), hps_ref)
+    wA = proc.get_freq_weighting()[0]
+    ro = dsp.spectrum_readout(spn, kern, alpha, prev, wA, proc.get_freq_scale())
+    db_ref = 10.0 * np.log10(sp_ref + 1e-30) + wA
+    same("spectrum dB", ro["db"], db_ref)
+    assert ro["peak_index"] == int(np.argmax(db_ref)) and ro["pitch_index"] == int(np.argmax(hps_ref))
+    np.savez_compressed(GOLD / "spectrum.npz", x=xs.astype(np.float32), spn=spn, kern_alpha=alpha, smoothed=sp_ref, db=db_ref,
+                        hps=hps_ref, peak_index=int(np.argmax(db_ref)), pitch_index=int(np.argmax(hps_ref)), weight=wA)
+
     # ---- O1/G2: IIR ------------------------------------------------------------------------------
     print("O1/G2 lfilter, decimate, exact IIR bank")
     bdec, adec = [np.array(v) for v in generated_filters.PARAMS["dec"]]

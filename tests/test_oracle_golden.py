@@ -132,3 +132,13 @@ def test_ring(golden):
         assert np.array_equal(ring.data_indexed(ring.offset - 100, ln - 100), g[f"win{step}"])
     with pytest.raises(Exception):
         dsp.decimate(np.ones(3), np.ones(3), np.zeros(0))
+
+
+def test_spectrum_readout(golden):
+    g = golden("spectrum")
+    alpha = float(g["kern_alpha"])
+    ro = dsp.spectrum_readout(g["spn"], dsp.smoothing_kernel(alpha, 8192), alpha, np.zeros(513), g["weight"],
+                              dsp.frequency_axis(1024))
+    assert np.array_equal(ro["smoothed"], g["smoothed"]) and np.array_equal(ro["db"], g["db"])
+    assert np.array_equal(dsp.harmonic_product_spectrum(g["smoothed"]), g["hps"])
+    assert ro["peak_index"] == int(g["peak_index"]) and ro["pitch_index"] == int(g["pitch_index"])

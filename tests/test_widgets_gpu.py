@@ -1,0 +1,138 @@
+"""Widget-level chains (the P3 drivers and the §8f "next" rows) against the oracle: the Qt-free engines
+reproduce what the widgets' handle_new_data slots compute, chunk by chunk."""
+import numpy as np
+import pytest
+
+from conftest import rel_max, synth
+from oracle import dsp
+
+pytestmark = pytest.mark.gpu
+
+
+def test_spectrum_post_against_golden(golden, hip):
+    import ctypes
+
+    from friture_amd import _lib
+    g = golden("spectrum")
+    spn = g["spn"]                                   # (bins, frames)
+    psd = np.ascontiguousarray(spn.T)
+    alpha = float(g["kern_alpha"])
+    kern = dsp.smoothing_kernel(alpha, 8192)
+    prev = np.zeros(513)
+    sm, db = np.empty(513), np.empty(513)
+    peak, pitch = ctypes.c_int(), ctypes.c_int()
+    w = np.ascontiguousarray(g["weight"])
+    _lib.check(hip.frt_spectrum_post(psd.ctypes.data, 0, psd.shape[0], 513, 513, kern.ctypes.data, 8192, alpha,
+                                     prev.ctypes.data, w.ctypes.data, None, sm.ctypes.data, db.ctypes.data,
+                                     ctypes.byref(peak), ctypes.byref(pitch)))
+    assert rel_max(sm, g["smoothed"]) < 1e-13 and np.max(np.abs(db - g["db"])) < 1e-9
+    assert peak.value == int(g["peak_index"]) and pitch.value == int(g["pitch_index"])
+    # float32 PSD slab (what the batch STFT engine leaves in HBM) and the dual-channel ratio
+    psd32 = psd.astype(np.float32)
+    ref = dsp.spectrum_readout(psd32.astype(np.float64).T, kern, alpha, prev, None, np.arange(513.0), ref_smoothed=g["smoothed"])
+    _lib.check(hip.frt_spectrum_post(psd32.ctypes.data, 1, psd.shape[0], 513, 513, kern.ctypes.data, 8192, alpha,
+                                     prev.ctypes.data, None, np.ascontiguousarray(g["smoothed"]).ctypes.data, sm.ctypes.data,
+                                     db.ctypes.data, ctypes.byref(peak), ctypes.byref(pitch)))
+    assert rel_max(sm, ref["smoothed"]) < 1e-13 and np.max(np.abs(db - ref["db"])) < 1e-9
+    assert peak.value == ref["peak_index"] and pitch.value == ref["pitch_index"]
+
+
+def test_spectrum_analyzer_stream(hip):
+    """512-sample chunks through SpectrumAnalyzer vs the widget body restated with the oracle."""
+    from friture_amd.spectrum import SpectrumAnalyzer
+    n_fft, overlap = 1024, 0.75
+    hop = 256
+    sa = SpectrumAnalyzer(n_fft, overlap, weighting=1, response_time=0.025)
+    x = (0.5 * np.sin(2 * np.pi * 440 * np.arange(512 * 20) / 48000) + 0.01 * synth("noise", 512 * 20, 2)).astype(np.float32)
+    ring, old_index = dsp.MirrorRing(), 0
+    prev = np.zeros(513)
+    w = dsp.weighting_curves(dsp.frequency_axis(n_fft))[0]
+    last = None
+    for c in range(20):
+        chunk = x[None, c * 512:(c + 1) * 512].astype(np.float64)
+        got = sa.handle_new_data(chunk)
+        ring.push(chunk)
+        realizable = int(np.floor((ring.offset - old_index) / (n_fft * (1 - overlap))))
+        if realizable > 0:
+            cols = []
+            for _ in range(realizable):
+                cols.append(dsp.psd_frame(ring.data_indexed(old_index, n_fft)[0], dsp.hann_symmetric(n_fft)))
+                old_index += hop
+            last = dsp.spectrum_readout(np.stack(cols, axis=1), sa.kernel, sa.alpha, prev, w, dsp.frequency_axis(n_fft))
+            prev = last["smoothed"]
+            assert got is not None
+            assert np.max(np.abs(got[1] - last["db"])) < 1e-8
+            assert got[2] == last["fmax"] and got[3] == last["fpitch"]
+        else:
+            assert got is None
+    assert abs(last["fmax"] - 440) < 48000 / n_fft
+
+
+def test_stft_stream_equals_batch(hip):
+    import torch
+
+    from friture_amd.stft import StftEngine
+    from friture_amd.stream import StftStream
+    x = np.stack([synth("noise", 40000, 1), synth("chirp", 40000, 2)])
+    st = StftStream(1024, 256, 2, max_chunk=512)
+    parts = []
+    pos = 0
+    for n in [512] * 30 + [100, 7, 3000, 512, 512]:
+        parts.append(st.push(x[:, pos:pos + n]))
+        pos += n
+    torch.cuda.synchronize()
+    got = torch.cat(parts, dim=1).cpu().numpy()
+    want = StftEngine(1024, 256, 2, 32).psd(x[:, :pos])
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_octave_spectrum_chain(hip):
+    from friture_amd.octavespectrum import OctaveSpectrum
+    osp = OctaveSpectrum(3, weighting=1, response_time=0.125)
+    ref_bank = dsp.OlaBank(3)
+    alphas, kernels = dsp.band_smoothing_setup(3, 0.125)
+    prev = [0.0] * 27
+    x = synth("noise", 512 * 12, 9).astype(np.float64)
+    fi, _, _ = dsp.octave_frequencies(27, 3)
+    A = dsp.band_weighting(fi)[0]
+    for c in range(12):
+        chunk = x[None, c * 512:(c + 1) * 512]
+        got = osp.handle_new_data(chunk)
+        y, _ = ref_bank.filter(chunk[0])
+        prev = dsp.band_energies(y, kernels, alphas, prev)
+        ref_db = dsp.band_db(prev, A)
+        assert np.max(np.abs(got[3] - ref_db)) < 1e-7
+    assert got[2] == osp.filters.f_nominal and len(got[2]) == 27
+
+
+def test_spectrogram_chain(hip):
+    """ring -> STFT(f64) -> dB/normalise -> freq resample -> time resample -> colour, chunked."""
+    from friture_amd.spectrogram import Spectrogram
+    sg = Spectrogram(fft_size=1024, weighting=1, screen_width=600, screen_height=120, timerange_s=2.0)
+    x = synth("chirp", 512 * 16, 4).astype(np.float64)
+    lut = dsp.colour_lut(dsp.cmrmap())
+    w = dsp.weighting_curves(dsp.frequency_axis(1024))[0]
+    tg = dsp.frequency_targets("mel", 20.0, 20000.0, 120)
+    ratio = sg.sfft_rate_frac / (__import__("fractions").Fraction(600, 2000))
+    tr = dsp.TimeResampler(sg.sfft_rate_frac, __import__("fractions").Fraction(600, 2000), 120)
+    ring, old_index = dsp.MirrorRing(), 0
+    total_px, mismatched = 0, 0
+    for c in range(16):
+        chunk = x[None, c * 512:(c + 1) * 512]
+        got = sg.handle_new_data(chunk)
+        ring.push(chunk)
+        realizable = int(np.floor((ring.offset - old_index) / 256.0))
+        if realizable <= 0:
+            assert got is None
+            continue
+        cols = []
+        for _ in range(realizable):
+            cols.append(dsp.psd_frame(ring.data_indexed(old_index, 1024)[0], dsp.hann_symmetric(1024)))
+            old_index += 256
+        norm = dsp.normalise(dsp.log_spectrum(np.stack(cols, axis=1)) + w[:, None], -140.0, 0.0)
+        want = dsp.colour_pixels(lut, tr.push(dsp.frequency_resample(tg, dsp.frequency_axis(1024), norm)))
+        assert got.shape == want.shape and got.dtype == np.uint32
+        total_px += want.size
+        mismatched += int(np.sum(got != want))
+    # the GPU STFT differs from pocketfft in the last bits: a pixel can flip only at a LUT bin edge
+    assert total_px > 0 and mismatched <= 1e-3 * total_px
