@@ -285,6 +285,7 @@ extern "C" int frt_octbank_create(frt_octbank** out, int bands_per_octave, int n
     h->mode = mode;
     h->nbands = kNOctave * bands_per_octave;
     h->nfilt = bands_per_octave + 1;
+    h->use_graph = getenv("FRT_NO_GRAPH") == nullptr;
     h->h_coef.assign((size_t)h->nfilt * kCoefStride, 0.0);
     h->h_order.assign(h->nfilt, 0);
     for (int i = 0; i < bands_per_octave; ++i) {       // 4th-order band-passes, 5 + 5 coefficients
@@ -320,6 +321,11 @@ extern "C" int frt_octbank_create(frt_octbank** out, int bands_per_octave, int n
 
 extern "C" void frt_octbank_destroy(frt_octbank* h) {
     if (!h) return;
+    for (auto& e : h->graphs)
+        if (e.exec) (void)hipGraphExecDestroy(e.exec);
+    if (h->gstream) (void)hipStreamDestroy(h->gstream);
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
     frt_ola_destroy(h);
     DeviceBuffer* bufs[] = {&h->coef, &h->order, &h->state, &h->xin, &h->ypacked, &h->chunk_end, &h->chunk_init, &h->power,
                             &h->eblock, &h->alpha, &h->decay_n, &h->smooth, &h->weight, &h->eout};
@@ -344,6 +350,7 @@ extern "C" int frt_octbank_set_chunk(frt_octbank* h, int chunk0) {
 
 extern "C" int frt_octbank_reset(frt_octbank* h) {
     FRT_REQUIRE(h, "frt_octbank_reset: null handle");
+    if (h->gstream) FRT_HIP_CHECK(hipStreamSynchronize(h->gstream));
     FRT_HIP_CHECK(hipMemsetAsync(h->state.ptr, 0, h->state.bytes, h->stream));
     if (h->ola) {
         int rc = frt_ola_reset(h);
@@ -484,6 +491,93 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
     return FRT_OK;
 }
 
+
+// Host-buffer path of frt_octbank_filter.  The first call with a block length runs eagerly (and
+// allocates every device buffer); the second captures H2D copy + stage kernels + D2H copy into a
+// hipGraph on a private stream; later calls replay it.  A graph is dropped when one of the device
+// buffers it baked in has been re-allocated since.
+static void snapshot_ptrs(const frt_octbank* h, const void** p) {
+    p[0] = h->xin.ptr;
+    p[1] = h->ypacked.ptr;
+    for (int j = 1; j < kNOctave; ++j) p[1 + j] = h->xbuf[j].ptr;
+    p[1 + kNOctave] = h->ola ? h->ola->pending.ptr : nullptr;
+}
+
+static int enqueue_filter(frt_octbank* h, int n, int64_t plen, hipStream_t s) {
+    const size_t in_bytes = (size_t)h->n_channels * n * sizeof(double), out_bytes = (size_t)h->n_channels * plen * sizeof(double);
+    FRT_HIP_CHECK(hipMemcpyAsync(h->xin.ptr, h->pin_in, in_bytes, hipMemcpyHostToDevice, s));
+    hipStream_t keep = h->stream;
+    h->stream = s;
+    int rc = h->mode == 1 ? frt_ola_filter(h, h->xin.as<double>(), n, h->ypacked.as<double>(), plen)
+                          : run_stages(h, h->xin.ptr, 0, n, n, h->ypacked.as<double>(), plen, nullptr, 0, 0);
+    h->stream = keep;
+    if (rc) return rc;
+    FRT_HIP_CHECK(hipMemcpyAsync(h->pin_out, h->ypacked.ptr, out_bytes, hipMemcpyDeviceToHost, s));
+    return FRT_OK;
+}
+
+static int filter_host(frt_octbank* h, const double* x, int n, double* y_packed, int64_t plen) {
+    const size_t in_bytes = (size_t)h->n_channels * n * sizeof(double), out_bytes = (size_t)h->n_channels * plen * sizeof(double);
+    int rc;
+    if ((rc = h->xin.reserve(in_bytes)) || (rc = h->ypacked.reserve(out_bytes))) return rc;
+    if (in_bytes > h->pin_in_bytes) {
+        if (h->pin_in) (void)hipHostFree(h->pin_in);
+        FRT_HIP_CHECK(hipHostMalloc(&h->pin_in, in_bytes, hipHostMallocDefault));
+        h->pin_in_bytes = in_bytes;
+    }
+    if (out_bytes > h->pin_out_bytes) {
+        if (h->pin_out) (void)hipHostFree(h->pin_out);
+        FRT_HIP_CHECK(hipHostMalloc(&h->pin_out, out_bytes, hipHostMallocDefault));
+        h->pin_out_bytes = out_bytes;
+    }
+    if (!h->gstream) FRT_HIP_CHECK(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
+    FRT_HIP_CHECK(hipStreamSynchronize(h->stream));        // order after earlier work on the caller's stream
+    memcpy(h->pin_in, x, in_bytes);
+
+    frt_octbank::StreamGraph* g = nullptr;
+    for (auto& e : h->graphs)
+        if (e.n == n) g = &e;
+    const void* now[2 + kNOctave];
+    const bool time_parallel = h->mode == 0 && h->chunk0 > 0 && n >= 2 * h->chunk0;   // allocates scratch per call shape
+    if (g) {
+        snapshot_ptrs(h, now);
+        if (memcmp(now, g->ptrs, sizeof(now)) != 0) {         // a buffer moved: the graph is stale
+            (void)hipGraphExecDestroy(g->exec);
+            g->exec = nullptr;
+            g->n = -1;
+            g = nullptr;
+            h->warmed_n = -1;
+        }
+    }
+    if (g) {
+        FRT_HIP_CHECK(hipGraphLaunch(g->exec, h->gstream));
+    } else if (!h->use_graph || time_parallel || h->warmed_n != n) {
+        if ((rc = enqueue_filter(h, n, plen, h->gstream))) return rc;
+        h->warmed_n = n;
+    } else {
+        hipGraph_t graph = nullptr;
+        FRT_HIP_CHECK(hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal));
+        rc = enqueue_filter(h, n, plen, h->gstream);
+        hipError_t e = hipStreamEndCapture(h->gstream, &graph);
+        if (rc) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        FRT_HIP_CHECK(e);
+        frt_octbank::StreamGraph entry;
+        entry.n = n;
+        e = hipGraphInstantiate(&entry.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        FRT_HIP_CHECK(e);
+        snapshot_ptrs(h, entry.ptrs);
+        h->graphs.push_back(entry);
+        FRT_HIP_CHECK(hipGraphLaunch(entry.exec, h->gstream));
+    }
+    FRT_HIP_CHECK(hipStreamSynchronize(h->gstream));
+    memcpy(y_packed, h->pin_out, out_bytes);
+    return FRT_OK;
+}
+
 extern "C" int frt_octbank_filter(frt_octbank* h, const double* x, int n, double* y_packed, int* dec_out) {
     FRT_REQUIRE(h && h->bpo >= 1, "frt_octbank_filter: needs a handle with bands");
     FRT_REQUIRE(n >= 0, "frt_octbank_filter: n %d < 0", n);
@@ -499,18 +593,7 @@ extern "C" int frt_octbank_filter(frt_octbank* h, const double* x, int n, double
     FRT_REQUIRE(dx == dy, "frt_octbank_filter: input and output must both be host or both be device memory");
     if (h->mode == 1) FRT_REQUIRE(n <= 1024, "frt_octbank_filter: the FFT bank takes blocks of at most 1024 samples (got %d)", n);
     if (dx) return h->mode == 1 ? frt_ola_filter(h, x, n, y_packed, plen) : run_stages(h, x, 0, n, n, y_packed, plen, nullptr, 0, 0);
-    int rc;
-    if ((rc = h->xin.reserve((size_t)h->n_channels * n * sizeof(double))) ||
-        (rc = h->ypacked.reserve((size_t)h->n_channels * plen * sizeof(double))))
-        return rc;
-    FRT_HIP_CHECK(hipMemcpyAsync(h->xin.ptr, x, (size_t)h->n_channels * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    rc = h->mode == 1 ? frt_ola_filter(h, h->xin.as<double>(), n, h->ypacked.as<double>(), plen)
-                      : run_stages(h, h->xin.ptr, 0, n, n, h->ypacked.as<double>(), plen, nullptr, 0, 0);
-    if (rc) return rc;
-    FRT_HIP_CHECK(hipMemcpyAsync(y_packed, h->ypacked.ptr, (size_t)h->n_channels * plen * sizeof(double), hipMemcpyDeviceToHost,
-                                 h->stream));
-    FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
-    return FRT_OK;
+    return filter_host(h, x, n, y_packed, plen);
 }
 
 extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, int block, const double* alphas,

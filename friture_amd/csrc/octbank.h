@@ -38,6 +38,20 @@ struct frt_octbank {
     frt::DeviceBuffer eblock, alpha, decay_n, smooth, weight, eout;
     int power_chunk0 = -1;
     frt_ola_state* ola = nullptr;
+    // interactive host-buffer path: the per-block launch sequence (H2D, nine stage kernels, D2H) is
+    // launch bound, so it is captured once per block length into a hipGraph and replayed
+    struct StreamGraph {
+        int n = 0;
+        hipGraphExec_t exec = nullptr;
+        const void* ptrs[2 + frt::kNOctave] = {};     // device buffers baked into the graph
+    };
+    std::vector<StreamGraph> graphs;
+    hipStream_t gstream = nullptr;
+    void* pin_in = nullptr;
+    void* pin_out = nullptr;
+    size_t pin_in_bytes = 0, pin_out_bytes = 0;
+    int warmed_n = -1;
+    bool use_graph = true;
     size_t stage_state_elems() const { return (size_t)n_channels * nfilt * frt::kStates; }
 };
 
