@@ -42,7 +42,6 @@ struct StftArgs {
     int n_groups;          // total lane groups = C * runs_per_channel
     int kind;              // FRT_STFT_*
     int vec2;              // 1: 2-sample vector loads are aligned
-    double psd_scale;      // 1 / N^2
     double norm_off;       // -spec_min
     double norm_scale;     // 1 / (spec_max - spec_min)
 #ifdef FRT_ABLATE
@@ -132,7 +131,6 @@ stft_kernel(const StftArgs a) {
     }
     if (wgt) wdb_mid = wgt[M / 2];
 
-    const T psd_scale = (T)(0.25 * a.psd_scale);
     const T norm_off = (T)a.norm_off, norm_scale = (T)a.norm_scale;
 
     auto load_slot = [&](long long f, int j) -> C {
@@ -247,10 +245,10 @@ stft_kernel(const StftArgs a) {
             C t = cmul(tu, D);
             T ar = S.x + t.y, ai = S.y - t.x;      // 2 X[k]
             T br = S.x - t.y, bi = S.y + t.x;      // 2 conj X[M-k]
-            res[j] = (ar * ar + ai * ai) * psd_scale;
-            res[4 + j] = (br * br + bi * bi) * psd_scale;
+            res[j] = ar * ar + ai * ai;           // the window table carries the 1/(2N) scale (exact: a power of two)
+            res[4 + j] = br * br + bi * bi;
         }
-        T res_mid = (v[4].x * v[4].x + v[4].y * v[4].y) * (T)a.psd_scale;     // bin M/2, meaningful for i == 0
+        T res_mid = (v[4].x * v[4].x + v[4].y * v[4].y) * (T)4;               // bin M/2, meaningful for i == 0
 
         // Advance the register window by one hop *before* the stores are issued: the wait for the
         // prefetched samples then sits behind a whole transform (latency hidden) and ahead of this
@@ -378,7 +376,9 @@ static int build_tables(frt_stft* h) {
     const double pi = 3.14159265358979323846;
     std::vector<T> win(N);
     // symmetric Hann, audioproc.py:76-80: 0.5 * (1 - cos(2 pi n / (N - 1)))
-    for (int n = 0; n < N; ++n) win[n] = (T)(0.5 * (1.0 - std::cos(2.0 * pi * n / (N - 1))));
+    // stored pre-scaled by 1/(2N): |X[k]|^2 / N^2 = |sum ... |^2 / 4 of the unpack then needs no multiply;
+    // N is a power of two, so the scaling is exact and results are unchanged
+    for (int n = 0; n < N; ++n) win[n] = (T)(0.5 * (1.0 - std::cos(2.0 * pi * n / (N - 1)))) * (T)(0.5 / N);
     std::vector<T> tw(2 * M), twn(2 * M);
     for (int n = 0; n < M; ++n) {
         tw[2 * n] = (T)std::cos(2.0 * pi * n / M);
@@ -492,7 +492,6 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     a.kind = kind;
     const size_t esz = h->precision == 32 ? 4 : 8;
     a.vec2 = (h->hop % 2 == 0) && (x_stride % 2 == 0) && (((uintptr_t)d_x) % (2 * esz) == 0);
-    a.psd_scale = 1.0 / ((double)N * (double)N);
     a.norm_off = -h->spec_min;
     a.norm_scale = 1.0 / (h->spec_max - h->spec_min);
 #ifdef FRT_ABLATE
