@@ -31,6 +31,8 @@ struct StftArgs {
     const void* tw;        // [M] cpx<T>: exp(-2 pi i n / M)
     const void* twn;       // [M] cpx<T>: exp(-2 pi i k / N)
     const void* weight;    // [M+1] T or null
+    const void* wimage;    // [M+1] T: 255 (weight - spec_min)/(spec_max - spec_min), colour-index offset per bin
+    double image_gain;     // 255 * (10/log2(10)) / (spec_max - spec_min): colour index per log2 of the PSD
     const uint32_t* lut;   // [256] or null
     long long x_stride;    // elements between channels
     long long n_frames;    // frames per channel
@@ -55,6 +57,8 @@ template <> __device__ __forceinline__ float db10<float>(float p) {
     return 3.01029995663981195f * __log2f(p + 1e-30f);
 }
 template <> __device__ __forceinline__ double db10<double>(double p) { return 10.0 * log10(p + 1e-30); }
+__device__ __forceinline__ float log2_t(float v) { return __log2f(v); }
+__device__ __forceinline__ double log2_t(double v) { return log2(v); }
 
 template <typename T>
 __device__ __forceinline__ T shfl_t(T v, int lane) { return __shfl(v, lane, 64); }
@@ -113,7 +117,11 @@ stft_kernel(const StftArgs a) {
     T wdb[NC], wdb_mid = 0;
     const T* wtab = (const T*)a.window;
     const C* twn = (const C*)a.twn;
-    const T* wgt = (const T*)a.weight;
+    // IMAGE folds dB, weighting, normalisation and the 255 of the LUT index into one multiply-add per
+    // bin: index = clamp(gain * log2(P + 1e-30) + wimage[k], 0, 255) — same value as the reference's
+    // clip((10 log10(P + eps) + w - min)/(max - min), 0, 1) * 255 up to float rounding
+    const T* wgt = (const T*)(a.kind == FRT_STFT_IMAGE ? a.wimage : a.weight);
+    const T image_gain = (T)a.image_gain;
     TwRegs<T, LOG2M> twr;
     if constexpr (HOIST) {
 #pragma unroll
@@ -283,34 +291,44 @@ stft_kernel(const StftArgs a) {
             if (a.kind == FRT_STFT_PSD) {
                 store_all(row, [](T x) { return x; });
             } else {
+                T wl[4], wh[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    T wl, wh;
                     if constexpr (HOIST) {
-                        wl = wdb[j];
-                        wh = wdb[4 + j];
+                        wl[j] = wdb[j];
+                        wh[j] = wdb[4 + j];
                     } else {
-                        wl = wgt ? wgt[klo + j * TPF + zero] : (T)0;
-                        wh = wgt ? wgt[khi - j * TPF + zero] : (T)0;
+                        wl[j] = wgt ? wgt[klo + j * TPF + zero] : (T)0;
+                        wh[j] = wgt ? wgt[khi - j * TPF + zero] : (T)0;
                     }
-                    res[j] = db10<T>(res[j]) + wl;
-                    res[4 + j] = db10<T>(res[4 + j]) + wh;
                 }
-                res_mid = db10<T>(res_mid) + wdb_mid;
-                if (a.kind >= FRT_STFT_NORM) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) res[j] = (res[j] + norm_off) * norm_scale;
-                    res_mid = (res_mid + norm_off) * norm_scale;
-                }
-                if (a.kind != FRT_STFT_IMAGE) {
-                    store_all(row, [](T x) { return x; });
-                } else {
+                if (a.kind == FRT_STFT_IMAGE) {
                     // colour words are 4 bytes whatever the arithmetic type
                     uint32_t* prow = (uint32_t*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
-                    store_all(prow, [&](T vv) -> uint32_t {
-                        vv = fmin(fmax(vv, (T)0), (T)1);   // NaN -> 0
-                        return lut_lds[(int)(vv * (T)255)];
-                    });
+                    auto pix = [&](T p, T w) -> uint32_t {
+                        T v = image_gain * log2_t(p + (T)1e-30) + w;
+                        v = fmin(fmax(v, (T)0), (T)255);      // NaN -> 0
+                        return lut_lds[(int)v];
+                    };
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        prow[klo + j * TPF] = pix(res[j], wl[j]);
+                        prow[khi - j * TPF] = pix(res[4 + j], wh[j]);
+                    }
+                    if (i == 0) prow[M / 2] = pix(res_mid, wdb_mid);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        res[j] = db10<T>(res[j]) + wl[j];
+                        res[4 + j] = db10<T>(res[4 + j]) + wh[j];
+                    }
+                    res_mid = db10<T>(res_mid) + wdb_mid;
+                    if (a.kind == FRT_STFT_NORM) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) res[j] = (res[j] + norm_off) * norm_scale;
+                        res_mid = (res_mid + norm_off) * norm_scale;
+                    }
+                    store_all(row, [](T x) { return x; });
                 }
             }
         }
@@ -364,7 +382,7 @@ struct frt_stft {
     int fft_size = 0, hop = 0, n_channels = 0, precision = 32, log2m = 0;
     int run_length = 0;
     hipStream_t stream = nullptr;
-    DeviceBuffer window, tw, twn, weight, lut;
+    DeviceBuffer window, tw, twn, weight, wimage, lut;
     bool has_weight = false, has_lut = false;
     double spec_min = -140.0, spec_max = 0.0;
     DeviceBuffer stage_in, stage_out;
@@ -424,6 +442,7 @@ extern "C" void frt_stft_destroy(frt_stft* h) {
     h->tw.release();
     h->twn.release();
     h->weight.release();
+    h->wimage.release();
     h->lut.release();
     h->stage_in.release();
     h->stage_out.release();
@@ -449,15 +468,22 @@ extern "C" int frt_stft_set_epilogue(frt_stft* h, const double* weight_db, doubl
     const int nb = h->fft_size / 2 + 1;
     int rc;
     h->has_weight = weight_db != nullptr;
-    if (weight_db) {
-        if (h->precision == 32) {
-            std::vector<float> w(nb);
-            for (int k = 0; k < nb; ++k) w[k] = (float)weight_db[k];
-            if ((rc = upload(h->weight, w))) return rc;
-        } else {
-            std::vector<double> w(weight_db, weight_db + nb);
-            if ((rc = upload(h->weight, w))) return rc;
+    // per-bin offset of the colour index (IMAGE kind), weighting and dB range folded in
+    const double span = spec_max - spec_min;
+    if (h->precision == 32) {
+        std::vector<float> w(nb), wi(nb);
+        for (int k = 0; k < nb; ++k) {
+            w[k] = weight_db ? (float)weight_db[k] : 0.f;
+            wi[k] = (float)(255.0 * ((weight_db ? weight_db[k] : 0.0) - spec_min) / span);
         }
+        if ((rc = upload(h->weight, w)) || (rc = upload(h->wimage, wi))) return rc;
+    } else {
+        std::vector<double> w(nb), wi(nb);
+        for (int k = 0; k < nb; ++k) {
+            w[k] = weight_db ? weight_db[k] : 0.0;
+            wi[k] = 255.0 * (w[k] - spec_min) / span;
+        }
+        if ((rc = upload(h->weight, w)) || (rc = upload(h->wimage, wi))) return rc;
     }
     h->has_lut = lut256 != nullptr;
     if (lut256) {
@@ -484,6 +510,8 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     a.tw = h->tw.ptr;
     a.twn = h->twn.ptr;
     a.weight = h->has_weight ? h->weight.ptr : nullptr;
+    a.wimage = h->wimage.ptr;
+    a.image_gain = 255.0 * 3.01029995663981195 / (h->spec_max - h->spec_min);
     a.lut = h->has_lut ? h->lut.as<uint32_t>() : nullptr;
     a.x_stride = x_stride;
     a.n_frames = F;
