@@ -30,6 +30,7 @@ struct StftArgs {
     const void* window;    // [N] T
     const void* tw;        // [M] cpx<T>: exp(-2 pi i n / M)
     const void* twn;       // [M] cpx<T>: exp(-2 pi i k / N)
+    const void* tws;       // [M/16] cpx<T>: exp(-2 pi i n / (M/16)), sub-transforms of stft_big_kernel (N >= 2048)
     const void* weight;    // [M+1] T or null
     const void* wimage;    // [M+1] T: 255 (weight - spec_min)/(spec_max - spec_min), colour-index offset per bin
     double image_gain;     // 255 * (10/log2(10)) / (spec_max - spec_min): colour index per log2 of the PSD
@@ -335,7 +336,33 @@ stft_kernel(const StftArgs a) {
     }
 }
 
+}  // namespace frt
+
+#include "stft_big.h"
+
+namespace frt {
+
 // ---- host side -----------------------------------------------------------------------------------
+
+template <int LOG2M>
+static int launch_big_one(const StftArgs& a, hipStream_t stream) {
+    using B = BigPlan<LOG2M>;
+    const int blocks = (a.n_groups + B::GPB - 1) / B::GPB;
+    hipLaunchKernelGGL((stft_big_kernel<LOG2M>), dim3(blocks), dim3(B::BLOCK), 0, stream, a);
+    FRT_HIP_CHECK(hipGetLastError());
+    return FRT_OK;
+}
+
+static int launch_big(int log2m, const StftArgs& a, hipStream_t stream) {
+    switch (log2m) {
+        case 10: return launch_big_one<10>(a, stream);
+        case 11: return launch_big_one<11>(a, stream);
+        case 12: return launch_big_one<12>(a, stream);
+        case 13: return launch_big_one<13>(a, stream);
+    }
+    set_last_error("big kernel: unsupported fft size 2^%d", log2m + 1);
+    return FRT_ERR_UNSUPPORTED;
+}
 
 
 template <typename TIN, typename T, int LOG2M, int SHIFT>
@@ -381,8 +408,9 @@ using namespace frt;
 struct frt_stft {
     int fft_size = 0, hop = 0, n_channels = 0, precision = 32, log2m = 0;
     int run_length = 0;
+    bool force_generic = false;   // A/B and tests: a negative run length selects the generic kernel
     hipStream_t stream = nullptr;
-    DeviceBuffer window, tw, twn, weight, wimage, lut;
+    DeviceBuffer window, tw, twn, tws, weight, wimage, lut;
     bool has_weight = false, has_lut = false;
     double spec_min = -140.0, spec_max = 0.0;
     DeviceBuffer stage_in, stage_out;
@@ -408,6 +436,15 @@ static int build_tables(frt_stft* h) {
     if ((rc = upload(h->window, win))) return rc;
     if ((rc = upload(h->tw, tw))) return rc;
     if ((rc = upload(h->twn, twn))) return rc;
+    if (M >= 1024) {                       // sub-transform table of stft_big_kernel
+        const int Ms = M / 16;
+        std::vector<T> tws(2 * Ms);
+        for (int n = 0; n < Ms; ++n) {
+            tws[2 * n] = (T)std::cos(2.0 * pi * n / Ms);
+            tws[2 * n + 1] = (T)(-std::sin(2.0 * pi * n / Ms));
+        }
+        if ((rc = upload(h->tws, tws))) return rc;
+    }
     return FRT_OK;
 }
 
@@ -441,6 +478,7 @@ extern "C" void frt_stft_destroy(frt_stft* h) {
     h->window.release();
     h->tw.release();
     h->twn.release();
+    h->tws.release();
     h->weight.release();
     h->wimage.release();
     h->lut.release();
@@ -458,6 +496,7 @@ extern "C" int frt_stft_set_stream(frt_stft* h, void* s) {
 extern "C" int frt_stft_set_run_length(frt_stft* h, int r) {
     FRT_REQUIRE(h, "frt_stft_set_run_length: null handle");
     h->run_length = r < 0 ? -r : r;
+    h->force_generic = r < 0;
     return FRT_OK;
 }
 
@@ -509,6 +548,7 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     a.window = h->window.ptr;
     a.tw = h->tw.ptr;
     a.twn = h->twn.ptr;
+    a.tws = h->tws.ptr;
     a.weight = h->has_weight ? h->weight.ptr : nullptr;
     a.wimage = h->wimage.ptr;
     a.image_gain = 255.0 * 3.01029995663981195 / (h->spec_max - h->spec_min);
@@ -548,6 +588,29 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     a.run = run;
     a.frame_base = 0;
 
+    // N >= 2048, float32, aligned even hop: the radix-16 + wave-local instance (stft_big.h)
+    if (h->precision == 32 && h->log2m >= 10 && a.vec2 && !h->force_generic) {
+        int brun = h->run_length;
+        if (brun <= 0) {
+            // measured (tools/stft_selftest bench, run sweep): N = 16384 runs one workgroup per CU and gains
+            // from long runs (one-off twiddle/LUT loads amortised, 16 -> exactly one round of workgroups at
+            // 4096 frames); the smaller sizes prefer fine-grained groups (tail balance), 2 frames each
+            brun = 2;
+            if (h->log2m >= 13) {
+                const long long total = (long long)F * h->n_channels;
+                brun = (int)((total + device_cu_count() - 1) / device_cu_count());
+                if (brun < 4) brun = 4;
+                if (brun > 16) brun = 16;
+            }
+        }
+        if (brun > F) brun = (int)F;
+        a.run = brun;
+        a.runs_per_channel = (int)((F + brun - 1) / brun);
+        const long long bgroups = (long long)a.runs_per_channel * h->n_channels;
+        FRT_REQUIRE(bgroups < (1ll << 31), "frt_stft_run: too many lane groups");
+        a.n_groups = (int)bgroups;
+        return launch_big(h->log2m, a, stream);
+    }
     const long long rest = F - a.frame_base;
     a.runs_per_channel = (int)((rest + run - 1) / run);
     const long long groups = (long long)a.runs_per_channel * h->n_channels;

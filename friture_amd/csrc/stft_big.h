@@ -1,0 +1,204 @@
+// stft_big.h — the instance of K1 for N >= 2048 (a frame spans several wavefronts), float32.
+// Included by stft.hip.
+//
+// The generic stft_kernel runs five Stockham passes over the whole workgroup for N = 16384: ten
+// workgroup barriers per frame, every pass re-reading its twiddles from L2 between barriers, one
+// 1024-thread workgroup per CU with nothing to overlap the stalls — 14 % of HBM peak.  This instance
+// factors M = N/2 = 16 * Ms so that only ONE exchange crosses wavefronts:
+//   1. thread t (Ms threads per frame) loads z[t + j Ms], j = 0..15 (coalesced), windows them and
+//      takes the 16-point DFT over j in registers;
+//   2. multiplies by exp(-2 pi i t k0 / M) and writes column k0 to LDS region k0 (the only
+//      workgroup-wide transpose), barrier;
+//   3. the 16 length-Ms transforms over t run as wave-local sub-transforms (fft_core.h, no barrier:
+//      Ms <= 512 points = one lane group of Ms/8 threads inside a wavefront), two rounds of eight;
+//      results return to their LDS region, barrier;
+//   4. thread t finishes the bin pairs (k, M-k), k = t + q Ms (q < 8), reading Z[k] = region
+//      (k mod 16), slot (k / 16): consecutive threads -> consecutive bins -> coalesced stores.
+// Three barriers per frame, 74 KB of LDS for N = 16384 -> two 512-thread workgroups per CU.
+#pragma once
+
+namespace frt {
+
+// Second half of a 16-point DFT.  With n = m + 4p and k = q + 4r,
+//   X[q + 4r] = sum_m W4^{mr} ( W16^{mq} sum_p a[m + 4p] W4^{pq} );
+// on entry a[m + 4q] holds the inner sum (first-stage butterfly m, output q), on return a[k] = X[k].
+template <typename T>
+__device__ __forceinline__ void dft16_second_stage(cpx<T> (&a)[16]) {
+    const T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173;   // cos, sin(pi/8)
+    const T h = (T)0.70710678118654752440;
+    auto mulc = [](cpx<T> v, T c, T s) -> cpx<T> { return {v.x * c + v.y * s, v.y * c - v.x * s}; };   // v (c - i s)
+    // twiddles W16^{mq} on a[m + 4q]
+    a[1 + 4] = mulc(a[1 + 4], c1, s1);        // m=1,q=1: W16^1
+    a[1 + 8] = mulc(a[1 + 8], h, h);          // m=1,q=2: W16^2
+    a[1 + 12] = mulc(a[1 + 12], s1, c1);      // m=1,q=3: W16^3
+    a[2 + 4] = mulc(a[2 + 4], h, h);          // W16^2
+    a[2 + 8] = mul_mi(a[2 + 8]);              // W16^4 = -i
+    a[2 + 12] = mulc(a[2 + 12], -h, h);       // W16^6
+    a[3 + 4] = mulc(a[3 + 4], s1, c1);        // W16^3
+    a[3 + 8] = mulc(a[3 + 8], -h, h);         // W16^6
+    a[3 + 12] = mulc(a[3 + 12], -c1, -s1);    // W16^9 = -W16^1
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // DFT4 over m of a[m + 4q] -> X[q + 4r] at r = 0..3; stored back into the four slots of column q
+        dft4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+    }
+    // a[4q + r] = X[q + 4r]: transpose the 4x4 index grid into natural order
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = q + 1; r < 4; ++r) {
+            const cpx<T> tmp = a[4 * q + r];
+            a[4 * q + r] = a[4 * r + q];
+            a[4 * r + q] = tmp;
+        }
+}
+
+template <int LOG2M>
+struct BigPlan {
+    static constexpr int M = 1 << LOG2M;
+    static constexpr int LOG2MS = LOG2M - 4;
+    static constexpr int MS = M / 16;                       // threads per frame = sub-transform length
+    static constexpr int TPFS = MS / 8;                     // threads per sub-transform
+    static constexpr int RS = lds_padded_size(MS) + 2;      // region stride (complex): conflict-free column reads
+    static constexpr int BLOCK = MS < 256 ? 256 : MS;
+    static constexpr int GPB = BLOCK / MS;                  // frames in flight per workgroup
+};
+
+template <int LOG2M>
+__global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const StftArgs a) {
+    using B = BigPlan<LOG2M>;
+    using C = cpx<float>;
+    constexpr int M = B::M, MS = B::MS, TPFS = B::TPFS, RS = B::RS, BLOCK = B::BLOCK, GPB = B::GPB;
+
+    __shared__ C lds[GPB * 16 * RS];
+    __shared__ uint32_t lut_lds[256];
+
+    const int tid = threadIdx.x;
+    const int grp = tid / MS;
+    const int t = tid - grp * MS;
+    C* reg = lds + grp * 16 * RS;
+
+    if (a.kind == FRT_STFT_IMAGE) {
+        for (int q = tid; q < 256; q += BLOCK) lut_lds[q] = a.lut[q];
+    }
+
+    const int gg = blockIdx.x * GPB + grp;
+    const bool group_ok = gg < a.n_groups;
+    const int ggc = group_ok ? gg : 0;
+    const int chan = ggc / a.runs_per_channel;
+    const int run = ggc - chan * a.runs_per_channel;
+    const long long f0 = a.frame_base + (long long)run * a.run;
+    long long nfr = a.n_frames - f0;
+    if (nfr > a.run) nfr = a.run;
+    if (!group_ok) nfr = 0;
+
+    const C* xs = (const C*)((const float*)a.x + chan * a.x_stride);
+    const C* win = (const C*)a.window;
+    const C* tw = (const C*)a.tw;          // exp(-2 pi i n / M)
+    const C* twn = (const C*)a.twn;        // exp(-2 pi i k / N)
+    const float* wgt = (const float*)(a.kind == FRT_STFT_IMAGE ? a.wimage : a.weight);
+    const float image_gain = (float)a.image_gain, norm_off = (float)a.norm_off, norm_scale = (float)a.norm_scale;
+
+    // twiddles of the wave-local sub-transforms depend on the thread's index in its sub-transform only
+    const int si = t % TPFS;               // index inside the sub-transform
+    const int sg = t / TPFS;               // sub-transform of a round (0..7)
+    TwRegs<float, B::LOG2MS> twr;
+    twr.load((const C*)a.tws, si);
+
+    for (int g = 0; g < a.run; ++g) {
+        const bool valid = g < nfr;
+        if (!__syncthreads_or(valid)) break;                 // also fences the previous frame's LDS reads
+        int zero = 0;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));        // keeps table loads inside the loop
+
+        // ---- 1. load + window + 16-point DFT over j -------------------------------------------------------
+        // n = t + (m + 4p) Ms: the four points of first-stage butterfly m arrive together; loads run one
+        // butterfly ahead of the arithmetic so that at most two groups of samples + window are in flight
+        // (all sixteen at once would need 64 more registers and halve the occupancy)
+        C v[16];
+        {
+            const C* xf = xs + ((f0 + (valid ? g : 0)) * a.hop >> 1) + t;
+            const C* wf = win + t + zero;
+            C d[4], w[4], dn[4], wn[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                d[p] = valid ? xf[(4 * p) * MS] : C{0.f, 0.f};
+                w[p] = wf[(4 * p) * MS];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (m < 3) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        dn[p] = valid ? xf[(m + 1 + 4 * p) * MS] : C{0.f, 0.f};
+                        wn[p] = wf[(m + 1 + 4 * p) * MS];
+                    }
+                }
+                C b0 = {d[0].x * w[0].x, d[0].y * w[0].y}, b1 = {d[1].x * w[1].x, d[1].y * w[1].y};
+                C b2 = {d[2].x * w[2].x, d[2].y * w[2].y}, b3 = {d[3].x * w[3].x, d[3].y * w[3].y};
+                dft4(b0, b1, b2, b3);
+                v[m] = b0; v[m + 4] = b1; v[m + 8] = b2; v[m + 12] = b3;      // v[m + 4q] = first-stage output q of butterfly m
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { d[p] = dn[p]; w[p] = wn[p]; }
+            }
+        }
+        dft16_second_stage(v);
+        // ---- 2. twiddle exp(-2 pi i t k0 / M), transpose through LDS ----------------------------------------
+#pragma unroll
+        for (int k0 = 1; k0 < 16; ++k0) v[k0] = cmul(v[k0], tw[((t * k0) & (M - 1)) + zero]);
+#pragma unroll
+        for (int k0 = 0; k0 < 16; ++k0) reg[k0 * RS + lds_pad(t)] = v[k0];
+        __syncthreads();
+        // ---- 3. sixteen wave-local transforms of length Ms over t, two rounds of eight ----------------------
+#pragma unroll 1
+        for (int r = 0; r < 2; ++r) {
+            C* buf = reg + (8 * r + sg) * RS;
+            C u[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] = buf[lds_pad(si + j * TPFS)];
+            fft_pow2_forward<float, B::LOG2MS, true>(u, buf, si, twr);
+            pass_sync<true>();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) buf[lds_pad(si + j * TPFS)] = u[j];
+        }
+        __syncthreads();
+        // ---- 4. conjugate-symmetric unpack of the pairs (k, M - k), k = t + q Ms ------------------------------
+        auto zat = [&](int k) -> C {                         // Z[k], k in [0, M]
+            k &= M - 1;
+            return reg[(k & 15) * RS + lds_pad(k >> 4)];
+        };
+        if (valid) {
+            float* row = (float*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
+            auto finish_store = [&](int k, float p) {
+                if (a.kind == FRT_STFT_PSD) {
+                    row[k] = p;
+                } else if (a.kind == FRT_STFT_IMAGE) {
+                    float vv = image_gain * __log2f(p + 1e-30f) + wgt[k + zero];
+                    vv = fminf(fmaxf(vv, 0.f), 255.f);
+                    ((uint32_t*)row)[k] = lut_lds[(int)vv];
+                } else {
+                    float vv = db10<float>(p) + (wgt ? wgt[k + zero] : 0.f);
+                    if (a.kind == FRT_STFT_NORM) vv = (vv + norm_off) * norm_scale;
+                    row[k] = vv;
+                }
+            };
+#pragma unroll 2
+            for (int q = 0; q < 8; ++q) {
+                const int k = t + q * MS;                    // k < M/2
+                const C A = zat(k), Bc = cconj(zat(M - k));
+                const C S = A + Bc, D = A - Bc;
+                const C tt = cmul(twn[k + zero], D);
+                const float ar = S.x + tt.y, ai = S.y - tt.x, br = S.x - tt.y, bi = S.y + tt.x;
+                finish_store(k, ar * ar + ai * ai);
+                finish_store(M - k, br * br + bi * bi);
+            }
+            if (t == 0) {
+                const C zm = zat(M / 2);
+                finish_store(M / 2, (zm.x * zm.x + zm.y * zm.y) * 4.f);
+            }
+        }
+    }
+}
+
+}  // namespace frt

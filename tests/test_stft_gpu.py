@@ -107,6 +107,32 @@ def test_run_length_invariance(engine_cls):
         assert np.array_equal(o, outs[0])
 
 
+@pytest.mark.parametrize("n_fft", [2048, 4096, 8192, 16384])
+def test_large_frame_instances(golden, engine_cls, n_fft):
+    """N >= 2048 has two instances of K1: the radix-16 + wave-local one (stft_big.h, the default) and the
+    generic workgroup Stockham walk (selected by a negative run length).  Both must sit inside the
+    tolerance of the oracle whatever the run length, and colour the same pixels up to LUT bin edges."""
+    hop = n_fft // 2
+    frames = 23
+    T = n_fft + hop * (frames - 1) + 3
+    x = np.stack([synth("noise", T, 5), synth("chirp", T, 6)])
+    ref = [dsp.stft_psd(x[c].astype(np.float64), n_fft, hop) for c in range(2)]
+    g = golden("image")
+    from friture_amd import tables
+    A = tables.weighting_db(tables.rfft_frequencies(n_fft), 1e-50)[0]
+    images = []
+    for run in (0, 1, 5, -1, -4):
+        e = engine_cls(n_fft, hop, 2, 32)
+        e.set_epilogue(A, -140.0, 0.0, g["lut"])
+        e.set_run_length(run)
+        got = e.psd(x)
+        for c in range(2):
+            assert per_frame_err(got[c], ref[c]) <= TOL32, (run, c)
+        images.append(e.image(x))
+    for im in images[1:]:
+        assert np.mean(im != images[0]) < 2e-3
+
+
 def test_db_norm_image_against_golden(golden, engine_cls):
     g = golden("image")
     x, A, lut = g["x"], g["weight"], g["lut"]
