@@ -70,6 +70,17 @@ SIGNATURES = {
     "frt_exp_smooth_2d": (c_int, [c_void_p, c_int, c_double, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "frt_spectrum_post": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_int, c_double, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "frt_pitch_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p, c_int, c_double,
+                                 c_double, c_double]),
+    "frt_pitch_destroy": (None, [c_void_p]),
+    "frt_pitch_set_stream": (c_int, [c_void_p, c_void_p]),
+    "frt_pitch_reset": (c_int, [c_void_p]),
+    "frt_pitch_set_previous": (c_int, [c_void_p, c_void_p]),
+    "frt_pitch_get_previous": (c_int, [c_void_p, c_void_p]),
+    "frt_pitch_set_gate": (c_int, [c_void_p, c_double, c_double, c_double]),
+    "frt_pitch_set_scratch_limit": (c_int, [c_void_p, c_int64]),
+    "frt_pitch_frames_for": (c_int64, [c_void_p, c_int64]),
+    "frt_pitch_track": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, POINTER(c_int64)]),
     "frt_lfilter_f64": (c_int, [POINTER(c_double), POINTER(c_double), c_int, POINTER(c_double), c_int, POINTER(c_double),
                                 POINTER(c_double), POINTER(c_double)]),
 }

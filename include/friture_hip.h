@@ -203,6 +203,35 @@ int frt_spectrum_post(const void* psd, int psd_is_f32, int n_frames, int n_bins,
                       const double* ref_smoothed, double* smoothed_out, double* db_out, int* peak_index_out,
                       int* pitch_index_out);
 
+/* ---- T1: pitch tracker (PitchTracker.estimate_pitch / update, friture/pitch_tracker.py:313-428) ---------
+ * Per frame of fft_size samples (hop apart): |rfft(frame * hann)| -> np.interp onto the log-spaced grid
+ * log_freqs[n_log] -> divide by its RMS -> strengths = kernels[n_candidates][n_log] @ grid spectrum ->
+ * arg-max, parabolic vertex (fastParabolicInterp :160-193), index -> Hz, confidence = strength / 2.56,
+ * frame level 20 log10(rms + eps); then the sequential gate: unvoiced (NaN) when level < min_db,
+ * confidence < conf, or the estimate jumps more than p_delta semitones from the previous voiced one.
+ * The grid and the kernel matrix are the caller's tables (_init_swipe :334-355, calcCosineKernel :195-264);
+ * the gate's "previous estimate" is carried in the handle, per channel, across calls. */
+typedef struct frt_pitch frt_pitch;
+int frt_pitch_create(frt_pitch** h, int fft_size, int hop, int n_channels, double sample_rate, const double* log_freqs,
+                     int n_log, const double* kernels, int n_candidates, double min_db, double conf, double p_delta);
+void frt_pitch_destroy(frt_pitch* h);
+int frt_pitch_set_stream(frt_pitch* h, void* hip_stream);
+/* forget the previous estimates (prev_f0 = None, :292) */
+int frt_pitch_reset(frt_pitch* h);
+/* the gate's carried state: previous[n_channels] (host or device), NaN = no previous estimate */
+int frt_pitch_set_previous(frt_pitch* h, const double* previous);
+int frt_pitch_get_previous(frt_pitch* h, double* previous);
+/* the widget changes the thresholds at run time (pitch_tracker.py:142-146) */
+int frt_pitch_set_gate(frt_pitch* h, double min_db, double conf, double p_delta);
+/* device scratch (spectra, grid spectra, strengths) a call may hold; longer runs go through it in chunks
+ * of frames.  Default 1 GiB. */
+int frt_pitch_set_scratch_limit(frt_pitch* h, int64_t bytes);
+int64_t frt_pitch_frames_for(const frt_pitch* h, int64_t T);
+/* x: [n_channels][x_stride] doubles, T valid samples per channel.  f0_out: [n_channels][n_frames], NaN =
+ * unvoiced.  raw_out (or NULL): [3][n_channels][n_frames] = estimate before gating, confidence, dBFS. */
+int frt_pitch_track(frt_pitch* h, const double* x, int64_t T, int64_t x_stride, double* f0_out, double* raw_out,
+                    int64_t* n_frames_out);
+
 #ifdef __cplusplus
 }
 #endif

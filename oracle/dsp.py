@@ -585,3 +585,114 @@ class TimeResampler:
                 w += n
             self.old = data[:, j]
         return out
+
+
+# --------------------------------------------------------------------------------------------
+# T1: SWIPE-style pitch tracker
+# --------------------------------------------------------------------------------------------
+# Parity pin: friture/test/test_pitch_tracker.py:42-71 holds two known answers (3000 and 1500),
+# but the reference's current estimate_pitch does not reproduce them (executed here through
+# oracle/refshim.py it returns nan for both: the candidates stop at max_freq = 1047 Hz and the
+# confidence gate rejects the 32-point frames).  The pin is therefore the reference code itself,
+# executed unmodified in the build container: oracle/make_golden_pitch.py -> tests/golden/pitch.npz.
+
+SWIPE_HARMONICS = (1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 13, 17, 19, 23)     # friture/pitch_tracker.py:217
+
+
+def parabolic_vertex(y1, y2, y3):
+    """Vertex offset and height of the parabola through (-1,y1), (0,y2), (1,y3)
+    — friture/pitch_tracker.py:160-193 (eps in the denominator included)."""
+    a = (y1 - 2 * y2 + y3) / 2
+    b = (y3 - y1) / 2
+    vx = -b / (2 * a + np.finfo(np.float64).eps)
+    return vx, a * vx ** 2 + b * vx + y2
+
+
+def swipe_kernel(f: float, freqs: np.ndarray) -> np.ndarray:
+    """One candidate's kernel over the log-spaced grid — friture/pitch_tracker.py:195-264.
+    Cosine peak lobes (half-width 0.15 of the harmonic spacing) at the selected harmonics, quarter
+    height at the others, negative half-height valley lobes between; sqrt(1/f) decay above harmonic
+    2.15; positive area normalised to 1; divided by the fraction of harmonics below Nyquist."""
+    harmonics = np.array(SWIPE_HARMONICS)
+    peak_w = 0.15
+    valley_w = 1 - peak_w
+    n_possible = min(int(freqs[-1] / f), len(harmonics))
+    selected = harmonics[:n_possible]
+    ratio = freqs / f
+    k = np.zeros_like(freqs)
+    for i in np.arange(1, harmonics[-1] + 1):
+        a = ratio - i
+        chosen = i in selected
+        valley = np.logical_and(-valley_w < a, a < (-peak_w if chosen else peak_w))
+        k[valley] = -np.cos((a[valley] + 0.5) / ((valley_w - peak_w) / 2) * (np.pi / 2)) / 2
+        peak = np.abs(a) < peak_w
+        k[peak] = np.cos(a[peak] / peak_w * (np.pi / 2)) / (1 if chosen else 4)
+    knee = f * (2 + peak_w)
+    k *= np.where(freqs <= knee, np.sqrt(1.0 / knee), np.sqrt(1.0 / freqs)) / np.sqrt(1.0 / knee)
+    k /= np.sum(k[k > 0])
+    k /= n_possible / len(harmonics)
+    return k
+
+
+def swipe_tables(sample_rate=SAMPLING_RATE, min_freq=65, max_freq=1047, cres=10):
+    """(log-spaced frequency grid, kernel matrix [candidates][grid]) — friture/pitch_tracker.py:334-355."""
+    n = int(np.log2(sample_rate / (2 * min_freq)) * (1200 / cres))
+    freqs = np.logspace(np.log2(min_freq), np.log2(sample_rate // 2), num=n, base=2)
+    n_cand = int(np.searchsorted(freqs, max_freq))
+    kernels = np.zeros((n_cand, n))
+    for i in range(n_cand):
+        kernels[i] = swipe_kernel(freqs[i], freqs)
+    return freqs, kernels
+
+
+def pitch_strengths(frame, window, freqs, kernels, sample_rate=SAMPLING_RATE):
+    """|rfft(frame*window)| -> np.interp onto the log grid -> RMS normalise -> kernels @ spectrum
+    — friture/pitch_tracker.py:370-383."""
+    n_fft = len(frame)
+    spectrum = np.abs(np.fft.rfft(frame * window))
+    lin = np.arange(len(spectrum), dtype="float64") * (float(sample_rate) / float(n_fft))
+    spec_log = np.interp(freqs, lin, spectrum)
+    spec_log = spec_log / np.sqrt(np.mean(spec_log ** 2))
+    return np.matmul(kernels, spec_log)
+
+
+def pitch_candidate(frame, window, freqs, kernels, sample_rate=SAMPLING_RATE):
+    """(f0 before gating, confidence, dBFS) of one frame — friture/pitch_tracker.py:370-420."""
+    s = pitch_strengths(frame, window, freqs, kernels, sample_rate)
+    i = int(np.argmax(s))
+    shift = parabolic_vertex(s[i - 1], s[i], s[i + 1])[0] if 0 < i < len(s) - 1 else 0
+    f0 = np.interp(i + shift, np.arange(len(freqs)), freqs)
+    rms = np.sqrt(np.mean(np.asarray(frame, np.float64) ** 2))
+    return float(f0), float(s[i] / 2.56), float(20 * np.log10(rms + np.finfo(np.float64).eps))
+
+
+class PitchGate:
+    """The voiced/unvoiced decision and its one word of state — friture/pitch_tracker.py:405-428:
+    unvoiced (nan) when the frame is quieter than min_db, the confidence is under `conf`, or the
+    estimate jumped more than p_delta semitones from the previous *voiced* estimate."""
+
+    def __init__(self, min_db=-50.0, conf=0.5, p_delta=2):
+        self.min_db, self.conf, self.p_delta = min_db, conf, p_delta
+        self.prev = None
+
+    def step(self, f0, confidence, dbfs):
+        jump = 12 * np.abs(np.log2(f0 / self.prev)) if self.prev is not None else 0
+        if dbfs < self.min_db or confidence < self.conf or jump > self.p_delta:
+            self.prev = None
+            return np.nan
+        self.prev = f0
+        return f0
+
+
+def pitch_track(x, n_fft, hop, freqs, kernels, sample_rate=SAMPLING_RATE, min_db=-50.0, conf=0.5, p_delta=2):
+    """All complete frames of x at the given hop through candidate + gate
+    — friture/pitch_tracker.py:313-332 (update/new_frames).  Returns (f0 with nan = unvoiced,
+    raw f0, confidence, dBFS), one entry per frame."""
+    window = hann_symmetric(n_fft)
+    gate = PitchGate(min_db, conf, p_delta)
+    frames = 0 if len(x) < n_fft else (len(x) - n_fft) // hop + 1
+    out = np.zeros((4, frames))
+    for g in range(frames):
+        f0, c, db = pitch_candidate(np.asarray(x[g * hop:g * hop + n_fft], np.float64), window, freqs, kernels, sample_rate)
+        out[:, g] = gate.step(f0, c, db), f0, c, db
+    return out

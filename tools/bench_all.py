@@ -130,6 +130,33 @@ def main():
         out.append(dict(kernel="K5 gcc_phat_kernel", workload=f"GCC-PHAT L={L}, {pairs} window pair(s), device resident f64", unit="windows/s",
                         gpu=pairs / dt, ms=dt * 1e3, algorithmic_GBps=pairs * 24 * L / dt / 1e9, cpu_oracle=cpu, parity_rel_max=err,
                         argmax=int(am[0])))
+    # ---- T1 pitch tracker ---------------------------------------------------------------------------------
+    from friture_amd.pitch_tracker import PitchEngine, swipe_tables
+    grid, _, kern = swipe_tables()
+    for n_fft, hop, ch, log2t in [(4096, 1024, 8, 22), (1024, 256, 8, 22)]:
+        T = 1 << log2t
+        tt = np.arange(T)
+        f_path = 110.0 * 2 ** (2.0 * tt / T)
+        ph = 2 * np.pi * np.cumsum(f_path) / 48000.0
+        base = 0.2 * (np.sin(ph) + 0.6 * np.sin(2 * ph) + 0.3 * np.sin(3 * ph))
+        x = torch.from_numpy(np.stack([base + 1e-3 * rng.standard_normal(T) for _ in range(ch)])).cuda()
+        eng = PitchEngine(n_fft, hop, ch, grid=grid, kernels=kern)
+        F = eng.frames_for(T)
+        dt = timeit(lambda: eng.track(x), sync, 5)
+        xs = x[0, : n_fft + hop * 63].cpu().numpy()
+        t0 = time.perf_counter()
+        ref = dsp.pitch_track(xs, n_fft, hop, grid, kern)
+        cpu = 64 / (time.perf_counter() - t0)
+        got = PitchEngine(n_fft, hop, 1, grid=grid, kernels=kern).track(xs)[0]
+        ok = np.array_equal(np.isnan(got), np.isnan(ref[0]))
+        m = ~np.isnan(ref[0])
+        err = float(np.max(np.abs(got[m] / ref[0][m] - 1))) if ok and m.any() else float("nan")
+        flops = 2.0 * kern.shape[0] * kern.shape[1]
+        out.append(dict(kernel="T1 pitch_strength_kernel (+ K1 f64, loggrid, pick, gate)",
+                        workload=f"pitch tracker N={n_fft} hop={hop} C={ch} T=2^{log2t}, 481 candidates x 1023 grid points, f64",
+                        unit="frames/s", gpu=ch * F / dt, ms=dt * 1e3, contraction_TFLOPs=ch * F * flops / dt / 1e12,
+                        cpu_oracle=cpu, parity_rel_max=err, voiced_pattern_equal=bool(ok)))
+        del x
     for rec in out:
         print(json.dumps(rec))
 
