@@ -71,6 +71,14 @@ __device__ __forceinline__ double dpp_row_bcast0(double v) {
     return __hiloint2double(hi, lo);
 }
 
+template <int T>
+__device__ __forceinline__ double dpp_row_bcast(double v) {          // lane T of every 16-lane row, to its row
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + T, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + T, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double dpp_row_shl1(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_update_dpp(0, lo, 0x101, 0xF, 0xF, true);    // row_shl:1, zero fill
@@ -84,6 +92,24 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// `count` consecutive samples of the 64 a wavefront holds in xv (one per lane), for the four filters of the
+// wavefront at once.  Straight-line code: no per-sample branch, the energy block boundaries are the caller's.
+// The top live lane of a row receives zn = 0 from its (all-zero) dead neighbour, so the reference's special
+// case for the last state (lfilter.py:139, no z[n+1] term) needs no select: 0 + x b == x b.
+template <bool ENERGY, bool KEEP>
+__device__ __forceinline__ void iir_samples(int k0, int count, double xv, double b0, double bn, double an, double& z,
+                                            double& acc, double decay, double* ykeep) {
+#pragma unroll 4
+    for (int k = k0; k < k0 + count; ++k) {
+        const double x = readlane_f64(xv, k);
+        const double y = dpp_row_bcast0(z + b0 * x);
+        const double zn = dpp_row_shl1(z);
+        z = (zn + x * bn) - y * an;
+        if (ENERGY) acc = acc * decay + y * y;     // zero-state block energy, Horner form (exp_smoothing.py:40-56)
+        if (KEEP) ykeep[k] = y;                    // every lane of the row writes the same value to the same slot
+    }
+}
+
 __global__ void __launch_bounds__(64) iir_stage_kernel(const IirStageArgs a) {
     __shared__ double stage_y[4][64];
 
@@ -94,7 +120,6 @@ __global__ void __launch_bounds__(64) iir_stage_kernel(const IirStageArgs a) {
     const bool fvalid = f < a.nfilt;
     const int fc = fvalid ? f : 0;
     const int ord = fvalid ? a.order[fc] : 0;
-    const bool is_last = s == ord - 1;
     const bool live = fvalid && s < ord;
     const bool leader = fvalid && s == 0;
 
@@ -111,17 +136,22 @@ __global__ void __launch_bounds__(64) iir_stage_kernel(const IirStageArgs a) {
     }
 
     const int band = fvalid ? a.band_index[fc] : -1;
-    const bool do_energy = a.eblock != nullptr && band >= 0 && a.pass != 1;
-    const double alpha = do_energy ? a.alpha[band] : 0.0;
+    const bool energy = a.eblock != nullptr && a.pass != 1;           // uniform
+    const bool my_energy = energy && band >= 0 && leader;
+    const double alpha = (energy && band >= 0) ? a.alpha[band] : 0.0;
     const double decay = 1.0 - alpha;
     double acc = 0.0;
+    double* eout = a.eblock + (size_t)c * a.nblocks * a.nbands + (band >= 0 ? band : 0);
+    const int elen = a.eblock_len;
 
     const bool write_y = a.pass != 1 && a.y != nullptr;
     const bool write_dec = a.pass != 1 && a.xnext != nullptr;
+    const bool keep = write_y || write_dec;                           // uniform
 
     const long long start = (long long)q * a.chunk;
     long long stop = start + a.chunk;
     if (stop > a.n) stop = a.n;
+    double* ykeep = &stage_y[r][0];
 
     for (long long base = start; base < stop; base += 64) {
         const int cnt = (int)((stop - base) < 64 ? (stop - base) : 64);
@@ -130,25 +160,28 @@ __global__ void __launch_bounds__(64) iir_stage_kernel(const IirStageArgs a) {
             const long long idx = (long long)c * a.x_stride + base + lane;
             xv = a.in_f32 ? (double)((const float*)a.x)[idx] : ((const double*)a.x)[idx];
         }
-        for (int k = 0; k < cnt; ++k) {
-            const double x = readlane_f64(xv, k);
-            const double y0 = z + b0 * x;
-            const double y = dpp_row_bcast0(y0);
-            const double zn = dpp_row_shl1(z);
-            const double xb = x * bn;
-            const double t = is_last ? xb : zn + xb;
-            z = t - y * an;
-            if (do_energy) {
-                // zero-state block energy: alpha * sum_i decay^(n-1-i) y_i^2, restarted per block
-                const long long gi = base + k;
-                if ((gi & (a.eblock_len - 1)) == 0) acc = 0.0;
-                acc = acc * decay + y * y;
-                if (leader && ((gi + 1) & (a.eblock_len - 1)) == 0)
-                    a.eblock[((size_t)c * a.nblocks + (gi >> a.eblock_shift)) * a.nbands + band] = alpha * acc;
+        if (!energy) {
+            if (keep) iir_samples<false, true>(0, cnt, xv, b0, bn, an, z, acc, decay, ykeep);
+            else iir_samples<false, false>(0, cnt, xv, b0, bn, an, z, acc, decay, ykeep);
+        } else if (cnt == 64 && elen >= 64) {
+            // energy blocks are whole multiples of this group: boundaries only between groups
+            if ((base & (elen - 1)) == 0) acc = 0.0;
+            if (keep) iir_samples<true, true>(0, 64, xv, b0, bn, an, z, acc, decay, ykeep);
+            else iir_samples<true, false>(0, 64, xv, b0, bn, an, z, acc, decay, ykeep);
+            if (my_energy && ((base + 64) & (elen - 1)) == 0) eout[(size_t)(base >> a.eblock_shift) * a.nbands] = alpha * acc;
+        } else {
+            // short energy blocks (low-rate stages) or a ragged tail: block by block
+            const int step = elen < 64 ? elen : 64;
+            for (int k0 = 0; k0 < cnt; k0 += step) {
+                const int m = (cnt - k0) < step ? (cnt - k0) : step;
+                if (((base + k0) & (elen - 1)) == 0) acc = 0.0;
+                if (keep) iir_samples<true, true>(k0, m, xv, b0, bn, an, z, acc, decay, ykeep);
+                else iir_samples<true, false>(k0, m, xv, b0, bn, an, z, acc, decay, ykeep);
+                if (my_energy && ((base + k0 + m) & (elen - 1)) == 0)
+                    eout[(size_t)((base + k0) >> a.eblock_shift) * a.nbands] = alpha * acc;
             }
-            if (leader) stage_y[r][k] = y;
         }
-        if (write_y || write_dec) {
+        if (keep) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -188,36 +221,80 @@ __global__ void __launch_bounds__(64) iir_scan_kernel(const double* __restrict__
 #pragma unroll
     for (int t = 0; t < kStates; ++t) m[t] = power[((size_t)f * kStates + s) * kStates + t];
     double z = state[(size_t)gid * kStates + s];
-    const int row0 = (threadIdx.x & 63) & ~15;
+    const double* ce = chunk_end + (size_t)gid * nchunks * kStates + s;
+    double* ci = chunk_init + (size_t)gid * nchunks * kStates + s;
+    double e_next = ce[0];
     for (int q = 0; q < nchunks; ++q) {
-        const size_t o = ((size_t)gid * nchunks + q) * kStates + s;
-        chunk_init[o] = z;
-        double acc = chunk_end[o];
-#pragma unroll
-        for (int t = 0; t < kStates; ++t) acc += m[t] * __shfl(z, row0 + t, 64);
-        z = acc;
+        ci[(size_t)q * kStates] = z;
+        const double e = e_next;
+        if (q + 1 < nchunks) e_next = ce[(size_t)(q + 1) * kStates];     // independent of z: overlaps the product
+        // A^L z as four interleaved partial sums (the serial part of the scan is this dependency chain)
+        double p[4] = {0.0, 0.0, 0.0, 0.0};
+        static_assert(kStates == 16, "one 16-lane row per filter");
+#define FRT_SCAN_TERM(T) p[(T) & 3] += m[T] * dpp_row_bcast<T>(z);
+        FRT_SCAN_TERM(0) FRT_SCAN_TERM(1) FRT_SCAN_TERM(2) FRT_SCAN_TERM(3) FRT_SCAN_TERM(4) FRT_SCAN_TERM(5)
+        FRT_SCAN_TERM(6) FRT_SCAN_TERM(7) FRT_SCAN_TERM(8) FRT_SCAN_TERM(9) FRT_SCAN_TERM(10) FRT_SCAN_TERM(11)
+        FRT_SCAN_TERM(12) FRT_SCAN_TERM(13) FRT_SCAN_TERM(14) FRT_SCAN_TERM(15)
+#undef FRT_SCAN_TERM
+        z = e + ((p[0] + p[1]) + (p[2] + p[3]));
     }
 }
 
 // sp_blk = E_blk + sp_{blk-1} * (1-alpha)^n  (exp_smoothing.py:52-54), optional dB + weighting.
-__global__ void energy_scan_kernel(const double* __restrict__ eblock, const double* __restrict__ decay_n,
-                                   double* __restrict__ smooth, void* __restrict__ out, int out_f32, int nblocks, int nbands,
-                                   int total, const double* __restrict__ weight_db, int as_db) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;    // (channel, band)
-    if (gid >= total) return;
-    const int c = gid / nbands, k = gid - c * nbands;
-    double prev = smooth[gid];
-    const double d = decay_n[k];
-    for (int b = 0; b < nblocks; ++b) {
-        const size_t o = ((size_t)c * nblocks + b) * nbands + k;
-        const double sp = eblock[o] + prev * d;
-        prev = sp;
-        double v = sp;
-        if (as_db) v = 10.0 * log10(sp + 1e-30) + (weight_db ? weight_db[k] : 0.0);
-        if (out_f32) ((float*)out)[o] = (float)v;
-        else ((double*)out)[o] = v;
+// One workgroup per channel.  The recurrence is two dependent operations per block; what costs is fetching
+// the block energies, so they go through LDS in tiles: all threads load a tile (coalesced, the next tile's
+// loads already in flight), `nbands` threads run the recurrence over it in LDS, all threads convert and write.
+constexpr int kEnergyThreads = 256;
+constexpr int kEnergyPerThread = 8;                                   // tile = 2048 values
+
+__global__ void __launch_bounds__(kEnergyThreads) energy_scan_kernel(const double* __restrict__ eblock,
+                                                                     const double* __restrict__ decay_n, double* __restrict__ smooth,
+                                                                     void* __restrict__ out, int out_f32, int nblocks, int nbands,
+                                                                     const double* __restrict__ weight_db, int as_db) {
+    __shared__ double tile[kEnergyThreads * kEnergyPerThread];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int tile_blocks = kEnergyThreads * kEnergyPerThread / nbands;      // whole blocks per tile (nbands <= 256)
+    const int tile_vals = tile_blocks * nbands;
+    const double* src = eblock + (size_t)c * nblocks * nbands;
+    const size_t obase = (size_t)c * nblocks * nbands;
+    double prev = tid < nbands ? smooth[(size_t)c * nbands + tid] : 0.0;
+    const double d = tid < nbands ? decay_n[tid] : 0.0;
+
+    double pre[kEnergyPerThread];
+    auto fetch = [&](int b0) {
+        const long long left = (long long)(nblocks - b0) * nbands;
+#pragma unroll
+        for (int j = 0; j < kEnergyPerThread; ++j) {
+            const int i = tid + j * kEnergyThreads;
+            pre[j] = (i < tile_vals && i < left) ? src[(size_t)b0 * nbands + i] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int b0 = 0; b0 < nblocks; b0 += tile_blocks) {
+        const int nb = (nblocks - b0) < tile_blocks ? (nblocks - b0) : tile_blocks;
+#pragma unroll
+        for (int j = 0; j < kEnergyPerThread; ++j) tile[tid + j * kEnergyThreads] = pre[j];
+        __syncthreads();
+        if (b0 + tile_blocks < nblocks) fetch(b0 + tile_blocks);
+        if (tid < nbands) {
+            for (int b = 0; b < nb; ++b) {
+                const double sp = tile[b * nbands + tid] + prev * d;
+                prev = sp;
+                tile[b * nbands + tid] = sp;
+            }
+        }
+        __syncthreads();
+        const int vals = nb * nbands;
+        for (int i = tid; i < vals; i += kEnergyThreads) {
+            double v = tile[i];
+            if (as_db) v = 10.0 * log10(v + 1e-30) + (weight_db ? weight_db[i % nbands] : 0.0);
+            const size_t o = obase + (size_t)b0 * nbands + i;
+            if (out_f32) ((float*)out)[o] = (float)v;
+            else ((double*)out)[o] = v;
+        }
+        __syncthreads();
     }
-    smooth[gid] = prev;
+    if (tid < nbands) smooth[(size_t)c * nbands + tid] = prev;
 }
 
 // ---- host side -----------------------------------------------------------------------------------
@@ -342,8 +419,8 @@ extern "C" int frt_octbank_set_stream(frt_octbank* h, void* s) {
 
 extern "C" int frt_octbank_set_chunk(frt_octbank* h, int chunk0) {
     FRT_REQUIRE(h, "frt_octbank_set_chunk: null handle");
-    FRT_REQUIRE(chunk0 == 0 || (chunk0 > 0 && chunk0 % 16384 == 0),
-                "frt_octbank_set_chunk: chunk %d must be 0 (sequential) or a multiple of 16384", chunk0);
+    FRT_REQUIRE(chunk0 == 0 || (chunk0 >= 1024 && chunk0 % 64 == 0),
+                "frt_octbank_set_chunk: chunk %d must be 0 (sequential) or a multiple of 64, at least 1024", chunk0);
     h->chunk0 = chunk0;
     return FRT_OK;
 }
@@ -400,12 +477,19 @@ extern "C" int frt_octbank_set_state(frt_octbank* h, const double* z) {
     return state_copy(h, const_cast<double*>(z), false);
 }
 
+// Samples per time chunk at octave stage j: the stage-0 chunk scaled to the stage's rate, a multiple of 64
+// (one wavefront load of samples), never below 64.
+static int stage_chunk(int chunk0, int j) {
+    int c = (chunk0 >> j) / 64 * 64;
+    return c < 64 ? 64 : c;
+}
+
 static int ensure_powers(frt_octbank* h) {
     if (h->power_chunk0 == h->chunk0) return FRT_OK;
     std::vector<double> p((size_t)kNOctave * h->nfilt * kStates * kStates);
     for (int j = 0; j < kNOctave; ++j)
         for (int f = 0; f < h->nfilt; ++f)
-            transition_power(&h->h_coef[(size_t)f * kCoefStride + kMaxOrder + 1], h->h_order[f], h->chunk0 >> j,
+            transition_power(&h->h_coef[(size_t)f * kCoefStride + kMaxOrder + 1], h->h_order[f], stage_chunk(h->chunk0, j),
                              &p[((size_t)j * h->nfilt + f) * kStates * kStates]);
     int rc = upload(h->power, p);
     if (rc) return rc;
@@ -420,9 +504,13 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
     int len[kNOctave];
     stage_lengths(n, len);
     const bool parallel = h->chunk0 > 0 && n >= 2 * h->chunk0;
-    int nchunks = 1;
+    int nchunks = 1;              // the largest chunk count of any stage (scratch size)
     if (parallel) {
-        nchunks = (n + h->chunk0 - 1) / h->chunk0;
+        for (int j = 0; j < kNOctave; ++j) {
+            const int cj = stage_chunk(h->chunk0, j);
+            const int nj = (len[j] + cj - 1) / cj;
+            if (nj > nchunks) nchunks = nj;
+        }
         int rc = ensure_powers(h);
         if (rc) return rc;
         const size_t ws = (size_t)h->n_channels * h->nfilt * nchunks * kStates * sizeof(double);
@@ -447,9 +535,9 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
         a.nfilt = h->nfilt;
         a.dec_filter = h->bpo;
         a.state = h->state.as<double>() + (size_t)j * h->stage_state_elems();
-        a.chunk = parallel ? (h->chunk0 >> j) : ((len[j] + 63) / 64 * 64);
+        a.chunk = parallel ? stage_chunk(h->chunk0, j) : ((len[j] + 63) / 64 * 64);
         if (a.chunk < 64) a.chunk = 64;
-        a.nchunks = parallel ? nchunks : 1;
+        a.nchunks = parallel ? (len[j] + a.chunk - 1) / a.chunk : 1;
         a.chunk_end = h->chunk_end.as<double>();
         a.chunk_init = h->chunk_init.as<double>();
         a.y = d_y;
@@ -631,8 +719,8 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
     }
     if ((rc = run_stages(h, d_x, 1, n, (int)n, nullptr, 0, h->eblock.as<double>(), block, nblocks))) return rc;
     const int total = h->n_channels * h->nbands;
-    hipLaunchKernelGGL(energy_scan_kernel, dim3((total + 63) / 64), dim3(64), 0, h->stream, h->eblock.as<double>(),
-                       h->decay_n.as<double>(), h->smooth.as<double>(), (void*)d_out, 1, nblocks, h->nbands, total,
+    hipLaunchKernelGGL(energy_scan_kernel, dim3(h->n_channels), dim3(kEnergyThreads), 0, h->stream, h->eblock.as<double>(),
+                       h->decay_n.as<double>(), h->smooth.as<double>(), (void*)d_out, 1, nblocks, h->nbands,
                        weight_db ? h->weight.as<double>() : nullptr, as_db);
     FRT_HIP_CHECK(hipGetLastError());
     if (!dx) {

@@ -64,6 +64,17 @@ __device__ __forceinline__ double log2_t(double v) { return log2(v); }
 template <typename T>
 __device__ __forceinline__ T shfl_t(T v, int lane) { return __shfl(v, lane, 64); }
 
+// Spectra are written once and read by a later stage: non-temporal stores keep the rows from evicting the
+// samples (and the tables) out of L2 / the Infinity Cache.
+template <typename T>
+__device__ __forceinline__ void stream_store(T* p, T v) {
+#ifdef FRT_PLAIN_STORES
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+
 // TIN: sample type in HBM; T: arithmetic type; SHIFT: register slots a hop advances (0 = reload all)
 template <typename TIN, typename T, int LOG2M, int SHIFT>
 __global__ void
@@ -284,10 +295,10 @@ stft_kernel(const StftArgs a) {
             auto store_all = [&](auto* r, auto conv) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    r[klo + j * TPF] = conv(res[j]);
-                    r[khi - j * TPF] = conv(res[4 + j]);
+                    stream_store(r + klo + j * TPF, conv(res[j]));
+                    stream_store(r + khi - j * TPF, conv(res[4 + j]));
                 }
-                if (i == 0) r[M / 2] = conv(res_mid);
+                if (i == 0) stream_store(r + M / 2, conv(res_mid));
             };
             if (a.kind == FRT_STFT_PSD) {
                 store_all(row, [](T x) { return x; });
@@ -313,10 +324,10 @@ stft_kernel(const StftArgs a) {
                     };
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        prow[klo + j * TPF] = pix(res[j], wl[j]);
-                        prow[khi - j * TPF] = pix(res[4 + j], wh[j]);
+                        stream_store(prow + klo + j * TPF, pix(res[j], wl[j]));
+                        stream_store(prow + khi - j * TPF, pix(res[4 + j], wh[j]));
                     }
-                    if (i == 0) prow[M / 2] = pix(res_mid, wdb_mid);
+                    if (i == 0) stream_store(prow + M / 2, pix(res_mid, wdb_mid));
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {

@@ -112,8 +112,9 @@ void frt_octbank_destroy(frt_octbank* h);
 int frt_octbank_set_stream(frt_octbank* h, void* hip_stream);
 /* zero every carried state (octave_filter_bank_decimation_filtic, friture/filter.py:121-133) */
 int frt_octbank_reset(frt_octbank* h);
-/* 0 (default): sequential in time, bit-identical to the reference.  chunk0 > 0 (multiple of 16384):
- * batches of at least 2*chunk0 samples are processed time-parallel in chunks of chunk0 samples. */
+/* 0 (default): sequential in time, bit-identical to the reference.  chunk0 > 0 (multiple of 64, >= 1024;
+ * a multiple of the energy block for frt_octbank_energies): batches of at least 2*chunk0 samples are
+ * processed time-parallel, octave stage j in chunks of max(64, chunk0 / 2^j) of its own samples. */
 int frt_octbank_set_chunk(frt_octbank* h, int chunk0);
 /* doubles per channel in the packed output for n input samples: sum over bands of ceil(n / dec) */
 int64_t frt_octbank_packed_length(const frt_octbank* h, int n);

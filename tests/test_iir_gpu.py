@@ -99,7 +99,8 @@ def test_iir_bank_ragged_blocks_and_channels(tabs):
         bank.filter(np.zeros((3, 0)))
 
 
-def test_time_parallel_mode_matches_sequential(tabs):
+@pytest.mark.parametrize("chunk", [16384, 4096, 1024, 3072])
+def test_time_parallel_mode_matches_sequential(tabs, chunk):
     from friture_amd.filter import IirBank
     bpo = 3
     boct, aoct = list(tabs[f"boct_{bpo}"]), list(tabs[f"aoct_{bpo}"])
@@ -107,7 +108,7 @@ def test_time_parallel_mode_matches_sequential(tabs):
     x = np.stack([synth("noise", n, 5), synth("tone", n, 6)]).astype(np.float64)
     seq = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, 2)
     par = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, 2)
-    par.set_chunk(16384)
+    par.set_chunk(chunk)
     # warm both with a first block so that the scan starts from a non-zero carried state
     seq.filter(x[:, :4096])
     par.filter(x[:, :4096])
@@ -120,7 +121,7 @@ def test_time_parallel_mode_matches_sequential(tabs):
     assert np.max(np.abs(par.get_state() - seq.get_state())) < 1e-9 * np.max(np.abs(seq.get_state()))
 
 
-@pytest.mark.parametrize("bpo,chunk", [(3, 0), (3, 16384), (24, 16384)])
+@pytest.mark.parametrize("bpo,chunk", [(3, 0), (3, 16384), (3, 2048), (3, 1024), (24, 16384), (24, 4096)])
 def test_band_energies(tabs, bpo, chunk):
     """frt_octbank_energies against the oracle's widget restatement: filter, y^2, exp smoothing."""
     from friture_amd.filter import IirBank
