@@ -62,6 +62,12 @@ struct IirStageArgs {
     int nbands;
     int band_index[kMaxFilters];    // global band index of each filter (-1 for the decimator)
     const double* alpha;       // [nbands]
+    // slot tables, filled by launch_iir_stage
+    int n_channels;
+    int n_row, n_quad;         // filters that need a 16-lane row (order > 4) / fit a quad (order <= 4)
+    int waves_row;             // wavefronts of row slots; quad slots follow
+    int row_filter[kMaxFilters];
+    int quad_filter[kMaxFilters];
 };
 
 __device__ __forceinline__ double dpp_row_bcast0(double v) {
@@ -92,50 +98,93 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// `count` consecutive samples of the 64 a wavefront holds in xv (one per lane), for the four filters of the
-// wavefront at once.  Straight-line code: no per-sample branch, the energy block boundaries are the caller's.
-// The top live lane of a row receives zn = 0 from its (all-zero) dead neighbour, so the reference's special
-// case for the last state (lfilter.py:139, no z[n+1] term) needs no select: 0 + x b == x b.
-template <bool ENERGY, bool KEEP>
-__device__ __forceinline__ void iir_samples(int k0, int count, double xv, double b0, double bn, double an, double& z,
-                                            double& acc, double decay, double* ykeep) {
+// DPP moves inside a filter's lane group.  LPS = 16: the group is a DPP row (row_newbcast:0, row_shl:1 with
+// zero fill).  LPS = 4: the group is a quad (quad_perm [0,0,0,0] and [1,2,3,3]).
+template <int LPS>
+__device__ __forceinline__ double group_bcast0(double v) {
+    constexpr int ctrl = LPS == 16 ? 0x150 : 0x00;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int LPS>
+__device__ __forceinline__ double group_shl1(double v) {
+    constexpr int ctrl = LPS == 16 ? 0x101 : 0xF9;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xF, 0xF, LPS == 16);
+    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xF, 0xF, LPS == 16);
+    return __hiloint2double(hi, lo);
+}
+
+// One sample of every filter of the wavefront.  The reference's update (lfilter.py:131-139)
+//     y = z[0] + b[0] x;   z[s] = z[s+1] + x b[s+1] - y a[s+1];   z[last] = x b[last] - y a[last]
+// with z[s+1] arriving by a lane shift.  `keep` is 1 except on the top lane of a quad, where the shift hands the
+// lane its own state back: fma(zn, keep, x b) is then exactly x b, and exactly zn + x b (one rounding) elsewhere.
+// In a 16-lane row the lanes above the filter order hold zeros, so the top live lane adds 0.
+template <int LPS>
+__device__ __forceinline__ double iir_step(double x, double b0, double bn, double an, double keep, double& z) {
+    const double y = group_bcast0<LPS>(z + b0 * x);
+    const double zn = group_shl1<LPS>(z);
+    z = __builtin_fma(zn, keep, x * bn) - y * an;
+    return y;
+}
+
+// `count` consecutive samples, read from and (KEEP) replaced by the outputs in the group's LDS row xy[0..63].
+// Straight-line code: no per-sample branch, the energy block boundaries are the caller's.
+template <int LPS, bool ENERGY, bool KEEP>
+__device__ __forceinline__ void iir_samples(int k0, int count, double* xy, double b0, double bn, double an, double keep,
+                                            double& z, double& acc, double decay) {
 #pragma unroll 4
     for (int k = k0; k < k0 + count; ++k) {
-        const double x = readlane_f64(xv, k);
-        const double y = dpp_row_bcast0(z + b0 * x);
-        const double zn = dpp_row_shl1(z);
-        z = (zn + x * bn) - y * an;
+        const double y = iir_step<LPS>(xy[k], b0, bn, an, keep, z);
         if (ENERGY) acc = acc * decay + y * y;     // zero-state block energy, Horner form (exp_smoothing.py:40-56)
-        if (KEEP) ykeep[k] = y;                    // every lane of the row writes the same value to the same slot
+        if (KEEP) xy[k] = y;                       // every lane of the group writes the same value to the same slot
     }
 }
 
-__global__ void __launch_bounds__(64) iir_stage_kernel(const IirStageArgs a) {
-    __shared__ double stage_y[4][64];
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
+// A wavefront carries 64 / LPS slots; a slot is one (channel, time chunk, filter) with its own sample stream.
+template <int LPS>
+__device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long wave, double* lds) {
+    constexpr int SPW = 64 / LPS;
     const int lane = threadIdx.x;
-    const int r = lane >> 4, s = lane & 15;
-    const int q = blockIdx.x, g = blockIdx.y, c = blockIdx.z;
-    const int f = 4 * g + r;
-    const bool fvalid = f < a.nfilt;
-    const int fc = fvalid ? f : 0;
-    const int ord = fvalid ? a.order[fc] : 0;
-    const bool live = fvalid && s < ord;
-    const bool leader = fvalid && s == 0;
+    const int sl = lane / LPS, s = lane % LPS;
+    const int nf = LPS == 4 ? a.n_quad : a.n_row;
+    const int* flist = LPS == 4 ? a.quad_filter : a.row_filter;
+    const long long nslots = (long long)a.n_channels * a.nchunks * nf;
+    const long long gslot = wave * SPW + sl;
+    const bool valid = gslot < nslots;
+    const long long gs = valid ? gslot : 0;
+    const int fi = (int)(gs % nf);
+    const long long cq = gs / nf;
+    const int q = (int)(cq % a.nchunks), c = (int)(cq / a.nchunks);
+    const int f = flist[fi];
+    const int ord = a.order[f];
+    const bool live = valid && s < ord;
+    const bool leader = valid && s == 0;
 
-    const double* cf = a.coef + (size_t)fc * kCoefStride;
+    const double* cf = a.coef + (size_t)f * kCoefStride;
     const double b0 = cf[0];
     const double bn = live ? cf[s + 1] : 0.0;
     const double an = live ? cf[kMaxOrder + 1 + s + 1] : 0.0;
+    const double keep = (LPS == 4 && s == 3) ? 0.0 : 1.0;
 
-    const size_t sidx = ((size_t)c * a.nfilt + fc) * kStates + s;
+    const size_t sidx = ((size_t)c * a.nfilt + f) * kStates + s;
+    const size_t cidx = (((size_t)c * a.nfilt + f) * a.nchunks + q) * kStates + s;
     double z = 0.0;
     if (live) {
         if (a.pass == 0) z = a.state[sidx];
-        else if (a.pass == 2) z = a.chunk_init[(((size_t)c * a.nfilt + fc) * a.nchunks + q) * kStates + s];
+        else if (a.pass == 2) z = a.chunk_init[cidx];
     }
 
-    const int band = fvalid ? a.band_index[fc] : -1;
+    const int band = a.band_index[f];
     const bool energy = a.eblock != nullptr && a.pass != 1;           // uniform
     const bool my_energy = energy && band >= 0 && leader;
     const double alpha = (energy && band >= 0) ? a.alpha[band] : 0.0;
@@ -146,97 +195,175 @@ __global__ void __launch_bounds__(64) iir_stage_kernel(const IirStageArgs a) {
 
     const bool write_y = a.pass != 1 && a.y != nullptr;
     const bool write_dec = a.pass != 1 && a.xnext != nullptr;
-    const bool keep = write_y || write_dec;                           // uniform
+    const bool keep_out = write_y || write_dec;                       // uniform
+    const bool is_dec = f == a.dec_filter;
 
     const long long start = (long long)q * a.chunk;
     long long stop = start + a.chunk;
     if (stop > a.n) stop = a.n;
-    double* ykeep = &stage_y[r][0];
+    if (!valid) stop = start;
+    double* xy = lds + sl * 64;
+    const long long xrow = (long long)c * a.x_stride;
 
-    for (long long base = start; base < stop; base += 64) {
-        const int cnt = (int)((stop - base) < 64 ? (stop - base) : 64);
-        double xv = 0.0;
-        if (lane < cnt) {
-            const long long idx = (long long)c * a.x_stride + base + lane;
-            xv = a.in_f32 ? (double)((const float*)a.x)[idx] : ((const double*)a.x)[idx];
-        }
-        if (!energy) {
-            if (keep) iir_samples<false, true>(0, cnt, xv, b0, bn, an, z, acc, decay, ykeep);
-            else iir_samples<false, false>(0, cnt, xv, b0, bn, an, z, acc, decay, ykeep);
-        } else if (cnt == 64 && elen >= 64) {
-            // energy blocks are whole multiples of this group: boundaries only between groups
-            if ((base & (elen - 1)) == 0) acc = 0.0;
-            if (keep) iir_samples<true, true>(0, 64, xv, b0, bn, an, z, acc, decay, ykeep);
-            else iir_samples<true, false>(0, 64, xv, b0, bn, an, z, acc, decay, ykeep);
-            if (my_energy && ((base + 64) & (elen - 1)) == 0) eout[(size_t)(base >> a.eblock_shift) * a.nbands] = alpha * acc;
-        } else {
-            // short energy blocks (low-rate stages) or a ragged tail: block by block
-            const int step = elen < 64 ? elen : 64;
-            for (int k0 = 0; k0 < cnt; k0 += step) {
-                const int m = (cnt - k0) < step ? (cnt - k0) : step;
-                if (((base + k0) & (elen - 1)) == 0) acc = 0.0;
-                if (keep) iir_samples<true, true>(k0, m, xv, b0, bn, an, z, acc, decay, ykeep);
-                else iir_samples<true, false>(k0, m, xv, b0, bn, an, z, acc, decay, ykeep);
-                if (my_energy && ((base + k0 + m) & (elen - 1)) == 0)
-                    eout[(size_t)((base + k0) >> a.eblock_shift) * a.nbands] = alpha * acc;
-            }
-        }
-        if (keep) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int g0 = 0; g0 < a.chunk; g0 += 64) {                        // a.chunk is a multiple of 64
+        const long long base = start + g0;
+        const long long left = stop - base;
+        const int cnt = left >= 64 ? 64 : (left > 0 ? (int)left : 0);
+        // the LPS lanes of a slot fetch its 64 samples
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int ff = 4 * g + rr;
-                if (ff >= a.nfilt) break;
-                if (ff == a.dec_filter) {
-                    if (write_dec && lane < 32 && 2 * lane < cnt)
-                        a.xnext[(long long)c * a.xnext_stride + (base >> 1) + lane] = stage_y[rr][2 * lane];
-                } else if (write_y && lane < cnt) {
-                    a.y[(long long)c * a.y_cstride + a.y_off[ff] + base + lane] = stage_y[rr][lane];
+        for (int j = 0; j < SPW; ++j) {
+            const int k = s + LPS * j;
+            double v = 0.0;
+            if (k < cnt) v = a.in_f32 ? (double)((const float*)a.x)[xrow + base + k] : ((const double*)a.x)[xrow + base + k];
+            xy[k] = v;
+        }
+        wave_lds_sync();
+        if (__all(cnt == 64)) {
+            if (!energy) {
+                if (keep_out) iir_samples<LPS, false, true>(0, 64, xy, b0, bn, an, keep, z, acc, decay);
+                else iir_samples<LPS, false, false>(0, 64, xy, b0, bn, an, keep, z, acc, decay);
+            } else if (elen >= 64) {
+                // energy blocks are whole multiples of a group: boundaries only between groups (chunks start on
+                // block boundaries, so the phase g0 mod elen is the same for every slot)
+                if ((g0 & (elen - 1)) == 0) acc = 0.0;
+                if (keep_out) iir_samples<LPS, true, true>(0, 64, xy, b0, bn, an, keep, z, acc, decay);
+                else iir_samples<LPS, true, false>(0, 64, xy, b0, bn, an, keep, z, acc, decay);
+                if (my_energy && ((g0 + 64) & (elen - 1)) == 0) eout[(size_t)(base >> a.eblock_shift) * a.nbands] = alpha * acc;
+            } else {
+                for (int k0 = 0; k0 < 64; k0 += elen) {               // short blocks of the low-rate stages
+                    acc = 0.0;
+                    if (keep_out) iir_samples<LPS, true, true>(k0, elen, xy, b0, bn, an, keep, z, acc, decay);
+                    else iir_samples<LPS, true, false>(k0, elen, xy, b0, bn, an, keep, z, acc, decay);
+                    if (my_energy) eout[(size_t)((base + k0) >> a.eblock_shift) * a.nbands] = alpha * acc;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            // ragged end of a channel (or slots past the end): same arithmetic, state frozen beyond the slot's count
+            for (int k = 0; k < 64; ++k) {
+                if (!__any(k < cnt)) break;
+                const bool on = k < cnt;
+                double zt = z;
+                const double y = iir_step<LPS>(xy[k], b0, bn, an, keep, zt);
+                z = on ? zt : z;
+                if (energy) {
+                    if (((g0 + k) & (elen - 1)) == 0) acc = 0.0;
+                    const double at = acc * decay + y * y;
+                    acc = on ? at : acc;
+                    if (my_energy && on && ((g0 + k + 1) & (elen - 1)) == 0)
+                        eout[(size_t)((base + k) >> a.eblock_shift) * a.nbands] = alpha * acc;
+                }
+                if (keep_out) xy[k] = y;
+            }
         }
+        if (keep_out) {
+            wave_lds_sync();
+            if (is_dec) {
+                if (write_dec) {
+#pragma unroll
+                    for (int j = 0; j < SPW; ++j) {
+                        const int k = s + LPS * j;
+                        if (!(k & 1) && k < cnt) a.xnext[(long long)c * a.xnext_stride + ((base + k) >> 1)] = xy[k];
+                    }
+                }
+            } else if (write_y) {
+                double* yrow = a.y + (long long)c * a.y_cstride + a.y_off[f] + base;
+#pragma unroll
+                for (int j = 0; j < SPW; ++j) {
+                    const int k = s + LPS * j;
+                    if (k < cnt) yrow[k] = xy[k];
+                }
+            }
+        }
+        wave_lds_sync();
     }
 
     if (live) {
-        if (a.pass == 1) a.chunk_end[(((size_t)c * a.nfilt + fc) * a.nchunks + q) * kStates + s] = z;
+        if (a.pass == 1) a.chunk_end[cidx] = z;
         else if (q == a.nchunks - 1) a.state[sidx] = z;
     }
 }
 
-// z_{q+1} = A^L z_q + s_q over the chunks of one (channel, filter); 16 lanes per filter.
-// power: [nfilt][16][16] row-major A^L; chunk_end -> chunk_init (may not alias).
-__global__ void __launch_bounds__(64) iir_scan_kernel(const double* __restrict__ power, const double* __restrict__ state,
-                                                      const double* __restrict__ chunk_end, double* __restrict__ chunk_init,
-                                                      int nfilt, int nchunks, int total_filters) {
-    const int gid = blockIdx.x * 4 + (threadIdx.x >> 4);     // (channel, filter) pair
-    const int s = threadIdx.x & 15;
-    if (gid >= total_filters) return;
+// grid.x = waves of 16-lane-row slots (filters of order > 4: the decimator) followed by waves of quad slots.
+__global__ void __launch_bounds__(64) iir_stage_kernel(const IirStageArgs a) {
+    __shared__ double lds[16 * 64];
+    if ((int)blockIdx.x < a.waves_row) iir_stage_body<16>(a, blockIdx.x, lds);
+    else iir_stage_body<4>(a, (long long)blockIdx.x - a.waves_row, lds);
+}
+
+// Fills the slot tables of a stage from the filter orders and launches it.
+static int launch_iir_stage(IirStageArgs a, const int* orders, int n_channels, hipStream_t stream) {
+    a.n_channels = n_channels;
+    a.n_row = a.n_quad = 0;
+    for (int f = 0; f < a.nfilt; ++f) {
+        if (orders[f] > 4) a.row_filter[a.n_row++] = f;
+        else a.quad_filter[a.n_quad++] = f;
+    }
+    const long long per = (long long)n_channels * a.nchunks;
+    const long long wr = (per * a.n_row + 3) / 4, wq = (per * a.n_quad + 15) / 16;
+    FRT_REQUIRE(wr + wq < (1ll << 31), "iir stage: too many wavefronts");
+    a.waves_row = (int)wr;
+    if (wr + wq == 0) return FRT_OK;
+    hipLaunchKernelGGL(iir_stage_kernel, dim3((unsigned)(wr + wq)), dim3(64), 0, stream, a);
+    FRT_HIP_CHECK(hipGetLastError());
+    return FRT_OK;
+}
+
+// A^L z for the 16 states of a filter held by the lanes of a DPP row, lane s owning row s of the matrix:
+// four interleaved partial sums (the serial part of the scan is this dependency chain).
+__device__ __forceinline__ double row_matvec(const double (&m)[kStates], double z) {
+    double p[4] = {0.0, 0.0, 0.0, 0.0};
+    static_assert(kStates == 16, "one 16-lane row per filter");
+#define FRT_SCAN_TERM(T) p[(T) & 3] += m[T] * dpp_row_bcast<T>(z);
+    FRT_SCAN_TERM(0) FRT_SCAN_TERM(1) FRT_SCAN_TERM(2) FRT_SCAN_TERM(3) FRT_SCAN_TERM(4) FRT_SCAN_TERM(5)
+    FRT_SCAN_TERM(6) FRT_SCAN_TERM(7) FRT_SCAN_TERM(8) FRT_SCAN_TERM(9) FRT_SCAN_TERM(10) FRT_SCAN_TERM(11)
+    FRT_SCAN_TERM(12) FRT_SCAN_TERM(13) FRT_SCAN_TERM(14) FRT_SCAN_TERM(15)
+#undef FRT_SCAN_TERM
+    return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
+// z_{q+1} = A^L z_q + s_q over the chunks of one (channel, filter): chunk_end (s_q, the zero-state end states
+// of pass 1) -> chunk_init (z_q).  One workgroup per (channel, filter), one 16-lane row per GROUP of `group`
+// consecutive chunks: (1) every row runs its group from a zero state, (2) row 0 chains the groups with
+// A^(L group), (3) every row replays its group from its true start.  3 x nchunks / rows serial steps instead
+// of nchunks.  power_l / power_g: [nfilt][16][16] row-major A^L and A^(L group).
+constexpr int kScanRows = 16;
+
+__global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* __restrict__ power_l,
+                                                                  const double* __restrict__ power_g,
+                                                                  const double* __restrict__ state,
+                                                                  const double* __restrict__ chunk_end,
+                                                                  double* __restrict__ chunk_init, int nfilt, int nchunks, int group) {
+    __shared__ double gend[kScanRows][kStates], gstart[kScanRows][kStates];
+    const int gid = blockIdx.x;                               // (channel, filter) pair
+    const int row = threadIdx.x >> 4, s = threadIdx.x & 15;
     const int f = gid % nfilt;
     double m[kStates];
 #pragma unroll
-    for (int t = 0; t < kStates; ++t) m[t] = power[((size_t)f * kStates + s) * kStates + t];
-    double z = state[(size_t)gid * kStates + s];
+    for (int t = 0; t < kStates; ++t) m[t] = power_l[((size_t)f * kStates + s) * kStates + t];
     const double* ce = chunk_end + (size_t)gid * nchunks * kStates + s;
     double* ci = chunk_init + (size_t)gid * nchunks * kStates + s;
-    double e_next = ce[0];
-    for (int q = 0; q < nchunks; ++q) {
+    const int q0 = row * group;
+    const int q1 = (q0 + group) < nchunks ? (q0 + group) : nchunks;
+
+    double z = 0.0;
+    for (int q = q0; q < q1; ++q) z = ce[(size_t)q * kStates] + row_matvec(m, z);
+    gend[row][s] = z;
+    __syncthreads();
+    if (row == 0) {
+        double mg[kStates];
+#pragma unroll
+        for (int t = 0; t < kStates; ++t) mg[t] = power_g[((size_t)f * kStates + s) * kStates + t];
+        double zz = state[(size_t)gid * kStates + s];
+        for (int r = 0; r < kScanRows; ++r) {
+            gstart[r][s] = zz;
+            zz = gend[r][s] + row_matvec(mg, zz);
+        }
+    }
+    __syncthreads();
+    z = gstart[row][s];
+    for (int q = q0; q < q1; ++q) {
         ci[(size_t)q * kStates] = z;
-        const double e = e_next;
-        if (q + 1 < nchunks) e_next = ce[(size_t)(q + 1) * kStates];     // independent of z: overlaps the product
-        // A^L z as four interleaved partial sums (the serial part of the scan is this dependency chain)
-        double p[4] = {0.0, 0.0, 0.0, 0.0};
-        static_assert(kStates == 16, "one 16-lane row per filter");
-#define FRT_SCAN_TERM(T) p[(T) & 3] += m[T] * dpp_row_bcast<T>(z);
-        FRT_SCAN_TERM(0) FRT_SCAN_TERM(1) FRT_SCAN_TERM(2) FRT_SCAN_TERM(3) FRT_SCAN_TERM(4) FRT_SCAN_TERM(5)
-        FRT_SCAN_TERM(6) FRT_SCAN_TERM(7) FRT_SCAN_TERM(8) FRT_SCAN_TERM(9) FRT_SCAN_TERM(10) FRT_SCAN_TERM(11)
-        FRT_SCAN_TERM(12) FRT_SCAN_TERM(13) FRT_SCAN_TERM(14) FRT_SCAN_TERM(15)
-#undef FRT_SCAN_TERM
-        z = e + ((p[0] + p[1]) + (p[2] + p[3]));
+        z = ce[(size_t)q * kStates] + row_matvec(m, z);
     }
 }
 
@@ -484,16 +611,29 @@ static int stage_chunk(int chunk0, int j) {
     return c < 64 ? 64 : c;
 }
 
-static int ensure_powers(frt_octbank* h) {
-    if (h->power_chunk0 == h->chunk0) return FRT_OK;
-    std::vector<double> p((size_t)kNOctave * h->nfilt * kStates * kStates);
-    for (int j = 0; j < kNOctave; ++j)
-        for (int f = 0; f < h->nfilt; ++f)
-            transition_power(&h->h_coef[(size_t)f * kCoefStride + kMaxOrder + 1], h->h_order[f], stage_chunk(h->chunk0, j),
-                             &p[((size_t)j * h->nfilt + f) * kStates * kStates]);
+// chunks a scan row chains (iir_scan_kernel)
+static int scan_group(int nchunks) { return (nchunks + kScanRows - 1) / kScanRows; }
+
+// A^L and A^(L group) of every (stage, filter) for the current chunking of n input samples.
+static int ensure_powers(frt_octbank* h, int n) {
+    if (h->power_chunk0 == h->chunk0 && h->power_n == n) return FRT_OK;
+    int len[kNOctave];
+    stage_lengths(n, len);
+    const size_t per = (size_t)kNOctave * h->nfilt * kStates * kStates;
+    std::vector<double> p(2 * per);
+    for (int j = 0; j < kNOctave; ++j) {
+        const int cj = stage_chunk(h->chunk0, j);
+        const int nj = (len[j] + cj - 1) / cj;
+        for (int f = 0; f < h->nfilt; ++f) {
+            const double* ac = &h->h_coef[(size_t)f * kCoefStride + kMaxOrder + 1];
+            transition_power(ac, h->h_order[f], cj, &p[((size_t)j * h->nfilt + f) * kStates * kStates]);
+            transition_power(ac, h->h_order[f], (long long)cj * scan_group(nj), &p[per + ((size_t)j * h->nfilt + f) * kStates * kStates]);
+        }
+    }
     int rc = upload(h->power, p);
     if (rc) return rc;
     h->power_chunk0 = h->chunk0;
+    h->power_n = n;
     return FRT_OK;
 }
 
@@ -511,7 +651,7 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
             const int nj = (len[j] + cj - 1) / cj;
             if (nj > nchunks) nchunks = nj;
         }
-        int rc = ensure_powers(h);
+        int rc = ensure_powers(h, n);
         if (rc) return rc;
         const size_t ws = (size_t)h->n_channels * h->nfilt * nchunks * kStates * sizeof(double);
         if ((rc = h->chunk_end.reserve(ws)) || (rc = h->chunk_init.reserve(ws))) return rc;
@@ -560,19 +700,19 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
         a.nbands = h->nbands;
         a.alpha = h->alpha.as<double>();
         if (a.n == 0) continue;
-        const dim3 grid(a.nchunks, (h->nfilt + 3) / 4, h->n_channels);
+        int rc;
         if (!parallel) {
             a.pass = 0;
-            hipLaunchKernelGGL(iir_stage_kernel, grid, dim3(64), 0, h->stream, a);
+            if ((rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream))) return rc;
         } else {
             a.pass = 1;
-            hipLaunchKernelGGL(iir_stage_kernel, grid, dim3(64), 0, h->stream, a);
-            const int total = h->n_channels * h->nfilt;
-            hipLaunchKernelGGL(iir_scan_kernel, dim3((total + 3) / 4), dim3(64), 0, h->stream,
-                               h->power.as<double>() + (size_t)j * h->nfilt * kStates * kStates, a.state,
-                               h->chunk_end.as<double>(), h->chunk_init.as<double>(), h->nfilt, a.nchunks, total);
+            if ((rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream))) return rc;
+            const size_t per = (size_t)kNOctave * h->nfilt * kStates * kStates, off = (size_t)j * h->nfilt * kStates * kStates;
+            hipLaunchKernelGGL(iir_scan_kernel, dim3(h->n_channels * h->nfilt), dim3(kScanRows * 16), 0, h->stream,
+                               h->power.as<double>() + off, h->power.as<double>() + per + off, a.state, h->chunk_end.as<double>(),
+                               h->chunk_init.as<double>(), h->nfilt, a.nchunks, scan_group(a.nchunks));
             a.pass = 2;
-            hipLaunchKernelGGL(iir_stage_kernel, grid, dim3(64), 0, h->stream, a);
+            if ((rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream))) return rc;
         }
         FRT_HIP_CHECK(hipGetLastError());
     }
@@ -768,8 +908,7 @@ extern "C" int frt_decimate_multiple(frt_octbank* h, int n_stages, const double*
         a.band_index[0] = -1;
         a.xnext = h->xbuf[j + 1].as<double>();
         a.xnext_stride = len[j + 1];
-        hipLaunchKernelGGL(iir_stage_kernel, dim3(1, 1, h->n_channels), dim3(64), 0, h->stream, a);
-        FRT_HIP_CHECK(hipGetLastError());
+        if ((rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream))) return rc;
     }
     const size_t obytes = (size_t)h->n_channels * len[n_stages] * sizeof(double);
     FRT_HIP_CHECK(hipMemcpyAsync(out, h->xbuf[n_stages].ptr, obytes, dx ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
@@ -824,10 +963,7 @@ extern "C" int frt_lfilter_f64(const double* b, const double* a, int n_coef, con
     s.y = dy.as<double>();
     s.y_cstride = n;
     s.band_index[0] = -1;
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(iir_stage_kernel, dim3(1, 1, 1), dim3(64), 0, nullptr, s);
-        e = hipGetLastError();
-    }
+    if (e == hipSuccess && launch_iir_stage(s, &order, 1, nullptr) != FRT_OK) e = hipErrorLaunchFailure;
     if (e == hipSuccess) e = hipMemcpy(y, dy.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(st.data(), dstate.ptr, kStates * sizeof(double), hipMemcpyDeviceToHost);
     cleanup();

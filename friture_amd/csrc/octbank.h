@@ -37,6 +37,7 @@ struct frt_octbank {
     frt::DeviceBuffer xin, ypacked, xbuf[frt::kNOctave], chunk_end, chunk_init, power;
     frt::DeviceBuffer eblock, alpha, decay_n, smooth, weight, eout;
     int power_chunk0 = -1;
+    int power_n = -1;
     frt_ola_state* ola = nullptr;
     // interactive host-buffer path: the per-block launch sequence (H2D, nine stage kernels, D2H) is
     // launch bound, so it is captured once per block length into a hipGraph and replayed

@@ -116,8 +116,11 @@ def test_time_parallel_mode_matches_sequential(tabs, chunk):
     yp, _ = par.filter(x[:, 4096:])
     for c in range(2):
         for k in range(27):
-            err = np.max(np.abs(yp[c][k] - ys[c][k])) / np.max(np.abs(ys[c][k]))
-            assert err < 1e-7, (c, k, err)
+            # same linear recurrence in another association order: rounding errors scale with the signal that
+            # drives the states (the input), not with the band's own level — a stop-band output 1e-5 below the
+            # input carries them at the same absolute size
+            err = np.max(np.abs(yp[c][k] - ys[c][k]))
+            assert err < 1e-7 * np.max(np.abs(ys[c][k])) + 1e-10 * np.max(np.abs(x[c])), (c, k, err)
     assert np.max(np.abs(par.get_state() - seq.get_state())) < 1e-9 * np.max(np.abs(seq.get_state()))
 
 

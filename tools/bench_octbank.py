@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--channels", type=int, default=8)
     ap.add_argument("--bpo", type=int, default=3)
     ap.add_argument("--log2-samples", type=int, default=22)
-    ap.add_argument("--chunk", type=int, default=16384)
+    ap.add_argument("--chunk", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--cpu-blocks", type=int, default=0, help="time the oracle on this many blocks of channel 0")
     args = ap.parse_args()
