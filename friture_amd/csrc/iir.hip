@@ -15,18 +15,20 @@
 //
 // Kernel shape.  A recurrence is serial in time, so the parallel axes are channels, filters, the
 // *state index inside a filter*, and — for long batches — time chunks.
-//   * One 16-lane DPP row per filter: lane s of the row owns state z[s] and the coefficient pair
-//     (b[s+1], a[s+1]).  Per sample: the row leader forms y = z[0] + b[0] x, `row_newbcast:0`
-//     hands y to the row, `row_shl:1` hands z[s+1] to lane s, and every lane updates its state
-//     with exactly the reference's operations.  The loop-carried dependency is add -> broadcast
-//     -> mul -> sub, whatever the filter order; a wavefront carries four filters.
-//   * One launch per octave stage; grid = (time chunk, filter group, channel).
+//   * A lane group per filter: lane s owns state z[s] and the coefficient pair (b[s+1], a[s+1]).  Per
+//     sample the group leader forms y = z[0] + b[0] x, a DPP broadcast hands y to the group, a DPP shift
+//     hands z[s+1] to lane s, and every lane updates its state with exactly the reference's operations.
+//     The loop-carried dependency is add -> broadcast -> mul -> sub, whatever the filter order.  The
+//     12th-order decimator takes a 16-lane DPP row, the 4th-order band-passes a quad: a wavefront carries
+//     4 or 16 slots, a slot being one (channel, time chunk, filter) with its own sample stream.
+//   * One launch per octave stage and pass.
 //   * Sequential mode (one chunk) starts from the carried state and is bit-identical to the
-//     reference.  Time-parallel mode runs every chunk twice: pass 1 from a zero state to get the
-//     chunk's zero-state end state, a short scan z_{q+1} = A^L z_q + s_q over the chunks (A^L is
-//     computed on the host), then pass 2 from the true initial state of each chunk.  That is the
-//     same linear recurrence evaluated in a different association order: results agree with the
-//     sequential ones to rounding (1e-15 relative), and the parallelism is C x filters x chunks.
+//     reference.  Time-parallel mode needs every chunk's initial state: the zero-state end states of the
+//     chunks (a table product, iir_zero_state_kernel), a scan z_{q+1} = A^L z_q + s_q over the chunks
+//     (iir_scan_kernel; the powers come from the host), then the output pass from the true initial state of
+//     each chunk.  That is the same linear recurrence in a different association order: results agree with
+//     the sequential ones to ~1e-10 of the input scale after nine stages (the direct-form decimator
+//     amplifies rounding), and the parallelism is C x filters x chunks.
 #include <cmath>
 
 #include "common.h"
@@ -308,6 +310,79 @@ static int launch_iir_stage(IirStageArgs a, const int* orders, int n_channels, h
     return FRT_OK;
 }
 
+// ---- time-parallel mode, pass 1: zero-state end states as dot products -----------------------------------
+// The end state of a chunk started from zero is linear in its samples:  s = sum_k A^(L-1-k) B x[k],
+// B[s] = b[s+1] - a[s+1] b[0].  Unlike the recurrence this has no serial dependency: a lane owns one
+// (channel, chunk) column and walks its samples, the table row g[k][0..rows) is wave-uniform (scalar loads,
+// the FMAs take it from SGPRs), 32 states per lane are accumulated at a time.  blockIdx.y splits the chunk
+// into K-slices whose partial sums the scan kernel adds; blockIdx.z tiles the rows.
+constexpr int kZsRows = 32;
+constexpr int kMaxSlices = 8;
+
+struct ZeroStateArgs {
+    const void* x;
+    long long x_stride;
+    int n, in_f32;
+    int chunk, nchunks, n_channels, nfilt;
+    int slice;                 // samples per K-slice (multiple of 4)
+    const double* table;       // [chunk][rows_padded]: g[k][r]
+    int rows, rows_padded;
+    const int* rowmap;         // [rows_padded]: f * kStates + s of each row, -1 for padding
+    double* partial;           // [n_slices][C][nfilt][nchunks][kStates]
+    long long partial_stride;
+};
+
+__global__ void __launch_bounds__(64) iir_zero_state_kernel(const ZeroStateArgs a) {
+    const int lane = threadIdx.x;
+    const long long col = (long long)blockIdx.x * 64 + lane;
+    const long long ncols = (long long)a.n_channels * a.nchunks;
+    const bool valid = col < ncols;
+    const long long cc = valid ? col : 0;
+    const int c = (int)(cc / a.nchunks), q = (int)(cc % a.nchunks);
+    const int r0 = blockIdx.z * kZsRows;
+    const int k0 = blockIdx.y * a.slice;
+    const long long first = (long long)q * a.chunk + k0;              // stage sample index of this lane's first sample
+    const long long xrow = (long long)c * a.x_stride;
+    const double* __restrict__ g = a.table + (size_t)k0 * a.rows_padded + r0;
+    double acc[kZsRows];
+#pragma unroll
+    for (int r = 0; r < kZsRows; ++r) acc[r] = 0.0;
+    // eight samples of the lane's own stream per batch (one 64-byte line), their loads in flight together
+    for (int k = 0; k < a.slice; k += 8) {
+        double xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long i = first + k + u;
+            const bool ok = valid && i < a.n;
+            const long long ii = ok ? xrow + i : 0;
+            const double v = a.in_f32 ? (double)((const float*)a.x)[ii] : ((const double*)a.x)[ii];
+            xv[u] = ok ? v : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double* __restrict__ gk = g + (size_t)(k + u) * a.rows_padded;
+#pragma unroll
+            for (int r = 0; r < kZsRows; ++r) acc[r] = __builtin_fma(gk[r], xv[u], acc[r]);
+        }
+    }
+    if (!valid) return;
+    double* out = a.partial + (size_t)blockIdx.y * a.partial_stride;
+#pragma unroll
+    for (int r = 0; r < kZsRows; ++r) {
+        const int m = a.rowmap[r0 + r];                               // uniform
+        if (m >= 0) out[(((size_t)c * a.nfilt + (m >> 4)) * a.nchunks + q) * kStates + (m & 15)] = acc[r];
+    }
+}
+
+// partial[0][i] += partial[1..n_slices)[i]: the K-slices of pass 1 summed in slice order
+__global__ void __launch_bounds__(256) iir_slice_sum_kernel(double* __restrict__ partial, long long stride, int n_slices, long long count) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double e = partial[i];
+    for (int p = 1; p < n_slices; ++p) e += partial[(size_t)p * stride + i];
+    partial[i] = e;
+}
+
 // A^L z for the 16 states of a filter held by the lanes of a DPP row, lane s owning row s of the matrix:
 // four interleaved partial sums (the serial part of the scan is this dependency chain).
 __device__ __forceinline__ double row_matvec(const double (&m)[kStates], double z) {
@@ -326,12 +401,13 @@ __device__ __forceinline__ double row_matvec(const double (&m)[kStates], double 
 // consecutive chunks: (1) every row runs its group from a zero state, (2) row 0 chains the groups with
 // A^(L group), (3) every row replays its group from its true start.  3 x nchunks / rows serial steps instead
 // of nchunks.  power_l / power_g: [nfilt][16][16] row-major A^L and A^(L group).
-constexpr int kScanRows = 16;
+constexpr int kScanRows = 32;
 
 __global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* __restrict__ power_l,
                                                                   const double* __restrict__ power_g,
                                                                   const double* __restrict__ state,
                                                                   const double* __restrict__ chunk_end,
+                                                                  const int* __restrict__ order,
                                                                   double* __restrict__ chunk_init, int nfilt, int nchunks, int group) {
     __shared__ double gend[kScanRows][kStates], gstart[kScanRows][kStates];
     const int gid = blockIdx.x;                               // (channel, filter) pair
@@ -344,16 +420,19 @@ __global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* 
     double* ci = chunk_init + (size_t)gid * nchunks * kStates + s;
     const int q0 = row * group;
     const int q1 = (q0 + group) < nchunks ? (q0 + group) : nchunks;
+    const bool live = s < order[f];
+    // zero-state end state of chunk q; lanes above the order stay 0 whatever the scratch holds
+    auto end_state = [&](int q) -> double { return live ? ce[(size_t)q * kStates] : 0.0; };
 
     double z = 0.0;
-    for (int q = q0; q < q1; ++q) z = ce[(size_t)q * kStates] + row_matvec(m, z);
+    for (int q = q0; q < q1; ++q) z = end_state(q) + row_matvec(m, z);
     gend[row][s] = z;
     __syncthreads();
     if (row == 0) {
         double mg[kStates];
 #pragma unroll
         for (int t = 0; t < kStates; ++t) mg[t] = power_g[((size_t)f * kStates + s) * kStates + t];
-        double zz = state[(size_t)gid * kStates + s];
+        double zz = live ? state[(size_t)gid * kStates + s] : 0.0;
         for (int r = 0; r < kScanRows; ++r) {
             gstart[r][s] = zz;
             zz = gend[r][s] + row_matvec(mg, zz);
@@ -363,7 +442,7 @@ __global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* 
     z = gstart[row][s];
     for (int q = q0; q < q1; ++q) {
         ci[(size_t)q * kStates] = z;
-        z = ce[(size_t)q * kStates] + row_matvec(m, z);
+        z = end_state(q) + row_matvec(m, z);
     }
 }
 
@@ -531,7 +610,7 @@ extern "C" void frt_octbank_destroy(frt_octbank* h) {
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     frt_ola_destroy(h);
-    DeviceBuffer* bufs[] = {&h->coef, &h->order, &h->state, &h->xin, &h->ypacked, &h->chunk_end, &h->chunk_init, &h->power,
+    DeviceBuffer* bufs[] = {&h->coef, &h->order, &h->state, &h->xin, &h->ypacked, &h->chunk_end, &h->chunk_init, &h->power, &h->zs_table, &h->zs_rowmap,
                             &h->eblock, &h->alpha, &h->decay_n, &h->smooth, &h->weight, &h->eout};
     for (auto* b : bufs) b->release();
     for (auto& b : h->xbuf) b.release();
@@ -546,6 +625,9 @@ extern "C" int frt_octbank_set_stream(frt_octbank* h, void* s) {
 
 extern "C" int frt_octbank_set_chunk(frt_octbank* h, int chunk0) {
     FRT_REQUIRE(h, "frt_octbank_set_chunk: null handle");
+    // A/B and tests: a negative value selects the same chunking with pass 1 run as a second recurrence
+    h->zero_state_by_recurrence = chunk0 < 0;
+    if (chunk0 < 0) chunk0 = -chunk0;
     FRT_REQUIRE(chunk0 == 0 || (chunk0 >= 1024 && chunk0 % 64 == 0),
                 "frt_octbank_set_chunk: chunk %d must be 0 (sequential) or a multiple of 64, at least 1024", chunk0);
     h->chunk0 = chunk0;
@@ -632,6 +714,39 @@ static int ensure_powers(frt_octbank* h, int n) {
     }
     int rc = upload(h->power, p);
     if (rc) return rc;
+    // zero-state response tables g[k][row] = (A^(L-1-k) B)[s], rows = the live states of every filter
+    std::vector<int> rowmap;
+    for (int f = 0; f < h->nfilt; ++f)
+        for (int t = 0; t < h->h_order[f]; ++t) rowmap.push_back(f * kStates + t);
+    h->zs_rows = (int)rowmap.size();
+    h->zs_rows_padded = (h->zs_rows + kZsRows - 1) / kZsRows * kZsRows;
+    rowmap.resize(h->zs_rows_padded, -1);
+    h->zs_offset.assign(kNOctave, 0);
+    size_t total = 0;
+    for (int j = 0; j < kNOctave; ++j) {
+        h->zs_offset[j] = total;
+        total += (size_t)stage_chunk(h->chunk0, j) * h->zs_rows_padded;
+    }
+    std::vector<double> tab(total, 0.0);
+    for (int j = 0; j < kNOctave; ++j) {
+        const int L = stage_chunk(h->chunk0, j);
+        int row = 0;
+        for (int f = 0; f < h->nfilt; ++f) {
+            const int ord = h->h_order[f];
+            const double* bc = &h->h_coef[(size_t)f * kCoefStride];
+            const double* ac = bc + kMaxOrder + 1;
+            std::vector<long double> v(ord), w(ord);
+            for (int t = 0; t < ord; ++t) v[t] = (long double)bc[t + 1] - (long double)ac[t + 1] * (long double)bc[0];
+            for (int k = L - 1; k >= 0; --k) {
+                for (int t = 0; t < ord; ++t) tab[h->zs_offset[j] + (size_t)k * h->zs_rows_padded + row + t] = (double)v[t];
+                // v <- A v:  (A v)[t] = v[t+1] - a[t+1] v[0]
+                for (int t = 0; t < ord; ++t) w[t] = (t + 1 < ord ? v[t + 1] : 0.0L) - (long double)ac[t + 1] * v[0];
+                v.swap(w);
+            }
+            row += ord;
+        }
+    }
+    if ((rc = upload(h->zs_table, tab)) || (rc = upload(h->zs_rowmap, rowmap))) return rc;
     h->power_chunk0 = h->chunk0;
     h->power_n = n;
     return FRT_OK;
@@ -654,7 +769,7 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
         int rc = ensure_powers(h, n);
         if (rc) return rc;
         const size_t ws = (size_t)h->n_channels * h->nfilt * nchunks * kStates * sizeof(double);
-        if ((rc = h->chunk_end.reserve(ws)) || (rc = h->chunk_init.reserve(ws))) return rc;
+        if ((rc = h->chunk_end.reserve(ws * kMaxSlices)) || (rc = h->chunk_init.reserve(ws))) return rc;
     }
     for (int j = 1; j < kNOctave; ++j) {
         int rc = h->xbuf[j].reserve((size_t)h->n_channels * len[j] * sizeof(double));
@@ -705,12 +820,34 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
             a.pass = 0;
             if ((rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream))) return rc;
         } else {
-            a.pass = 1;
-            if ((rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream))) return rc;
+            int n_slices = 1;
+            const long long slice_stride = (long long)h->n_channels * h->nfilt * a.nchunks * kStates;
+            if (h->zero_state_by_recurrence) {
+                a.pass = 1;
+                if ((rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream))) return rc;
+            } else {
+                // K-slices: enough wavefronts to fill the chip when the columns alone do not
+                const long long colwaves = ((long long)h->n_channels * a.nchunks + 63) / 64;
+                while (n_slices < kMaxSlices && colwaves * n_slices < 2048 && a.chunk / (2 * n_slices) >= 8) n_slices *= 2;
+                ZeroStateArgs z{};
+                z.x = a.x; z.x_stride = a.x_stride; z.n = a.n; z.in_f32 = a.in_f32;
+                z.chunk = a.chunk; z.nchunks = a.nchunks; z.n_channels = h->n_channels; z.nfilt = h->nfilt;
+                z.slice = a.chunk / n_slices;
+                z.table = h->zs_table.as<double>() + h->zs_offset[j];
+                z.rows = h->zs_rows; z.rows_padded = h->zs_rows_padded;
+                z.rowmap = h->zs_rowmap.as<int>();
+                z.partial = h->chunk_end.as<double>();
+                z.partial_stride = slice_stride;
+                hipLaunchKernelGGL(iir_zero_state_kernel, dim3((unsigned)colwaves, n_slices, h->zs_rows_padded / kZsRows), dim3(64), 0,
+                                   h->stream, z);
+                if (n_slices > 1)
+                    hipLaunchKernelGGL(iir_slice_sum_kernel, dim3((unsigned)((slice_stride + 255) / 256)), dim3(256), 0, h->stream,
+                                       h->chunk_end.as<double>(), slice_stride, n_slices, slice_stride);
+            }
             const size_t per = (size_t)kNOctave * h->nfilt * kStates * kStates, off = (size_t)j * h->nfilt * kStates * kStates;
             hipLaunchKernelGGL(iir_scan_kernel, dim3(h->n_channels * h->nfilt), dim3(kScanRows * 16), 0, h->stream,
                                h->power.as<double>() + off, h->power.as<double>() + per + off, a.state, h->chunk_end.as<double>(),
-                               h->chunk_init.as<double>(), h->nfilt, a.nchunks, scan_group(a.nchunks));
+                               h->order.as<int>(), h->chunk_init.as<double>(), h->nfilt, a.nchunks, scan_group(a.nchunks));
             a.pass = 2;
             if ((rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream))) return rc;
         }

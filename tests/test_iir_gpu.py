@@ -99,7 +99,7 @@ def test_iir_bank_ragged_blocks_and_channels(tabs):
         bank.filter(np.zeros((3, 0)))
 
 
-@pytest.mark.parametrize("chunk", [16384, 4096, 1024, 3072])
+@pytest.mark.parametrize("chunk", [16384, 4096, 1024, 3072, -2048])
 def test_time_parallel_mode_matches_sequential(tabs, chunk):
     from friture_amd.filter import IirBank
     bpo = 3
@@ -124,7 +124,7 @@ def test_time_parallel_mode_matches_sequential(tabs, chunk):
     assert np.max(np.abs(par.get_state() - seq.get_state())) < 1e-9 * np.max(np.abs(seq.get_state()))
 
 
-@pytest.mark.parametrize("bpo,chunk", [(3, 0), (3, 16384), (3, 2048), (3, 1024), (24, 16384), (24, 4096)])
+@pytest.mark.parametrize("bpo,chunk", [(3, 0), (3, 16384), (3, 2048), (3, 1024), (3, -2048), (24, 16384), (24, 4096)])
 def test_band_energies(tabs, bpo, chunk):
     """frt_octbank_energies against the oracle's widget restatement: filter, y^2, exp smoothing."""
     from friture_amd.filter import IirBank
