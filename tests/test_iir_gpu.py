@@ -152,3 +152,47 @@ def test_band_energies(tabs, bpo, chunk):
     bank.reset()
     db = bank.energies(x32, 1024, alphas, weight_db=A, as_db=True)
     assert np.max(np.abs(db - (10 * np.log10(got.astype(np.float64) + 1e-30) + A))) < 1e-3
+
+
+def test_full_size_bank_properties(tabs):
+    """BASELINE configs[2] size (8 ch x 2^22 samples, 1/3 octave, device resident) through size-independent
+    properties: exact linearity in amplitude, streaming == batch (state and smoothed energies carried
+    across calls), chunking invariance, and agreement of the first blocks with the oracle."""
+    import torch
+    from friture_amd.filter import IirBank
+    bpo, C, n = 3, 8, 1 << 22
+    boct, aoct = list(tabs[f"boct_{bpo}"]), list(tabs[f"aoct_{bpo}"])
+    alphas, kernels = dsp.band_smoothing_setup(bpo, 1.0)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    x = 0.25 * torch.randn((C, n), generator=gen, device="cuda", dtype=torch.float32)
+
+    def bank(chunk):
+        b = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, C)
+        b.set_chunk(chunk)
+        return b
+
+    e = bank(2048).energies(x, 1024, alphas)
+    torch.cuda.synchronize()
+    assert e.shape == (C, n // 1024, 27) and bool(torch.isfinite(e).all()) and bool((e > 0).all())
+    # every operation of the chain is linear or quadratic in the input and 2 is a power of two: exact
+    e2 = bank(2048).energies(2.0 * x, 1024, alphas)
+    assert torch.equal(e2, 4.0 * e)
+    # two calls of half the length == one call (filter states and smoothed energies live in the handle)
+    b = bank(2048)
+    h1 = b.energies(x[:, :n // 2].contiguous(), 1024, alphas)
+    h2 = b.energies(x[:, n // 2:].contiguous(), 1024, alphas)
+    halves = torch.cat([h1, h2], dim=1)
+    assert float(((halves - e).abs() / e).max()) < 1e-5
+    # another chunking of the time axis, and the recurrence form of the zero-state pass
+    for chunk in (16384, -4096):
+        other = bank(chunk).energies(x, 1024, alphas)
+        assert float(((other - e).abs() / e).max()) < 1e-5, chunk
+    # the first 32 blocks of two channels against the oracle (sequential recurrence from zero state)
+    for c in (0, C - 1):
+        xs = x[c, :32 * 1024].cpu().numpy().astype(np.float64)
+        zs = dsp.iir_bank_filtic(tabs["bdec"], tabs["adec"], boct, aoct)
+        prev = [0.0] * 27
+        for blk in range(32):
+            y, _, zs = dsp.iir_bank(tabs["bdec"], tabs["adec"], boct, aoct, xs[blk * 1024:(blk + 1) * 1024], zs)
+            prev = dsp.band_energies(y, kernels, alphas, prev)
+            assert np.max(np.abs(e[c, blk].cpu().numpy() / np.array(prev) - 1)) <= 1e-5, (c, blk)

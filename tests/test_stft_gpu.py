@@ -217,3 +217,30 @@ def test_device_resident_full_size_properties(engine_cls):
     # linearity: PSD(2x) = 4 PSD(x) exactly in binary floating point
     psd2 = e.psd(2.0 * x)
     assert torch.equal(psd2, 4.0 * psd)
+
+
+def test_large_frame_shard_full_size_properties(engine_cls):
+    """BASELINE configs[3], one GPU's shard (32 of 256 ch, T = 2^20, N = 16384, hop 8192): Parseval per frame,
+    sampled frames against the oracle, exact linearity in amplitude."""
+    import torch
+    C, T, N, hop = 32, 1 << 20, 16384, 8192
+    gen = torch.Generator(device="cuda").manual_seed(43)
+    x = 0.25 * torch.randn((C, T), generator=gen, device="cuda", dtype=torch.float32)
+    e = engine_cls(N, hop, C, 32)
+    psd = e.psd(x)
+    torch.cuda.synchronize()
+    F = e.frames_for(T)
+    assert psd.shape == (C, F, N // 2 + 1) and F == 127
+    w = torch.tensor(dsp.hann_symmetric(N), device="cuda")
+    for c in (0, 17, 31):
+        frames = x[c].unfold(0, N, hop).double() * w
+        lhs = (frames ** 2).sum(dim=1)
+        p = psd[c].double()
+        rhs = (p[:, 0] + 2 * p[:, 1:N // 2].sum(dim=1) + p[:, N // 2]) * N
+        assert float(((lhs - rhs).abs() / lhs).max()) < 1e-5
+    rng = np.random.default_rng(1)
+    win = dsp.hann_symmetric(N)
+    for c, f in zip(rng.integers(0, C, 12), rng.integers(0, F, 12)):
+        xs = x[c, f * hop:f * hop + N].cpu().numpy().astype(np.float64)
+        assert rel_max(psd[c, f].cpu().numpy(), dsp.psd_frame(xs, win)) <= TOL32
+    assert torch.equal(e.psd(2.0 * x), 4.0 * psd)

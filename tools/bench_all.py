@@ -116,7 +116,7 @@ def main():
                         unit="octave-bands/s", gpu=9 * bpo / dt, ms=dt * 1e3, cpu_oracle=cpu, parity_rel_max=err))
 
     # ---- K5 GCC-PHAT --------------------------------------------------------------------------------------
-    for L, pairs in [(24000, 100), (24000, 1)]:
+    for L, pairs in [(24000, 100), (24000, 1024), (24000, 1)]:
         d0 = 0.25 * rng.standard_normal((pairs, L))
         d1 = np.roll(d0, 37, axis=1) + 0.025 * rng.standard_normal((pairs, L))
         g = GccPhat(L, pairs)
