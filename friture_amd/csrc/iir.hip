@@ -458,6 +458,7 @@ __global__ void __launch_bounds__(kEnergyThreads) energy_scan_kernel(const doubl
                                                                      void* __restrict__ out, int out_f32, int nblocks, int nbands,
                                                                      const double* __restrict__ weight_db, int as_db) {
     __shared__ double tile[kEnergyThreads * kEnergyPerThread];
+    __shared__ double seg_end[kEnergyThreads], seg_pow[kEnergyThreads], seg_carry[kEnergyThreads];
     const int c = blockIdx.x, tid = threadIdx.x;
     const int tile_blocks = kEnergyThreads * kEnergyPerThread / nbands;      // whole blocks per tile (nbands <= 256)
     const int tile_vals = tile_blocks * nbands;
@@ -482,11 +483,41 @@ __global__ void __launch_bounds__(kEnergyThreads) energy_scan_kernel(const doubl
         for (int j = 0; j < kEnergyPerThread; ++j) tile[tid + j * kEnergyThreads] = pre[j];
         __syncthreads();
         if (b0 + tile_blocks < nblocks) fetch(b0 + tile_blocks);
+        // The recurrence over the tile's blocks, split into `nseg` runs of consecutive blocks per band so that
+        // nseg * nbands threads work: each run from a zero carry, the runs chained, then the carry folded in
+        // (sp_b = local_b + carry d^(b - run start + 1)).
+        const int nseg = kEnergyThreads / nbands > 8 ? 8 : (kEnergyThreads / nbands < 1 ? 1 : kEnergyThreads / nbands);
+        const int seg_len = (nb + nseg - 1) / nseg;
+        const int seg = tid / nbands, band = tid - seg * nbands;
+        const bool worker = seg < nseg;
+        const double dk = worker ? decay_n[band] : 0.0;
+        const int sb0 = seg * seg_len, sb1 = (sb0 + seg_len) < nb ? (sb0 + seg_len) : nb;
+        double local = 0.0, dpow = 1.0;
+        if (worker) {
+            for (int b = sb0; b < sb1; ++b) {
+                local = tile[b * nbands + band] + local * dk;
+                tile[b * nbands + band] = local;
+                dpow *= dk;
+            }
+            seg_end[seg * nbands + band] = local;
+            seg_pow[seg * nbands + band] = dpow;
+        }
+        __syncthreads();
         if (tid < nbands) {
-            for (int b = 0; b < nb; ++b) {
-                const double sp = tile[b * nbands + tid] + prev * d;
-                prev = sp;
-                tile[b * nbands + tid] = sp;
+            double carry = prev;
+            for (int g = 0; g < nseg; ++g) {
+                seg_carry[g * nbands + tid] = carry;
+                carry = seg_end[g * nbands + tid] + carry * seg_pow[g * nbands + tid];
+            }
+            prev = carry;
+        }
+        __syncthreads();
+        if (worker) {
+            const double carry = seg_carry[seg * nbands + band];
+            double p = dk;
+            for (int b = sb0; b < sb1; ++b) {
+                tile[b * nbands + band] += carry * p;
+                p *= dk;
             }
         }
         __syncthreads();
