@@ -1,13 +1,16 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-B=$R/tools/bin/stft_selftest
-export FRT_BENCH_SETS=4
-$B check | grep -E "pix_bad=[1-9]|FAIL|SELFTEST" | head -5
-echo -n "fast img: "; $B bench 1024 512 1 26 3 0 50 | tail -1
-echo -n "fast img: "; $B bench 1024 512 1 26 3 0 50 | tail -1
-echo -n "     psd: "; $B bench 1024 512 1 26 0 0 50 | tail -1
-export FRT_IMAGE_EXACT_EPS=1
-echo -n "eps  img: "; $B bench 1024 512 1 26 3 0 50 | tail -1
-echo -n "eps  img: "; $B bench 1024 512 1 26 3 0 50 | tail -1
-unset FRT_IMAGE_EXACT_EPS
-cd $R && timeout 600 python -m pytest tests/test_stft_gpu.py tests/test_widgets_gpu.py -x -q 2>&1 | tail -3
+cat > /tmp/pb.py <<PY
+import sys, time; sys.path.insert(0,"$R")
+import numpy as np, torch
+from friture_amd.pitch_tracker import PitchEngine
+x=torch.from_numpy(0.2*np.random.default_rng(0).standard_normal((8,1<<22))).cuda()
+for lim in (1<<30, 470<<20, 320<<20, 240<<20, 160<<20):
+    e=PitchEngine(4096,1024,8); e.set_scratch_limit(lim)
+    for _ in range(2): e.track(x)
+    torch.cuda.synchronize(); t0=time.perf_counter()
+    for _ in range(5): e.track(x)
+    torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/5
+    print(lim>>20, "MB: %.3f ms"%(dt*1e3), "%.3e frames/s"%(8*e.frames_for(1<<22)/dt))
+PY
+python /tmp/pb.py
