@@ -603,12 +603,16 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     if (h->precision == 32 && h->log2m >= 10 && a.vec2 && !h->force_generic) {
         int brun = h->run_length;
         if (brun <= 0) {
-            // measured (tools/stft_selftest bench, run sweep): N = 16384 runs one workgroup per CU and gains
-            // from long runs (one-off twiddle/LUT loads amortised, 16 -> exactly one round of workgroups at
-            // 4096 frames); the smaller sizes prefer fine-grained groups (tail balance), 2 frames each
-            brun = 2;
-            if (h->log2m >= 13) {
-                const long long total = (long long)F * h->n_channels;
+            // every thread keeps its window, twiddle and weight factors in registers for the whole run, so runs
+            // should be long — as long as the groups still fill the chip several times over.  Measured (run sweep
+            // with tools/stft_selftest bench): 8-16 frames per group is the plateau for every size.
+            const long long total = (long long)F * h->n_channels;
+            const int gpb_big = (M / 16) < 256 ? 256 / (M / 16) : 1;
+            const long long want = (long long)device_cu_count() * 8 * gpb_big;
+            brun = (int)(total / want);
+            if (brun < 2) brun = 2;
+            if (brun > 8) brun = 8;
+            if (h->log2m >= 13) {          // one workgroup per CU: a single round of workgroups beats short runs
                 brun = (int)((total + device_cu_count() - 1) / device_cu_count());
                 if (brun < 4) brun = 4;
                 if (brun > 16) brun = 16;

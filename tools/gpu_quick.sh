@@ -1,16 +1,11 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-cat > /tmp/pb.py <<PY
-import sys, time; sys.path.insert(0,"$R")
-import numpy as np, torch
-from friture_amd.pitch_tracker import PitchEngine
-x=torch.from_numpy(0.2*np.random.default_rng(0).standard_normal((8,1<<22))).cuda()
-for lim in (1<<30, 470<<20, 320<<20, 240<<20, 160<<20):
-    e=PitchEngine(4096,1024,8); e.set_scratch_limit(lim)
-    for _ in range(2): e.track(x)
-    torch.cuda.synchronize(); t0=time.perf_counter()
-    for _ in range(5): e.track(x)
-    torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/5
-    print(lim>>20, "MB: %.3f ms"%(dt*1e3), "%.3e frames/s"%(8*e.frames_for(1<<22)/dt))
-PY
-python /tmp/pb.py
+B=$R/tools/bin/stft_selftest
+export FRT_BENCH_SETS=4
+$B check | tail -1
+for cfg in "16384 8192 32 20" "16384 4096 32 20" "8192 4096 32 21" "4096 1024 16 22" "2048 1024 16 22"; do
+  set -- $cfg
+  echo -n "psd: "; $B bench $1 $2 $3 $4 0 0 10 | tail -1
+  echo -n "img: "; $B bench $1 $2 $3 $4 3 0 10 | tail -1
+done
+cd $R; python -m pytest tests -x -q -m gpu 2>&1 | tail -2
