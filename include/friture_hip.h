@@ -85,7 +85,9 @@ int frt_stft_image(frt_stft* h, const float* x, int64_t T, uint32_t* rgba_out, i
 int frt_stft_analyzelive_f64(frt_stft* h, const double* frame, double* psd_out);
 /* Number of frames frt_stft_run produces for T samples per channel. */
 int64_t frt_stft_frames_for(const frt_stft* h, int64_t T);
-/* Tuning hook (bench / tests): frames a workgroup lane-group processes back to back; 0 = auto. */
+/* Tuning hook (bench / tests): frames a workgroup lane-group processes back to back; 0 = auto.  A negative
+ * value sets the run length to its magnitude and, for fft_size >= 2048, selects the generic workgroup-wide
+ * kernel instead of the radix-16 + wave-local one (A/B runs). */
 int frt_stft_set_run_length(frt_stft* h, int frames_per_run);
 
 /* ---- K2 / K4: octave filter bank with decimation, band energies -------------------------------
@@ -114,7 +116,9 @@ int frt_octbank_set_stream(frt_octbank* h, void* hip_stream);
 int frt_octbank_reset(frt_octbank* h);
 /* 0 (default): sequential in time, bit-identical to the reference.  chunk0 > 0 (multiple of 64, >= 1024;
  * a multiple of the energy block for frt_octbank_energies): batches of at least 2*chunk0 samples are
- * processed time-parallel, octave stage j in chunks of max(64, chunk0 / 2^j) of its own samples. */
+ * processed time-parallel, octave stage j in chunks of max(64, chunk0 / 2^j) of its own samples.  The two modes
+ * agree to ~1e-10 of the input scale (same recurrences, other association order).  A negative value selects
+ * the same chunking with the zero-state pass run as a second recurrence instead of a table product (A/B runs). */
 int frt_octbank_set_chunk(frt_octbank* h, int chunk0);
 /* doubles per channel in the packed output for n input samples: sum over bands of ceil(n / dec) */
 int64_t frt_octbank_packed_length(const frt_octbank* h, int n);
