@@ -116,3 +116,31 @@ def test_delay_estimator_chain_against_oracle(hip):
     assert ref is not None and abs(est.delay_ms - ref["delay_ms"]) < 1e-9 and abs(est.delay_ms - 1.75) < 1e-9
     assert est.correlation == ref["correlation_pct"] and abs(est.Xcorr_extremum - ref["extremum"]) < 1e-9
     assert np.max(np.abs(est.old_Xcorr - ref["smoothed"])) < 1e-9
+
+
+def test_configs4_full_size_properties(hip):
+    """BASELINE configs[4], the delay-estimator half: 100 windows of L = 24000 at 50 % overlap of one 2-channel
+    recording whose second channel is the first delayed by 37 samples, device resident.
+    Properties: every window finds the true delay, swapping the channels negates it (circularly), scaling both
+    channels leaves the PHAT-weighted correlation unchanged to rounding, sampled windows equal the oracle."""
+    import torch
+    from friture_amd.signal.correlation import GccPhat
+    L, windows, lag = 24000, 100, 37
+    n = L // 2 * (windows + 1)
+    rng = np.random.default_rng(123)
+    ch0 = 0.25 * rng.standard_normal(n)
+    ch1 = np.roll(ch0, lag) + 0.025 * rng.standard_normal(n)
+    d0 = np.stack([ch0[w * L // 2:w * L // 2 + L] for w in range(windows)])
+    d1 = np.stack([ch1[w * L // 2:w * L // 2 + L] for w in range(windows)])
+    g = GccPhat(L, windows)
+    a0, a1 = torch.from_numpy(d0).cuda(), torch.from_numpy(d1).cuda()
+    x01, am01 = g.correlate(a0, a1)
+    x10, am10 = g.correlate(a1, a0)
+    xs, _ = g.correlate(4.0 * a0, 4.0 * a1)
+    torch.cuda.synchronize()
+    assert bool((am01 == lag).all()) and bool((am10 == L - lag).all())
+    x01n = x01.cpu().numpy()
+    assert np.max(np.abs(xs.cpu().numpy() - x01n)) <= 1e-12 * np.max(np.abs(x01n))
+    for w in (0, 41, 99):
+        ref, _, _ = dsp.gcc_phat(d0[w].copy(), d1[w].copy())
+        assert np.max(np.abs(x01n[w] - ref)) <= 1e-9 * np.max(np.abs(ref))

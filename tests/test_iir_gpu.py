@@ -196,3 +196,34 @@ def test_full_size_bank_properties(tabs):
             y, _, zs = dsp.iir_bank(tabs["bdec"], tabs["adec"], boct, aoct, xs[blk * 1024:(blk + 1) * 1024], zs)
             prev = dsp.band_energies(y, kernels, alphas, prev)
             assert np.max(np.abs(e[c, blk].cpu().numpy() / np.array(prev) - 1)) <= 1e-5, (c, blk)
+
+
+def test_configs4_bank_full_size_properties(tabs):
+    """BASELINE configs[4], the filter-bank half on one GPU's shard scale: 64 ch x 2^20 samples, 1/24 octave
+    (216 bands), device resident: exact linearity, chunking invariance, first blocks of two channels vs the oracle."""
+    import torch
+    from friture_amd.filter import IirBank
+    bpo, C, n = 24, 64, 1 << 20
+    boct, aoct = list(tabs[f"boct_{bpo}"]), list(tabs[f"aoct_{bpo}"])
+    alphas, kernels = dsp.band_smoothing_setup(bpo, 1.0)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = 0.25 * torch.randn((C, n), generator=gen, device="cuda", dtype=torch.float32)
+
+    def run(chunk, scale=1.0):
+        b = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, C)
+        b.set_chunk(chunk)
+        return b.energies(scale * x, 1024, alphas)
+
+    e = run(4096)
+    torch.cuda.synchronize()
+    assert e.shape == (C, n // 1024, 216) and bool(torch.isfinite(e).all()) and bool((e > 0).all())
+    assert torch.equal(run(4096, 2.0), 4.0 * e)
+    assert float(((run(16384) - e).abs() / e).max()) < 1e-5
+    for c in (0, C - 1):
+        xs = x[c, :8 * 1024].cpu().numpy().astype(np.float64)
+        zs = dsp.iir_bank_filtic(tabs["bdec"], tabs["adec"], boct, aoct)
+        prev = [0.0] * 216
+        for blk in range(8):
+            y, _, zs = dsp.iir_bank(tabs["bdec"], tabs["adec"], boct, aoct, xs[blk * 1024:(blk + 1) * 1024], zs)
+            prev = dsp.band_energies(y, kernels, alphas, prev)
+            assert np.max(np.abs(e[c, blk].cpu().numpy() / np.array(prev) - 1)) <= 1e-5, (c, blk)
