@@ -452,6 +452,7 @@ __global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* 
 // loads already in flight), `nbands` threads run the recurrence over it in LDS, all threads convert and write.
 constexpr int kEnergyThreads = 256;
 constexpr int kEnergyPerThread = 8;                                   // tile = 2048 values
+static_assert((kMaxFilters - 1) * kNOctave <= kEnergyThreads, "one recurrence thread per band");
 
 __global__ void __launch_bounds__(kEnergyThreads) energy_scan_kernel(const double* __restrict__ eblock,
                                                                      const double* __restrict__ decay_n, double* __restrict__ smooth,
@@ -465,8 +466,6 @@ __global__ void __launch_bounds__(kEnergyThreads) energy_scan_kernel(const doubl
     const double* src = eblock + (size_t)c * nblocks * nbands;
     const size_t obase = (size_t)c * nblocks * nbands;
     double prev = tid < nbands ? smooth[(size_t)c * nbands + tid] : 0.0;
-    const double d = tid < nbands ? decay_n[tid] : 0.0;
-
     double pre[kEnergyPerThread];
     auto fetch = [&](int b0) {
         const long long left = (long long)(nblocks - b0) * nbands;
@@ -1026,7 +1025,6 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
         d_out = h->eout.as<float>();
     }
     if ((rc = run_stages(h, d_x, 1, n, (int)n, nullptr, 0, h->eblock.as<double>(), block, nblocks))) return rc;
-    const int total = h->n_channels * h->nbands;
     hipLaunchKernelGGL(energy_scan_kernel, dim3(h->n_channels), dim3(kEnergyThreads), 0, h->stream, h->eblock.as<double>(),
                        h->decay_n.as<double>(), h->smooth.as<double>(), (void*)d_out, 1, nblocks, h->nbands,
                        weight_db ? h->weight.as<double>() : nullptr, as_db);

@@ -86,7 +86,7 @@ __launch_bounds__((Pow2Plan<LOG2M>::TPF < 256 ? 256 : Pow2Plan<LOG2M>::TPF))
 #endif
 stft_kernel(const StftArgs a) {
     using P = Pow2Plan<LOG2M>;
-    constexpr int M = P::M, N = 2 * M, TPF = P::TPF;
+    constexpr int M = P::M, TPF = P::TPF;            // M = N/2 complex points
     constexpr int BLOCK = TPF < 256 ? 256 : TPF;
     constexpr int GPB = BLOCK / TPF;                 // lane groups (concurrent frames) per block
     constexpr bool WAVE = TPF <= 64;                 // a frame lives inside one wavefront
