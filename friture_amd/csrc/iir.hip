@@ -324,7 +324,8 @@ struct ZeroStateArgs {
     long long x_stride;
     int n, in_f32;
     int chunk, nchunks, n_channels, nfilt;
-    int slice;                 // samples per K-slice (multiple of 4)
+    int slice;                 // samples per K-slice (multiple of 8)
+    int vec;                   // rows 16-byte aligned: vector loads allowed
     const double* table;       // [chunk][rows_padded]: g[k][r]
     int rows, rows_padded;
     const int* rowmap;         // [rows_padded]: f * kStates + s of each row, -1 for padding
@@ -347,16 +348,36 @@ __global__ void __launch_bounds__(64) iir_zero_state_kernel(const ZeroStateArgs 
     double acc[kZsRows];
 #pragma unroll
     for (int r = 0; r < kZsRows; ++r) acc[r] = 0.0;
-    // eight samples of the lane's own stream per batch (one 64-byte line), their loads in flight together
+    // eight samples of the lane's own stream per batch (one 64-byte line), their loads in flight together;
+    // 16-byte loads when the rows are aligned (a.vec) — a quarter / half of the load instructions, each of
+    // which touches 64 different cache lines
     for (int k = 0; k < a.slice; k += 8) {
         double xv[8];
+        const long long i0 = first + k;
+        if (a.vec && valid && i0 + 8 <= a.n) {
+            if (a.in_f32) {
+                const float4* p = (const float4*)((const float*)a.x + xrow + i0);
+                const float4 lo = p[0], hi = p[1];
+                xv[0] = lo.x; xv[1] = lo.y; xv[2] = lo.z; xv[3] = lo.w;
+                xv[4] = hi.x; xv[5] = hi.y; xv[6] = hi.z; xv[7] = hi.w;
+            } else {
+                const double2* p = (const double2*)((const double*)a.x + xrow + i0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const long long i = first + k + u;
-            const bool ok = valid && i < a.n;
-            const long long ii = ok ? xrow + i : 0;
-            const double v = a.in_f32 ? (double)((const float*)a.x)[ii] : ((const double*)a.x)[ii];
-            xv[u] = ok ? v : 0.0;
+                for (int u = 0; u < 4; ++u) {
+                    const double2 v = p[u];
+                    xv[2 * u] = v.x;
+                    xv[2 * u + 1] = v.y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long i = i0 + u;
+                const bool ok = valid && i < a.n;
+                const long long ii = ok ? xrow + i : 0;
+                const double v = a.in_f32 ? (double)((const float*)a.x)[ii] : ((const double*)a.x)[ii];
+                xv[u] = ok ? v : 0.0;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -863,6 +884,7 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
                 z.x = a.x; z.x_stride = a.x_stride; z.n = a.n; z.in_f32 = a.in_f32;
                 z.chunk = a.chunk; z.nchunks = a.nchunks; z.n_channels = h->n_channels; z.nfilt = h->nfilt;
                 z.slice = a.chunk / n_slices;
+                z.vec = ((uintptr_t)a.x % 16 == 0) && (a.x_stride % (a.in_f32 ? 4 : 2) == 0);
                 z.table = h->zs_table.as<double>() + h->zs_offset[j];
                 z.rows = h->zs_rows; z.rows_padded = h->zs_rows_padded;
                 z.rowmap = h->zs_rowmap.as<int>();
