@@ -64,8 +64,8 @@ __device__ __forceinline__ double grid_value(const PitchArgs& a, const double* P
 
 // One workgroup per group of 8 frames; lane = 8 * (grid point mod 8) + frame, so that a store instruction
 // covers 8 grid points x 8 frames = 512 contiguous bytes of the [group][grid][8] layout; the four wavefronts
-// split the grid.  Two passes over the power spectra (the second one cache-served): the RMS of a frame's grid
-// spectrum, then the normalised values — 256 bytes of LDS, one barrier, occupancy bounded by registers only.
+// split the grid.  Pass 1 writes the unnormalised grid spectrum and sums its squares, pass 2 divides the lane's own
+// values by the frame's RMS — 256 bytes of LDS, one barrier, occupancy bounded by registers only.
 __global__ void __launch_bounds__(256) pitch_loggrid_kernel(const PitchArgs a) {
     __shared__ double part[4][kFramesPerGroup];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -77,23 +77,25 @@ __global__ void __launch_bounds__(256) pitch_loggrid_kernel(const PitchArgs a) {
     const bool live = gf < total;
     const double* P = a.psd + (live ? gf : 0) * a.nb;
     const int lq = a.Lp / 4, l0 = wave * lq, l1 = l0 + lq;      // Lp is a multiple of 32
+    // pass 1: the unnormalised grid spectrum goes to its final place, the squares are summed
     double ss = 0.0;
-    if (live)
-        for (int l = l0 + li; l < l1 && l < a.L; l += 8) {
-            const double v = grid_value(a, P, l);
+    for (int l = l0 + li; l < l1; l += 8) {
+        double v = 0.0;
+        if (live && l < a.L) {
+            v = grid_value(a, P, l);
             ss += v * v;
         }
+        out[l * kFramesPerGroup + q] = v;
+    }
     // the eight lanes of a frame hold interleaved partial sums; fixed-order butterfly over lane bits 3..5
     for (int o = 8; o < 64; o <<= 1) ss += __shfl_xor(ss, o, 64);
     if (li == 0) part[wave][q] = ss;
     __syncthreads();
     ss = (part[0][q] + part[1][q]) + (part[2][q] + part[3][q]);
     const double rms = sqrt(ss / (double)a.L);                      // :379
-    for (int l = l0 + li; l < l1; l += 8) {
-        double v = 0.0;
-        if (live && l < a.L) v = grid_value(a, P, l) / rms;         // :380 (0/0 = nan for silence, as upstream)
-        out[l * kFramesPerGroup + q] = v;
-    }
+    // pass 2: every lane divides the values it wrote itself (:380; 0/0 = nan for silence, as upstream)
+    if (live)
+        for (int l = l0 + li; l < l1 && l < a.L; l += 8) out[l * kFramesPerGroup + q] = out[l * kFramesPerGroup + q] / rms;
 }
 
 // frame level: 20 log10(sqrt(mean(frame^2)) + eps)   (:399-400).  One wavefront per frame.

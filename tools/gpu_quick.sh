@@ -1,12 +1,8 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT
-B=$R/tools/bin/stft_selftest
-export FRT_BENCH_SETS=4
-for v in base pf2; do
-  [ $v = pf2 ] && export LD_LIBRARY_PATH=$R/friture_amd/lib/variants/pf2
-  $B check | tail -1
-  echo -n "$v psd: "; $B bench 1024 512 1 26 0 0 50 | tail -1
-  echo -n "$v img: "; $B bench 1024 512 1 26 3 0 50 | tail -1
-  echo -n "$v psd hop256: "; $B bench 1024 256 1 26 0 0 30 | tail -1
-  echo -n "$v img N512: "; $B bench 512 256 1 26 3 0 30 | tail -1
-done
+cd $GRAFT_REPO_ROOT
+timeout 600 python -m pytest tests/test_pitch_gpu.py -x -q 2>&1 | tail -2
+python tools/bench_all.py 2>/dev/null | grep T1 | cut -c1-330
+python bench.py --steps 50 --warmup 5 --cpu-budget 0 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('value %.3e frac %.3f kernel_ms %.4f'%(d['value'], d['roofline']['frac'], d['roofline']['kernel_ms']), d.get('psd_output'), d.get('same_batch',{}).get('kernel_ms'), '%.3e'%d['octave_bands']['value'])"
