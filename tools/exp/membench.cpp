@@ -100,14 +100,14 @@ int main(int argc, char** argv) {
                 default: hipLaunchKernelGGL(copy_kernel, dim3(256 * 8), dim3(256), 0, 0, (const float4*)x, (float4*)out, (long long)nframes * 128); break;
             }
         };
-        for (int i = 0; i < 5; ++i) launch();
+        for (int i = 0; i < (mode == 0 ? 3000 : 300); ++i) launch();      // clock ramp: reach the sustained clocks before timing
         HK(hipEventRecord(e0, 0));
-        for (int i = 0; i < 50; ++i) launch();
+        for (int i = 0; i < 200; ++i) launch();
         HK(hipEventRecord(e1, 0));
         HK(hipEventSynchronize(e1));
         float ms;
         HK(hipEventElapsedTime(&ms, e0, e1));
-        const double per = ms / 50 * 1e-3, bytes = (double)nframes * 4100;
+        const double per = ms / 200 * 1e-3, bytes = (double)nframes * 4100;
         printf("mode %d run %d sets %d: %.3f ms  %.0f GB/s (%.1f%% of 8 TB/s)\n", mode, run, sets, per * 1e3, bytes / per * 1e-9, bytes / per / 8e10);
     }
     return 0;

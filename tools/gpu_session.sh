@@ -14,6 +14,6 @@ echo "== rocprofv3 kernel stats of the bench command"
 echo "== rocprofv3 PMC passes of the bench command (separate passes, kernel-trace only)"
 for c in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum"; do
   n=$(echo $c | cut -d' ' -f1)
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/prof/pmc_bench/$n -o p --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --cpu-budget 0 > $R/gpurun_out/prof/pmc_$n.log 2>&1 ); echo "pmc $n rc=$?"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/prof/pmc_bench/$n -o p --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --cpu-budget 0 --prewarm-ms 0 > $R/gpurun_out/prof/pmc_$n.log 2>&1 ); echo "pmc $n rc=$?"
 done
 ls gpurun_out/prof/stats | tail -2
