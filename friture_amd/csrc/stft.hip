@@ -64,14 +64,16 @@ __device__ __forceinline__ double log2_t(double v) { return log2(v); }
 template <typename T>
 __device__ __forceinline__ T shfl_t(T v, int lane) { return __shfl(v, lane, 64); }
 
-// Spectra are written once and read by a later stage: non-temporal stores keep the rows from evicting the
-// samples (and the tables) out of L2 / the Infinity Cache.
+// Row stores.  Plain by default.  Non-temporal stores (-DFRT_NT_STORES) keep the rows from evicting the samples
+// out of L2 / the Infinity Cache: a batch that is re-used or was just produced is then read 15 % faster, but a batch
+// read cold from HBM — the benchmark's case — runs 3 % slower and writes 5 % more bytes (the L2 lets go of
+// partially written lines earlier).  Measured at sustained clocks, DESIGN.md §5/§6.
 template <typename T>
 __device__ __forceinline__ void stream_store(T* p, T v) {
-#ifdef FRT_PLAIN_STORES
-    *p = v;
-#else
+#ifdef FRT_NT_STORES
     __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
 #endif
 }
 
