@@ -610,15 +610,12 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
             // with tools/stft_selftest bench): 8-16 frames per group is the plateau for every size.
             const long long total = (long long)F * h->n_channels;
             const int gpb_big = (M / 16) < 256 ? 256 / (M / 16) : 1;
-            const long long want = (long long)device_cu_count() * 8 * gpb_big;
-            brun = (int)(total / want);
-            if (brun < 2) brun = 2;
-            if (brun > 8) brun = 8;
-            if (h->log2m >= 13) {          // one workgroup per CU: a single round of workgroups beats short runs
-                brun = (int)((total + device_cu_count() - 1) / device_cu_count());
-                if (brun < 4) brun = 4;
-                if (brun > 16) brun = 16;
-            }
+            (void)total;
+            brun = h->log2m >= 13 ? 16 : 8;
+            // ... unless that leaves fewer lane groups than one round of workgroups (N = 16384: one workgroup
+            // per CU) or two rounds (smaller sizes)
+            const long long need = (long long)device_cu_count() * (h->log2m >= 13 ? 1 : 2) * gpb_big;
+            while (brun > 1 && ((F + brun - 1) / brun) * h->n_channels < need) brun /= 2;
         }
         if (brun > F) brun = (int)F;
         a.run = brun;
