@@ -10,8 +10,10 @@ A-weighting, normalisation to [-140, 0] dB and the colour look-up — over T = 2
 samples resident in HBM (131 071 spectra per channel per step).  A step is one pass of the hot
 path over one such batch; the steps rotate over --batches distinct batches (default 3, different
 seeds, separate output buffers) so that every step reads its samples from HBM — with a single
-268 MB batch re-processed every step, part of it survives in the 256 MB Infinity Cache between
-steps and the rate reads 10-15 % high (reported separately as `same_batch`).  With N GPUs every rank owns its own channel(s) (weak scaling, no data-path
+268 MB batch re-processed every step, part of it can survive in the 256 MB Infinity Cache between
+steps (it does when the rows are stored non-temporally; reported separately as `same_batch`).
+Before anything is timed the GPU is brought to its sustained clocks with --prewarm-ms of the same
+launches: straight after start-up a 55-launch run sits inside the clock ramp and reads 17 % slow.  With N GPUs every rank owns its own channel(s) (weak scaling, no data-path
 collective); `value` is the whole-job spectra/s: total spectra of all ranks / max-over-ranks time.
 
 One JSON line is printed by rank 0; besides the contract fields it carries
@@ -284,8 +286,9 @@ def main():
                                     "note": "same launches writing the float PSD instead of colour pixels (same byte counts)"}
         if same_batch_ms is not None:
             result["same_batch"] = {"kernel_ms": same_batch_ms, "spectra_per_s": spectra_per_step / (same_batch_ms * 1e-3) / 1.0,
-                                    "note": "the same batch every step: its samples partly survive in the Infinity Cache "
-                                            "between steps (spectra are written with non-temporal stores); not the headline"}
+                                    "note": "the same batch every step (what a naive loop measures); with the default plain row "
+                                            "stores the rows evict the samples and this equals the rotating figure, with the "
+                                            "-DFRT_NT_STORES build the samples partly survive in the Infinity Cache; not the headline"}
         if octave is not None:
             result["octave_bands"] = octave
         if world == 1 and args.cpu_budget > 0:
