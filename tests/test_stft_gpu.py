@@ -244,3 +244,28 @@ def test_large_frame_shard_full_size_properties(engine_cls):
         xs = x[c, f * hop:f * hop + N].cpu().numpy().astype(np.float64)
         assert rel_max(psd[c, f].cpu().numpy(), dsp.psd_frame(xs, win)) <= TOL32
     assert torch.equal(e.psd(2.0 * x), 4.0 * psd)
+
+
+def test_randomised_shapes_against_oracle(engine_cls):
+    """A seeded sweep over frame size, hop (aligned, odd, larger than the frame), channel count, frame count,
+    precision and run length: every kernel instance and dispatch branch against the oracle."""
+    rng = np.random.default_rng(20260924)
+    sizes = [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384]
+    for trial in range(120):
+        n_fft = int(rng.choice(sizes))
+        mode = int(rng.integers(0, 4))
+        hop = {0: n_fft // 2, 1: n_fft // 4, 2: int(rng.integers(1, 2 * n_fft)), 3: 2 * int(rng.integers(1, n_fft))}[mode]
+        C = int(rng.integers(1, 5))
+        frames = int(rng.integers(1, 40 if n_fft <= 2048 else 12))
+        T = n_fft + hop * (frames - 1) + int(rng.integers(0, hop))
+        precision = 32 if rng.random() < 0.75 else 64
+        x = (0.25 * rng.standard_normal((C, T))).astype(np.float32 if precision == 32 else np.float64)
+        e = engine_cls(n_fft, hop, C, precision)
+        run = int(rng.choice([0, 0, 1, 3, 8, -2]))
+        e.set_run_length(run)
+        got = e.psd(x)
+        assert got.shape == (C, frames, n_fft // 2 + 1), (trial, n_fft, hop, C, frames)
+        tol = TOL32 if precision == 32 else TOL64
+        for c in range(C):
+            ref = dsp.stft_psd(x[c].astype(np.float64), n_fft, hop)
+            assert per_frame_err(got[c], ref) <= tol, (trial, n_fft, hop, C, frames, precision, run, c)
