@@ -24,10 +24,10 @@
 namespace frt {
 
 constexpr int kFramesPerGroup = 8;      // frames sharing one scalar load of S
-constexpr int kFramesPerWave = 16;      // frames a wavefront accumulates (two groups)
-constexpr int kFramesPerBlock = 64;     // 4 wavefronts x 16 frames
-constexpr int kCandPerLane = 2;
-constexpr int kCandPerWave = 128;       // 64 lanes x 2 candidates
+constexpr int kFramesPerWave = 8;       // frames a wavefront accumulates (one group)
+constexpr int kFramesPerBlock = 32;     // 4 wavefronts x 8 frames
+constexpr int kCandPerLane = 4;
+constexpr int kCandPerWave = 256;       // 64 lanes x 4 candidates
 
 struct PitchArgs {
     const double* x;          // [C][x_stride]
@@ -116,44 +116,77 @@ __global__ void __launch_bounds__(256) pitch_level_kernel(const PitchArgs a) {
 }
 
 // strengths[frame][cand] = sum_l kt[l][cand] * S[frame][l]    (pitch_tracker.py:383)
-// A lane owns kCandPerLane candidates x kFramesPerWave frames.  Each kernel-matrix element a wavefront loads
-// is used for 16 frames: with 8 the kernel ran at the L1/L2 delivery rate of the matrix (64 B/clk/CU at the
-// FMA-bound rate), not at the FMA rate.
+// A lane owns kCandPerLane candidates x kFramesPerWave frames.  Software pipeline over pairs of grid points: scalar
+// loads return out of order, so ANY use of one needs lgkmcnt(0) — placed by hand right BEFORE the next pair's
+// loads are issued (where only the current pair is outstanding), not where the compiler would put it (before the
+// first use, i.e. after the next pair was requested, draining it as well).  The next pair's 64-byte S rows and
+// matrix elements are then in flight during the 64 FMAs of the current pair.
 __global__ void __launch_bounds__(256) pitch_strength_kernel(const double* __restrict__ kt, const double* __restrict__ s,
                                                              double* __restrict__ strength, int L, int Lp, int Kp,
                                                              long long n_frames) {
-    constexpr int G = kFramesPerWave / kFramesPerGroup;
+    static_assert(kFramesPerWave == kFramesPerGroup && kCandPerLane == 4, "tile: 4 candidates x 8 frames per lane");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const long long group = ((long long)blockIdx.x * 4 + wave) * G;           // first 8-frame group of this wave
+    const long long group = (long long)blockIdx.x * 4 + wave;                 // the 8-frame group of this wave
     const int c0 = blockIdx.y * kCandPerWave + kCandPerLane * lane;
+    if (group * kFramesPerGroup >= n_frames) return;
     const double* __restrict__ sg = s + group * (long long)Lp * kFramesPerGroup;
     const double* __restrict__ kc = kt + c0;
-    double acc[kCandPerLane][kFramesPerWave];
+    double acc[kCandPerLane][kFramesPerGroup];
 #pragma unroll
     for (int i = 0; i < kCandPerLane; ++i)
 #pragma unroll
-        for (int q = 0; q < kFramesPerWave; ++q) acc[i][q] = 0.0;
-    if (group * kFramesPerGroup >= n_frames) return;
-#pragma unroll 2
-    for (int l = 0; l < L; ++l) {
-        const double2 k01 = *(const double2*)(kc + (long long)l * Kp);
-        const double k[kCandPerLane] = {k01.x, k01.y};
-        double sv[kFramesPerWave];
+        for (int q = 0; q < kFramesPerGroup; ++q) acc[i][q] = 0.0;
+
+    struct Pair {                      // two consecutive grid points
+        double2 k[2][2];               // [point][half]: the lane's four candidates
+        double sv[2][kFramesPerGroup];
+    };
+    // No bounds in the loop: the matrix and every group's S rows are zero-padded to Lp (a multiple of 4) rows and
+    // both buffers carry four spare rows, so the last iteration's look-ahead reads valid memory it never uses.
+    auto fetch = [&](int l, Pair& p) {
 #pragma unroll
-        for (int g = 0; g < G; ++g)
+        for (int u = 0; u < 2; ++u) {
+            p.k[u][0] = *(const double2*)(kc + (long long)(l + u) * Kp);
+            p.k[u][1] = *(const double2*)(kc + (long long)(l + u) * Kp + 2);
 #pragma unroll
-            for (int q = 0; q < kFramesPerGroup; ++q)
-                sv[g * kFramesPerGroup + q] = sg[((long long)g * Lp + l) * kFramesPerGroup + q];
+            for (int q = 0; q < kFramesPerGroup; ++q) p.sv[u][q] = sg[(long long)(l + u) * kFramesPerGroup + q];
+        }
+    };
+    auto use = [&](const Pair& p) {
 #pragma unroll
-        for (int i = 0; i < kCandPerLane; ++i)
+        for (int u = 0; u < 2; ++u) {
+            const double k[4] = {p.k[u][0].x, p.k[u][0].y, p.k[u][1].x, p.k[u][1].y};
 #pragma unroll
-            for (int q = 0; q < kFramesPerWave; ++q) acc[i][q] = __builtin_fma(k[i], sv[q], acc[i][q]);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < kFramesPerGroup; ++q) acc[i][q] = __builtin_fma(k[i], p.sv[u][q], acc[i][q]);
+        }
+    };
+    constexpr int kLgkm0 = 0xC07F;     // s_waitcnt lgkmcnt(0), vmcnt / expcnt untouched
+    Pair a, b;
+    fetch(0, a);
+    for (int l = 0; l < Lp; l += 4) {
+        // sched_barrier: keep the machine scheduler from sinking the look-ahead loads down to their first use
+        __builtin_amdgcn_s_waitcnt(kLgkm0);
+        fetch(l + 2, b);
+        __builtin_amdgcn_sched_barrier(0);
+        use(a);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(kLgkm0);
+        fetch(l + 4, a);
+        __builtin_amdgcn_sched_barrier(0);
+        use(b);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int q = 0; q < kFramesPerWave; ++q) {
+    for (int q = 0; q < kFramesPerGroup; ++q) {
         const long long gf = group * kFramesPerGroup + q;
-        if (gf < n_frames) *(double2*)(strength + gf * Kp + c0) = double2{acc[0][q], acc[1][q]};
+        if (gf < n_frames) {
+            double* o = strength + gf * Kp + c0;
+            *(double2*)o = double2{acc[0][q], acc[1][q]};
+            *(double2*)(o + 2) = double2{acc[2][q], acc[3][q]};
+        }
     }
 }
 
@@ -363,7 +396,7 @@ extern "C" int frt_pitch_create(frt_pitch** out, int fft_size, int hop, int n_ch
         while (j < nb - 1 && (double)(j + 1) * binw <= log_freqs[l]) ++j;
         jidx[l] = j;
     }
-    std::vector<double> kt((size_t)n_log * h->Kp, 0.0);
+    std::vector<double> kt((size_t)(h->Lp + 4) * h->Kp, 0.0);      // rows L .. Lp+3 stay zero (look-ahead of the strength kernel)
     for (int c = 0; c < n_candidates; ++c)
         for (int l = 0; l < n_log; ++l) kt[(size_t)l * h->Kp + c] = kernels[(size_t)c * n_log + l];
     std::vector<double> fr(log_freqs, log_freqs + n_log);
@@ -420,7 +453,7 @@ extern "C" int frt_pitch_track(frt_pitch* h, const double* x, int64_t T, int64_t
     const long long fc_alloc = F < fc_max ? F : fc_max;
     const long long padded = ((long long)h->C * fc_alloc + kFramesPerBlock - 1) / kFramesPerBlock * kFramesPerBlock;
     if ((rc = h->psd.reserve((size_t)h->C * fc_alloc * nb * sizeof(double))) ||
-        (rc = h->s.reserve((size_t)padded * h->Lp * sizeof(double))) ||
+        (rc = h->s.reserve(((size_t)padded * h->Lp + 4 * kFramesPerGroup) * sizeof(double))) ||
         (rc = h->strength.reserve((size_t)padded * h->Kp * sizeof(double))))
         return rc;
 
