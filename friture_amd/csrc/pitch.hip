@@ -115,6 +115,36 @@ __global__ void __launch_bounds__(256) pitch_level_kernel(const PitchArgs a) {
     }
 }
 
+// The same level when the hop divides the frame (every overlap the widgets offer): overlapping frames share
+// hop-sized blocks, so the sum of squares of every block is formed once (one wavefront per block) ...
+__global__ void __launch_bounds__(256) pitch_block_energy_kernel(const double* __restrict__ x, long long x_stride, int hop,
+                                                                 long long first_block, long long n_blocks, int C,
+                                                                 double* __restrict__ eb) {
+    const int lane = threadIdx.x & 63;
+    const long long gb = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gb >= n_blocks * C) return;
+    const int chan = (int)(gb / n_blocks);
+    const long long b = gb - (long long)chan * n_blocks;
+    const double* xb = x + chan * x_stride + (first_block + b) * hop;
+    double e = 0.0;
+    for (int n = lane; n < hop; n += 64) e += xb[n] * xb[n];
+    e = wave_sum(e);
+    if (lane == 0) eb[gb] = e;
+}
+
+// ... and a frame adds up its N / hop blocks.
+__global__ void __launch_bounds__(256) pitch_level_from_blocks_kernel(const PitchArgs a, const double* __restrict__ eb,
+                                                                      long long n_blocks, int per_frame) {
+    const long long gf = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gf >= (long long)a.C * a.Fc) return;
+    const int chan = (int)(gf / a.Fc);
+    const long long fl = gf - (long long)chan * a.Fc;                  // frame inside the chunk = its first block
+    double e = 0.0;
+    for (int j = 0; j < per_frame; ++j) e += eb[(long long)chan * n_blocks + fl + j];
+    const double r = sqrt(e / (double)a.N);
+    a.raw[(2ll * a.C + chan) * a.F + a.f_start + fl] = 20.0 * log10(r + std::numeric_limits<double>::epsilon());
+}
+
 // strengths[frame][cand] = sum_l kt[l][cand] * S[frame][l]    (pitch_tracker.py:383)
 // A lane owns kCandPerLane candidates x kFramesPerWave frames.  Software pipeline over pairs of grid points: scalar
 // loads return out of order, so ANY use of one needs lgkmcnt(0) — placed by hand right BEFORE the next pair's
@@ -319,13 +349,13 @@ struct frt_pitch {
     frt_stft* stft = nullptr;
     hipStream_t stream = nullptr;
     size_t scratch_limit = 1ull << 30;
-    DeviceBuffer freqs, jidx, kt, psd, s, strength, raw, prev, stage_in, stage_out;
+    DeviceBuffer freqs, jidx, kt, psd, s, strength, raw, prev, eb, stage_in, stage_out;
 };
 
 extern "C" void frt_pitch_destroy(frt_pitch* h) {
     if (!h) return;
     if (h->stft) frt_stft_destroy(h->stft);
-    DeviceBuffer* bufs[] = {&h->freqs, &h->jidx, &h->kt, &h->psd, &h->s, &h->strength, &h->raw, &h->prev, &h->stage_in, &h->stage_out};
+    DeviceBuffer* bufs[] = {&h->freqs, &h->jidx, &h->kt, &h->psd, &h->s, &h->strength, &h->raw, &h->prev, &h->eb, &h->stage_in, &h->stage_out};
     for (auto* b : bufs) b->release();
     delete h;
 }
@@ -475,7 +505,17 @@ extern "C" int frt_pitch_track(frt_pitch* h, const double* x, int64_t T, int64_t
         const unsigned blocks = (unsigned)((total + kFramesPerBlock - 1) / kFramesPerBlock);
         // the strength kernel reads whole 8-frame groups: have the grid kernel fill every group a block touches
         hipLaunchKernelGGL(pitch_loggrid_kernel, dim3(blocks * (kFramesPerBlock / kFramesPerGroup)), dim3(256), 0, h->stream, a);
-        hipLaunchKernelGGL(pitch_level_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, h->stream, a);
+        if (h->N % h->hop == 0 && h->N / h->hop >= 2) {
+            const int per_frame = h->N / h->hop;
+            const long long n_blocks = fc + per_frame - 1;             // hop-sized blocks the chunk's frames cover
+            if ((rc = h->eb.reserve((size_t)h->C * n_blocks * sizeof(double)))) return rc;
+            hipLaunchKernelGGL(pitch_block_energy_kernel, dim3((unsigned)((n_blocks * h->C + 3) / 4)), dim3(256), 0, h->stream, dx,
+                               (long long)x_stride, h->hop, (long long)f0, n_blocks, h->C, h->eb.as<double>());
+            hipLaunchKernelGGL(pitch_level_from_blocks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a,
+                               h->eb.as<double>(), n_blocks, per_frame);
+        } else {
+            hipLaunchKernelGGL(pitch_level_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, h->stream, a);
+        }
         hipLaunchKernelGGL(pitch_strength_kernel, dim3(blocks, h->Kp / kCandPerWave), dim3(256), 0, h->stream, a.kt, a.s, a.strength,
                            h->L, h->Lp, h->Kp, total);
         hipLaunchKernelGGL(pitch_pick_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, h->stream, a);
