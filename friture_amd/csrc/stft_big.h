@@ -113,7 +113,9 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
     C tw1[HOIST1 ? 15 : 1];
     C winr[HOIST1 ? 16 : 1];                    // the thread's 16 window pairs, same condition
     C twur[HOIST1 ? 8 : 1];                     // and the 8 unpack factors exp(-2 pi i k / N), k = t + q Ms
-    float wgr[HOIST1 ? 16 : 1];                 // and the dB / colour-index offsets of the thread's 16 bins
+    // ... and the dB / colour-index offsets of the thread's 16 bins
+    constexpr bool HOISTW = HOIST1;
+    float wgr[HOISTW ? 16 : 1];
     if constexpr (HOIST1) {
 #pragma unroll
         for (int k0 = 1; k0 < 16; ++k0) tw1[k0 - 1] = tw[(t * k0) & (M - 1)];
@@ -122,11 +124,23 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             twur[q] = twn[t + q * MS];
-            wgr[q] = wgt ? wgt[t + q * MS] : 0.f;
-            wgr[8 + q] = wgt ? wgt[M - t - q * MS] : 0.f;
+            if constexpr (HOISTW) {
+                wgr[q] = wgt ? wgt[t + q * MS] : 0.f;
+                wgr[8 + q] = wgt ? wgt[M - t - q * MS] : 0.f;
+            }
         }
     }
 
+    // N <= 4096: the 16 samples of the NEXT frame are requested as soon as the current frame's first stage has left
+    // its registers (32 more live registers: +15 % at 2048 / 4096; at 8192 the kernel would drop to one wave per SIMD
+    // or lose the hoisted weights, at 16384 it spills — measured slower or equal there)
+    constexpr bool PREFETCH = HOIST1 && LOG2M <= 11;
+    C nx[PREFETCH ? 16 : 1];                     // the samples of the frame about to be transformed
+    if constexpr (PREFETCH) {
+        const C* x0 = xs + (f0 * a.hop >> 1) + t;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) nx[j] = nfr > 0 ? x0[j * MS] : C{0.f, 0.f};
+    }
     for (int g = 0; g < a.run; ++g) {
         const bool valid = g < nfr;
         if (!__syncthreads_or(valid)) break;                 // also fences the previous frame's LDS reads
@@ -138,7 +152,18 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
         // butterfly ahead of the arithmetic so that at most two groups of samples + window are in flight
         // (all sixteen at once would need 64 more registers and halve the occupancy)
         C v[16];
-        {
+        if constexpr (PREFETCH) {
+            // the frame's 16 samples were requested during the previous frame's sub-transforms (or before the loop)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                C b0 = {nx[m].x * winr[m].x, nx[m].y * winr[m].y};
+                C b1 = {nx[m + 4].x * winr[m + 4].x, nx[m + 4].y * winr[m + 4].y};
+                C b2 = {nx[m + 8].x * winr[m + 8].x, nx[m + 8].y * winr[m + 8].y};
+                C b3 = {nx[m + 12].x * winr[m + 12].x, nx[m + 12].y * winr[m + 12].y};
+                dft4(b0, b1, b2, b3);
+                v[m] = b0; v[m + 4] = b1; v[m + 8] = b2; v[m + 12] = b3;      // v[m + 4q] = first-stage output q of butterfly m
+            }
+        } else {
             const C* xf = xs + ((f0 + (valid ? g : 0)) * a.hop >> 1) + t;
             const C* wf = win + t + zero;
             C d[4], w[4], dn[4], wn[4];
@@ -176,6 +201,18 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
         }
 #pragma unroll
         for (int k0 = 0; k0 < 16; ++k0) reg[k0 * RS + lds_pad(t)] = v[k0];
+        if constexpr (PREFETCH) {
+            // v is dead from here on: request the next frame's samples now, a whole round of sub-transforms and the
+            // unpack ahead of their use (the barriers below only wait for LDS traffic)
+            if (g + 1 < nfr) {
+                const C* xn = xs + ((f0 + g + 1) * a.hop >> 1) + t;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) nx[j] = xn[j * MS];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) nx[j] = C{0.f, 0.f};
+            }
+        }
         __syncthreads();
         // ---- 3. sixteen wave-local transforms of length Ms over t, two rounds of eight ----------------------
 #pragma unroll 1
@@ -222,7 +259,11 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
             };
             if constexpr (HOIST1) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) pair(q, twur[q], wgr[q], wgr[8 + q]);
+                for (int q = 0; q < 8; ++q) {
+                    if constexpr (HOISTW) pair(q, twur[q], wgr[q], wgr[8 + q]);
+                    else pair(q, twur[q], a.kind == FRT_STFT_PSD ? 0.f : weight_at(t + q * MS),
+                              a.kind == FRT_STFT_PSD ? 0.f : weight_at(M - t - q * MS));
+                }
             } else {
 #pragma unroll 2
                 for (int q = 0; q < 8; ++q)
