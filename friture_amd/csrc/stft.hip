@@ -361,7 +361,16 @@ template <int LOG2M>
 static int launch_big_one(const StftArgs& a, hipStream_t stream) {
     using B = BigPlan<LOG2M>;
     const int blocks = (a.n_groups + B::GPB - 1) / B::GPB;
-    hipLaunchKernelGGL((stft_big_kernel<LOG2M>), dim3(blocks), dim3(B::BLOCK), 0, stream, a);
+    // rows on 16-byte boundaries (the library's own staging buffers and torch tensors are): the LDS-DMA variant
+    const bool aligned16 = ((uintptr_t)a.x % 16 == 0) && (a.x_stride % 4 == 0) && (a.hop % 4 == 0);
+    if constexpr (B::GPB == 1) {
+        if (aligned16 && !getenv("FRT_STFT_NO_DMA")) {
+            hipLaunchKernelGGL((stft_big_kernel<LOG2M, true>), dim3(blocks), dim3(B::BLOCK), 0, stream, a);
+            FRT_HIP_CHECK(hipGetLastError());
+            return FRT_OK;
+        }
+    }
+    hipLaunchKernelGGL((stft_big_kernel<LOG2M, false>), dim3(blocks), dim3(B::BLOCK), 0, stream, a);
     FRT_HIP_CHECK(hipGetLastError());
     return FRT_OK;
 }

@@ -1,4 +1,4 @@
-// stft_big.h — the instance of K1 for N >= 2048 (a frame spans several wavefronts), float32.
+// stft_big.h — the instances of K1 for N >= 2048 (a frame spans several wavefronts), float32.
 // Included by stft.hip.
 //
 // The generic stft_kernel runs five Stockham passes over the whole workgroup for N = 16384: ten
@@ -64,14 +64,20 @@ struct BigPlan {
     static constexpr int GPB = BLOCK / MS;                  // frames in flight per workgroup
 };
 
-template <int LOG2M>
+// DMA (one frame per workgroup, N >= 8192, 16-byte aligned rows): the samples of the NEXT frame are copied from HBM
+// straight into LDS (global_load_lds_dwordx4, no registers involved) while the current frame's sub-transforms and
+// unpack run; the first stage then reads its 16 samples from LDS.  These sizes cannot afford the 32 live registers a
+// register prefetch costs (they hold ~90 hoisted constants), and have the LDS to spare.
+template <int LOG2M, bool DMA>
 __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const StftArgs a) {
     using B = BigPlan<LOG2M>;
     using C = cpx<float>;
     constexpr int M = B::M, MS = B::MS, TPFS = B::TPFS, RS = B::RS, BLOCK = B::BLOCK, GPB = B::GPB;
+    static_assert(!DMA || GPB == 1, "the staged variant serves one frame per workgroup");
 
     __shared__ C lds[GPB * 16 * RS];
     __shared__ uint32_t lut_lds[256];
+    __shared__ __attribute__((aligned(16))) C stage[DMA ? M : 1];
 
     const int tid = threadIdx.x;
     const int grp = tid / MS;
@@ -141,8 +147,25 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
 #pragma unroll
         for (int j = 0; j < 16; ++j) nx[j] = nfr > 0 ? x0[j * MS] : C{0.f, 0.f};
     }
+    // one frame = M complex = 8 M bytes = M / 128 wave-instructions of 1 KB, dealt round-robin to the wavefronts
+    auto stage_frame = [&](long long frame) {
+        const char* src = (const char*)(xs + (frame * a.hop >> 1));
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+#pragma unroll
+        for (int j = 0; j < M / 128 / (BLOCK / 64); ++j) {
+            const int chunk = j * (BLOCK / 64) + wave;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + chunk * 1024 + lane * 16),
+                                             (void __attribute__((address_space(3)))*)((char*)stage + chunk * 1024), 16, 0, 0);
+        }
+    };
+    if constexpr (DMA) {
+        if (nfr > 0) stage_frame(f0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): nothing younger is in flight yet that the loop's vmcnt(16) could count on
+    }
     for (int g = 0; g < a.run; ++g) {
         const bool valid = g < nfr;
+        // the staged frame has landed once at most the 16 row stores of the previous frame are still outstanding
+        if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x4F70);           // vmcnt(16), other counters untouched
         if (!__syncthreads_or(valid)) break;                 // also fences the previous frame's LDS reads
         int zero = 0;
         asm volatile("s_mov_b32 %0, 0" : "=s"(zero));        // keeps table loads inside the loop
@@ -162,6 +185,19 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
                 C b3 = {nx[m + 12].x * winr[m + 12].x, nx[m + 12].y * winr[m + 12].y};
                 dft4(b0, b1, b2, b3);
                 v[m] = b0; v[m + 4] = b1; v[m + 8] = b2; v[m + 12] = b3;      // v[m + 4q] = first-stage output q of butterfly m
+            }
+        } else if constexpr (DMA) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                C d[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) d[p] = valid ? stage[t + (m + 4 * p) * MS] : C{0.f, 0.f};
+                C b0 = {d[0].x * winr[m].x, d[0].y * winr[m].y};
+                C b1 = {d[1].x * winr[m + 4].x, d[1].y * winr[m + 4].y};
+                C b2 = {d[2].x * winr[m + 8].x, d[2].y * winr[m + 8].y};
+                C b3 = {d[3].x * winr[m + 12].x, d[3].y * winr[m + 12].y};
+                dft4(b0, b1, b2, b3);
+                v[m] = b0; v[m + 4] = b1; v[m + 8] = b2; v[m + 12] = b3;
             }
         } else {
             const C* xf = xs + ((f0 + (valid ? g : 0)) * a.hop >> 1) + t;
@@ -214,6 +250,10 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
             }
         }
         __syncthreads();
+        if constexpr (DMA) {
+            // every thread has read its samples of this frame: the staging buffer is free for the next one
+            if (g + 1 < nfr) stage_frame(f0 + g + 1);
+        }
         // ---- 3. sixteen wave-local transforms of length Ms over t, two rounds of eight ----------------------
 #pragma unroll 1
         for (int r = 0; r < 2; ++r) {
