@@ -68,6 +68,7 @@ struct IirStageArgs {
     int n_channels;
     int n_row, n_quad;         // filters that need a 16-lane row (order > 4) / fit a quad (order <= 4)
     int waves_row;             // wavefronts of row slots; quad slots follow
+    int dec_lanes;             // lanes per slot of the decimator's mode (16 or 4), 0 without a decimator
     int row_filter[kMaxFilters];
     int quad_filter[kMaxFilters];
 };
@@ -197,7 +198,8 @@ __device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long 
 
     const bool write_y = a.pass != 1 && a.y != nullptr;
     const bool write_dec = a.pass != 1 && a.xnext != nullptr;
-    const bool keep_out = write_y || write_dec;                       // uniform
+    // uniform: the band signals when asked for, the decimator's output in the wavefronts that carry the decimator
+    const bool keep_out = write_y || (write_dec && a.dec_lanes == LPS);
     const bool is_dec = f == a.dec_filter;
 
     const long long start = (long long)q * a.chunk;
@@ -296,9 +298,11 @@ __global__ void __launch_bounds__(64) iir_stage_kernel(const IirStageArgs a) {
 static int launch_iir_stage(IirStageArgs a, const int* orders, int n_channels, hipStream_t stream) {
     a.n_channels = n_channels;
     a.n_row = a.n_quad = 0;
+    a.dec_lanes = 0;
     for (int f = 0; f < a.nfilt; ++f) {
         if (orders[f] > 4) a.row_filter[a.n_row++] = f;
         else a.quad_filter[a.n_quad++] = f;
+        if (f == a.dec_filter) a.dec_lanes = orders[f] > 4 ? 16 : 4;
     }
     const long long per = (long long)n_channels * a.nchunks;
     const long long wr = (per * a.n_row + 3) / 4, wq = (per * a.n_quad + 15) / 16;

@@ -83,7 +83,7 @@ def main():
         del x, o, xb, ob
 
     # ---- K2/K4 exact IIR bank energies ---------------------------------------------------------------
-    for ch, bpo, log2n, chunk in [(8, 3, 22, 2048), (64, 24, 20, 4096), (8, 3, 16, 0)]:
+    for ch, bpo, log2n, chunk in [(8, 3, 22, 2048), (64, 24, 20, 8192), (8, 3, 16, 0)]:
         n = 1 << log2n
         bank = IirBank(t["bdec"], t["adec"], list(t[f"boct_{bpo}"]), list(t[f"aoct_{bpo}"]), ch)
         bank.set_chunk(chunk)
