@@ -408,12 +408,14 @@ __global__ void __launch_bounds__(256) iir_slice_sum_kernel(double* __restrict__
     partial[i] = e;
 }
 
-// A^L z for the 16 states of a filter held by the lanes of a DPP row, lane s owning row s of the matrix:
-// four interleaved partial sums (the serial part of the scan is this dependency chain).
+// A^L z for the states of a filter held by the lanes of a DPP row, lane s owning row s of the matrix.  NT: number of
+// (leading) non-zero columns, i.e. the filter order rounded up to 4; four interleaved partial sums (the serial part
+// of the scan is this dependency chain).
+template <int NT>
 __device__ __forceinline__ double row_matvec(const double (&m)[kStates], double z) {
     double p[4] = {0.0, 0.0, 0.0, 0.0};
-    static_assert(kStates == 16, "one 16-lane row per filter");
-#define FRT_SCAN_TERM(T) p[(T) & 3] += m[T] * dpp_row_bcast<T>(z);
+    static_assert(kStates == 16 && NT % 4 == 0 && NT <= 16, "one 16-lane row per filter");
+#define FRT_SCAN_TERM(T) if (T < NT) p[(T) & 3] += m[T] * dpp_row_bcast<T>(z);
     FRT_SCAN_TERM(0) FRT_SCAN_TERM(1) FRT_SCAN_TERM(2) FRT_SCAN_TERM(3) FRT_SCAN_TERM(4) FRT_SCAN_TERM(5)
     FRT_SCAN_TERM(6) FRT_SCAN_TERM(7) FRT_SCAN_TERM(8) FRT_SCAN_TERM(9) FRT_SCAN_TERM(10) FRT_SCAN_TERM(11)
     FRT_SCAN_TERM(12) FRT_SCAN_TERM(13) FRT_SCAN_TERM(14) FRT_SCAN_TERM(15)
@@ -425,19 +427,17 @@ __device__ __forceinline__ double row_matvec(const double (&m)[kStates], double 
 // of pass 1) -> chunk_init (z_q).  One workgroup per (channel, filter), one 16-lane row per GROUP of `group`
 // consecutive chunks: (1) every row runs its group from a zero state, (2) row 0 chains the groups with
 // A^(L group), (3) every row replays its group from its true start.  3 x nchunks / rows serial steps instead
-// of nchunks.  power_l / power_g: [nfilt][16][16] row-major A^L and A^(L group).
+// of nchunks.  power_l / power_g: [nfilt][16][16] row-major A^L and A^(L group).  The end states of eight chunks
+// are fetched at a time, so that no serial step waits for memory.
 constexpr int kScanRows = 32;
+constexpr int kScanBatch = 8;
 
-__global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* __restrict__ power_l,
-                                                                  const double* __restrict__ power_g,
-                                                                  const double* __restrict__ state,
-                                                                  const double* __restrict__ chunk_end,
-                                                                  const int* __restrict__ order,
-                                                                  double* __restrict__ chunk_init, int nfilt, int nchunks, int group) {
-    __shared__ double gend[kScanRows][kStates], gstart[kScanRows][kStates];
-    const int gid = blockIdx.x;                               // (channel, filter) pair
+template <int NT>
+__device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l, const double* __restrict__ power_g,
+                                              const double* __restrict__ state, const double* __restrict__ chunk_end,
+                                              double* __restrict__ chunk_init, int gid, int f, bool live, int nchunks, int group,
+                                              double (*gend)[kStates], double (*gstart)[kStates]) {
     const int row = threadIdx.x >> 4, s = threadIdx.x & 15;
-    const int f = gid % nfilt;
     double m[kStates];
 #pragma unroll
     for (int t = 0; t < kStates; ++t) m[t] = power_l[((size_t)f * kStates + s) * kStates + t];
@@ -445,12 +445,20 @@ __global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* 
     double* ci = chunk_init + (size_t)gid * nchunks * kStates + s;
     const int q0 = row * group;
     const int q1 = (q0 + group) < nchunks ? (q0 + group) : nchunks;
-    const bool live = s < order[f];
-    // zero-state end state of chunk q; lanes above the order stay 0 whatever the scratch holds
-    auto end_state = [&](int q) -> double { return live ? ce[(size_t)q * kStates] : 0.0; };
+    // zero-state end states of chunks q .. q+7; lanes above the order stay 0 whatever the scratch holds
+    auto end_states = [&](int q, double (&e)[kScanBatch]) {
+#pragma unroll
+        for (int j = 0; j < kScanBatch; ++j) e[j] = (live && q + j < q1) ? ce[(size_t)(q + j) * kStates] : 0.0;
+    };
 
     double z = 0.0;
-    for (int q = q0; q < q1; ++q) z = end_state(q) + row_matvec(m, z);
+    for (int q = q0; q < q1; q += kScanBatch) {
+        double e[kScanBatch];
+        end_states(q, e);
+#pragma unroll
+        for (int j = 0; j < kScanBatch; ++j)
+            if (q + j < q1) z = e[j] + row_matvec<NT>(m, z);
+    }
     gend[row][s] = z;
     __syncthreads();
     if (row == 0) {
@@ -460,15 +468,38 @@ __global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* 
         double zz = live ? state[(size_t)gid * kStates + s] : 0.0;
         for (int r = 0; r < kScanRows; ++r) {
             gstart[r][s] = zz;
-            zz = gend[r][s] + row_matvec(mg, zz);
+            zz = gend[r][s] + row_matvec<NT>(mg, zz);
         }
     }
     __syncthreads();
     z = gstart[row][s];
-    for (int q = q0; q < q1; ++q) {
-        ci[(size_t)q * kStates] = z;
-        z = end_state(q) + row_matvec(m, z);
+    for (int q = q0; q < q1; q += kScanBatch) {
+        double e[kScanBatch];
+        end_states(q, e);
+#pragma unroll
+        for (int j = 0; j < kScanBatch; ++j) {
+            if (q + j < q1) {
+                ci[(size_t)(q + j) * kStates] = z;
+                z = e[j] + row_matvec<NT>(m, z);
+            }
+        }
     }
+}
+
+__global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* __restrict__ power_l,
+                                                                  const double* __restrict__ power_g,
+                                                                  const double* __restrict__ state,
+                                                                  const double* __restrict__ chunk_end,
+                                                                  const int* __restrict__ order,
+                                                                  double* __restrict__ chunk_init, int nfilt, int nchunks, int group) {
+    __shared__ double gend[kScanRows][kStates], gstart[kScanRows][kStates];
+    const int gid = blockIdx.x;                               // (channel, filter) pair
+    const int f = gid % nfilt;
+    const int ord = order[f];                                 // uniform in the workgroup
+    const bool live = (int)(threadIdx.x & 15) < ord;
+    if (ord <= 4) iir_scan_body<4>(power_l, power_g, state, chunk_end, chunk_init, gid, f, live, nchunks, group, gend, gstart);
+    else if (ord <= 12) iir_scan_body<12>(power_l, power_g, state, chunk_end, chunk_init, gid, f, live, nchunks, group, gend, gstart);
+    else iir_scan_body<16>(power_l, power_g, state, chunk_end, chunk_init, gid, f, live, nchunks, group, gend, gstart);
 }
 
 // sp_blk = E_blk + sp_{blk-1} * (1-alpha)^n  (exp_smoothing.py:52-54), optional dB + weighting.
