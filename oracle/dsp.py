@@ -206,6 +206,12 @@ def _load_iir_c():
     global _iir_c
     if _iir_c is None:
         so = _HERE / "_build" / "libiir_ref.so"
+        if not so.exists():                      # not built yet (fresh checkout): one quiet attempt with the Makefile
+            import subprocess
+            try:
+                subprocess.run(["make", "-C", str(_HERE)], capture_output=True, timeout=120, check=False)
+            except Exception:
+                pass
         if so.exists():
             lib = ctypes.CDLL(str(so))
             lib.oracle_lfilter_df2t.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p, ctypes.c_long,
