@@ -12,7 +12,7 @@ import ctypes
 
 import numpy as np
 
-from . import _lib, tables
+from . import _lib
 from .audioproc import audioproc
 from .constants import SAMPLING_RATE
 from .ringbuffer import RingBuffer

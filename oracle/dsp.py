@@ -16,7 +16,6 @@ friture/test/test_exp_smoothing.py) are replayed against the oracle in the same 
 from __future__ import annotations
 
 import ctypes
-import math
 from pathlib import Path
 
 import numpy as np
