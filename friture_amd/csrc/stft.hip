@@ -357,30 +357,31 @@ namespace frt {
 
 // ---- host side -----------------------------------------------------------------------------------
 
-template <int LOG2M>
+template <typename T, int LOG2M>
 static int launch_big_one(const StftArgs& a, hipStream_t stream) {
     using B = BigPlan<LOG2M>;
     const int blocks = (a.n_groups + B::GPB - 1) / B::GPB;
-    // rows on 16-byte boundaries (the library's own staging buffers and torch tensors are): the LDS-DMA variant
-    const bool aligned16 = ((uintptr_t)a.x % 16 == 0) && (a.x_stride % 4 == 0) && (a.hop % 4 == 0);
-    if constexpr (B::GPB == 1) {
+    if constexpr (sizeof(T) == 4 && B::GPB == 1) {
+        // rows on 16-byte boundaries (the library's own staging buffers and torch tensors are): the LDS-DMA variant
+        const bool aligned16 = ((uintptr_t)a.x % 16 == 0) && (a.x_stride % 4 == 0) && (a.hop % 4 == 0);
         if (aligned16 && !getenv("FRT_STFT_NO_DMA")) {
-            hipLaunchKernelGGL((stft_big_kernel<LOG2M, true>), dim3(blocks), dim3(B::BLOCK), 0, stream, a);
+            hipLaunchKernelGGL((stft_big_kernel<T, LOG2M, true>), dim3(blocks), dim3(B::BLOCK), 0, stream, a);
             FRT_HIP_CHECK(hipGetLastError());
             return FRT_OK;
         }
     }
-    hipLaunchKernelGGL((stft_big_kernel<LOG2M, false>), dim3(blocks), dim3(B::BLOCK), 0, stream, a);
+    hipLaunchKernelGGL((stft_big_kernel<T, LOG2M, false>), dim3(blocks), dim3(B::BLOCK), 0, stream, a);
     FRT_HIP_CHECK(hipGetLastError());
     return FRT_OK;
 }
 
+template <typename T>
 static int launch_big(int log2m, const StftArgs& a, hipStream_t stream) {
     switch (log2m) {
-        case 10: return launch_big_one<10>(a, stream);
-        case 11: return launch_big_one<11>(a, stream);
-        case 12: return launch_big_one<12>(a, stream);
-        case 13: return launch_big_one<13>(a, stream);
+        case 10: return launch_big_one<T, 10>(a, stream);
+        case 11: return launch_big_one<T, 11>(a, stream);
+        case 12: return launch_big_one<T, 12>(a, stream);
+        case 13: return launch_big_one<T, 13>(a, stream);
     }
     set_last_error("big kernel: unsupported fft size 2^%d", log2m + 1);
     return FRT_ERR_UNSUPPORTED;
@@ -610,8 +611,11 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     a.run = run;
     a.frame_base = 0;
 
-    // N >= 2048, float32, aligned even hop: the radix-16 + wave-local instance (stft_big.h)
-    if (h->precision == 32 && h->log2m >= 10 && a.vec2 && !h->force_generic) {
+    // N >= 2048, aligned even hop: the radix-16 + wave-local instances (stft_big.h)
+    // (float64: where it measures faster than the generic walk — N = 2048 and N = 16384; at 4096 / 8192 the instance
+    // needs 260 VGPRs, one wave per SIMD, and loses)
+    const bool big_ok = h->precision == 32 ? h->log2m >= 10 : (h->log2m == 10 || h->log2m == 13);
+    if (big_ok && a.vec2 && !h->force_generic) {
         int brun = h->run_length;
         if (brun <= 0) {
             // every thread keeps its window, twiddle and weight factors in registers for the whole run, so runs
@@ -632,7 +636,7 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
         const long long bgroups = (long long)a.runs_per_channel * h->n_channels;
         FRT_REQUIRE(bgroups < (1ll << 31), "frt_stft_run: too many lane groups");
         a.n_groups = (int)bgroups;
-        return launch_big(h->log2m, a, stream);
+        return h->precision == 32 ? launch_big<float>(h->log2m, a, stream) : launch_big<double>(h->log2m, a, stream);
     }
     const long long rest = F - a.frame_base;
     a.runs_per_channel = (int)((rest + run - 1) / run);

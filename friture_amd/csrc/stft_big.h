@@ -68,10 +68,13 @@ struct BigPlan {
 // straight into LDS (global_load_lds_dwordx4, no registers involved) while the current frame's sub-transforms and
 // unpack run; the first stage then reads its 16 samples from LDS.  These sizes cannot afford the 32 live registers a
 // register prefetch costs (they hold ~90 hoisted constants), and have the LDS to spare.
-template <int LOG2M, bool DMA>
+// T: float (every optimisation below) or double (the transform structure only: no register-resident constants, no
+// prefetch, no staging — the float64 instance serves the drop-in / pitch-tracker path, twice the registers and LDS).
+template <typename T, int LOG2M, bool DMA>
 __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const StftArgs a) {
     using B = BigPlan<LOG2M>;
-    using C = cpx<float>;
+    using C = cpx<T>;
+    static_assert(!DMA || sizeof(T) == 4, "LDS staging is a float32 feature");
     constexpr int M = B::M, MS = B::MS, TPFS = B::TPFS, RS = B::RS, BLOCK = B::BLOCK, GPB = B::GPB;
     static_assert(!DMA || GPB == 1, "the staged variant serves one frame per workgroup");
 
@@ -98,30 +101,30 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
     if (nfr > a.run) nfr = a.run;
     if (!group_ok) nfr = 0;
 
-    const C* xs = (const C*)((const float*)a.x + chan * a.x_stride);
+    const C* xs = (const C*)((const T*)a.x + chan * a.x_stride);
     const C* win = (const C*)a.window;
     const C* tw = (const C*)a.tw;          // exp(-2 pi i n / M)
     const C* twn = (const C*)a.twn;        // exp(-2 pi i k / N)
-    const float* wgt = (const float*)(a.kind == FRT_STFT_IMAGE ? a.wimage : a.weight);
-    const float image_gain = (float)a.image_gain, norm_off = (float)a.norm_off, norm_scale = (float)a.norm_scale;
+    const T* wgt = (const T*)(a.kind == FRT_STFT_IMAGE ? a.wimage : a.weight);
+    const T image_gain = (T)a.image_gain, norm_off = (T)a.norm_off, norm_scale = (T)a.norm_scale;
 
     // twiddles of the wave-local sub-transforms depend on the thread's index in its sub-transform only
     const int si = t % TPFS;               // index inside the sub-transform
     const int sg = t / TPFS;               // sub-transform of a round (0..7)
-    TwRegs<float, B::LOG2MS> twr;
+    TwRegs<T, B::LOG2MS> twr;
     twr.load((const C*)a.tws, si);
     // so do the thread's other per-frame constants — the 15 factors exp(-2 pi i t k0 / M) between the radix-16
     // stage and the sub-transforms, its 16 window pairs, its 8 unpack factors and the 16 dB / colour-index offsets
     // of its bins: ~90 registers (239 in all at N = 16384) instead of ~55 L2 reads per frame.  Measured with runs of
     // 8-16 frames: +37 % at N = 16384 (one 512-thread workgroup per CU either way), +9...15 % at 4096 / 8192 (two
     // 256-thread workgroups per CU instead of three), +3 % at 2048.
-    constexpr bool HOIST1 = LOG2M >= 10;
+    constexpr bool HOIST1 = LOG2M >= 10 && sizeof(T) == 4;
     C tw1[HOIST1 ? 15 : 1];
     C winr[HOIST1 ? 16 : 1];                    // the thread's 16 window pairs, same condition
     C twur[HOIST1 ? 8 : 1];                     // and the 8 unpack factors exp(-2 pi i k / N), k = t + q Ms
     // ... and the dB / colour-index offsets of the thread's 16 bins
     constexpr bool HOISTW = HOIST1;
-    float wgr[HOISTW ? 16 : 1];
+    T wgr[HOISTW ? 16 : 1];
     if constexpr (HOIST1) {
 #pragma unroll
         for (int k0 = 1; k0 < 16; ++k0) tw1[k0 - 1] = tw[(t * k0) & (M - 1)];
@@ -131,8 +134,8 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
         for (int q = 0; q < 8; ++q) {
             twur[q] = twn[t + q * MS];
             if constexpr (HOISTW) {
-                wgr[q] = wgt ? wgt[t + q * MS] : 0.f;
-                wgr[8 + q] = wgt ? wgt[M - t - q * MS] : 0.f;
+                wgr[q] = wgt ? wgt[t + q * MS] : (T)0;
+                wgr[8 + q] = wgt ? wgt[M - t - q * MS] : (T)0;
             }
         }
     }
@@ -145,7 +148,7 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
     if constexpr (PREFETCH) {
         const C* x0 = xs + (f0 * a.hop >> 1) + t;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) nx[j] = nfr > 0 ? x0[j * MS] : C{0.f, 0.f};
+        for (int j = 0; j < 16; ++j) nx[j] = nfr > 0 ? x0[j * MS] : C{(T)0, (T)0};
     }
     // one frame = M complex = 8 M bytes = M / 128 wave-instructions of 1 KB, dealt round-robin to the wavefronts
     auto stage_frame = [&](long long frame) {
@@ -191,7 +194,7 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
             for (int m = 0; m < 4; ++m) {
                 C d[4];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) d[p] = valid ? stage[t + (m + 4 * p) * MS] : C{0.f, 0.f};
+                for (int p = 0; p < 4; ++p) d[p] = valid ? stage[t + (m + 4 * p) * MS] : C{(T)0, (T)0};
                 C b0 = {d[0].x * winr[m].x, d[0].y * winr[m].y};
                 C b1 = {d[1].x * winr[m + 4].x, d[1].y * winr[m + 4].y};
                 C b2 = {d[2].x * winr[m + 8].x, d[2].y * winr[m + 8].y};
@@ -205,7 +208,7 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
             C d[4], w[4], dn[4], wn[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                d[p] = valid ? xf[(4 * p) * MS] : C{0.f, 0.f};
+                d[p] = valid ? xf[(4 * p) * MS] : C{(T)0, (T)0};
                 if constexpr (HOIST1) w[p] = winr[4 * p];
                 else w[p] = wf[(4 * p) * MS];
             }
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
                 if (m < 3) {
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
-                        dn[p] = valid ? xf[(m + 1 + 4 * p) * MS] : C{0.f, 0.f};
+                        dn[p] = valid ? xf[(m + 1 + 4 * p) * MS] : C{(T)0, (T)0};
                         if constexpr (HOIST1) wn[p] = winr[m + 1 + 4 * p];
                         else wn[p] = wf[(m + 1 + 4 * p) * MS];
                     }
@@ -246,7 +249,7 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
                 for (int j = 0; j < 16; ++j) nx[j] = xn[j * MS];
             } else {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) nx[j] = C{0.f, 0.f};
+                for (int j = 0; j < 16; ++j) nx[j] = C{(T)0, (T)0};
             }
         }
         __syncthreads();
@@ -261,7 +264,7 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
             C u[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) u[j] = buf[lds_pad(si + j * TPFS)];
-            fft_pow2_forward<float, B::LOG2MS, true>(u, buf, si, twr);
+            fft_pow2_forward<T, B::LOG2MS, true>(u, buf, si, twr);
             pass_sync<true>();
 #pragma unroll
             for (int j = 0; j < 8; ++j) buf[lds_pad(si + j * TPFS)] = u[j];
@@ -273,27 +276,29 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
             return reg[(k & 15) * RS + lds_pad(k >> 4)];
         };
         if (valid) {
-            float* row = (float*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
-            auto finish_store = [&](int k, float p, float w) {
+            T* row = (T*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
+            // colour words are 4 bytes whatever the arithmetic type
+            uint32_t* prow = (uint32_t*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
+            auto finish_store = [&](int k, T p, T w) {
                 if (a.kind == FRT_STFT_PSD) {
                     row[k] = p;
                 } else if (a.kind == FRT_STFT_IMAGE) {
-                    float vv = image_gain * __log2f(p + 1e-30f) + w;
-                    vv = fminf(fmaxf(vv, 0.f), 255.f);
-                    ((uint32_t*)row)[k] = lut_lds[(int)vv];
+                    T vv = image_gain * log2_t(p + (T)1e-30) + w;
+                    vv = fmin(fmax(vv, (T)0), (T)255);
+                    prow[k] = lut_lds[(int)vv];
                 } else {
-                    float vv = db10<float>(p) + w;
+                    T vv = db10<T>(p) + w;
                     if (a.kind == FRT_STFT_NORM) vv = (vv + norm_off) * norm_scale;
                     row[k] = vv;
                 }
             };
-            auto weight_at = [&](int k) -> float { return wgt ? wgt[k + zero] : 0.f; };
-            auto pair = [&](int q, C wk, float wlo, float whi) {
+            auto weight_at = [&](int k) -> T { return wgt ? wgt[k + zero] : (T)0; };
+            auto pair = [&](int q, C wk, T wlo, T whi) {
                 const int k = t + q * MS;                    // k < M/2
                 const C A = zat(k), Bc = cconj(zat(M - k));
                 const C S = A + Bc, D = A - Bc;
                 const C tt = cmul(wk, D);
-                const float ar = S.x + tt.y, ai = S.y - tt.x, br = S.x - tt.y, bi = S.y + tt.x;
+                const T ar = S.x + tt.y, ai = S.y - tt.x, br = S.x - tt.y, bi = S.y + tt.x;
                 finish_store(k, ar * ar + ai * ai, wlo);
                 finish_store(M - k, br * br + bi * bi, whi);
             };
@@ -301,18 +306,18 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if constexpr (HOISTW) pair(q, twur[q], wgr[q], wgr[8 + q]);
-                    else pair(q, twur[q], a.kind == FRT_STFT_PSD ? 0.f : weight_at(t + q * MS),
-                              a.kind == FRT_STFT_PSD ? 0.f : weight_at(M - t - q * MS));
+                    else pair(q, twur[q], a.kind == FRT_STFT_PSD ? (T)0 : weight_at(t + q * MS),
+                              a.kind == FRT_STFT_PSD ? (T)0 : weight_at(M - t - q * MS));
                 }
             } else {
 #pragma unroll 2
                 for (int q = 0; q < 8; ++q)
-                    pair(q, twn[t + q * MS + zero], a.kind == FRT_STFT_PSD ? 0.f : weight_at(t + q * MS),
-                         a.kind == FRT_STFT_PSD ? 0.f : weight_at(M - t - q * MS));
+                    pair(q, twn[t + q * MS + zero], a.kind == FRT_STFT_PSD ? (T)0 : weight_at(t + q * MS),
+                         a.kind == FRT_STFT_PSD ? (T)0 : weight_at(M - t - q * MS));
             }
             if (t == 0) {
                 const C zm = zat(M / 2);
-                finish_store(M / 2, (zm.x * zm.x + zm.y * zm.y) * 4.f, a.kind == FRT_STFT_PSD ? 0.f : weight_at(M / 2));
+                finish_store(M / 2, (zm.x * zm.x + zm.y * zm.y) * (T)4, a.kind == FRT_STFT_PSD ? (T)0 : weight_at(M / 2));
             }
         }
     }
