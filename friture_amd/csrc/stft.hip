@@ -612,9 +612,7 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     a.frame_base = 0;
 
     // N >= 2048, aligned even hop: the radix-16 + wave-local instances (stft_big.h)
-    // (float64: where it measures faster than the generic walk — N = 2048 and N = 16384; at 4096 / 8192 the instance
-    // needs 260 VGPRs, one wave per SIMD, and loses)
-    const bool big_ok = h->precision == 32 ? h->log2m >= 10 : (h->log2m == 10 || h->log2m == 13);
+    const bool big_ok = h->log2m >= 10;
     if (big_ok && a.vec2 && !h->force_generic) {
         int brun = h->run_length;
         if (brun <= 0) {

@@ -111,8 +111,10 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
     // twiddles of the wave-local sub-transforms depend on the thread's index in its sub-transform only
     const int si = t % TPFS;               // index inside the sub-transform
     const int sg = t / TPFS;               // sub-transform of a round (0..7)
-    TwRegs<T, B::LOG2MS> twr;
-    twr.load((const C*)a.tws, si);
+    // float64: the sub-transform twiddles are re-read from the table (56 registers otherwise: one wave per SIMD)
+    constexpr bool TWREG = sizeof(T) == 4;
+    TwRegs<T, TWREG ? B::LOG2MS : 3> twr;
+    if constexpr (TWREG) twr.load((const C*)a.tws, si);
     // so do the thread's other per-frame constants — the 15 factors exp(-2 pi i t k0 / M) between the radix-16
     // stage and the sub-transforms, its 16 window pairs, its 8 unpack factors and the 16 dB / colour-index offsets
     // of its bins: ~90 registers (239 in all at N = 16384) instead of ~55 L2 reads per frame.  Measured with runs of
@@ -264,7 +266,12 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
             C u[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) u[j] = buf[lds_pad(si + j * TPFS)];
-            fft_pow2_forward<T, B::LOG2MS, true>(u, buf, si, twr);
+            if constexpr (TWREG) {
+                fft_pow2_forward<T, B::LOG2MS, true>(u, buf, si, twr);
+            } else {
+                TwTable<T, B::LOG2MS> twt{(const C*)a.tws, zero};
+                fft_pow2_forward<T, B::LOG2MS, true>(u, buf, si, twt);
+            }
             pass_sync<true>();
 #pragma unroll
             for (int j = 0; j < 8; ++j) buf[lds_pad(si + j * TPFS)] = u[j];
