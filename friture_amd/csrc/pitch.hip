@@ -17,6 +17,7 @@
 // Compiled with -ffp-contract=off: everything outside the contraction keeps the reference's
 // operation order; the contraction itself uses explicit fma().
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 
 #include "common.h"
@@ -96,6 +97,69 @@ __global__ void __launch_bounds__(256) pitch_loggrid_kernel(const PitchArgs a) {
     // pass 2: every lane divides the values it wrote itself (:380; 0/0 = nan for silence, as upstream)
     if (live)
         for (int l = l0 + li; l < l1 && l < a.L; l += 8) out[l * kFramesPerGroup + q] = out[l * kFramesPerGroup + q] / rms;
+}
+
+// The same kernel for grids of 32*VPL points (the widget's grid has 1023 -> Lp = 1024, VPL = 32): a lane's VPL values
+// stay in registers between the two passes, so S is written once and never read back, and the fully unrolled
+// pass 1 lets the compiler batch the index/bin loads of many grid points.  Operation for operation the same
+// arithmetic as above (bit-identical results).
+template <int VPL>
+__global__ void __launch_bounds__(256) pitch_loggrid_reg_kernel(const PitchArgs a) {
+    __shared__ double part[4][kFramesPerGroup];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long group = blockIdx.x;
+    const long long total = (long long)a.C * a.Fc;
+    const int q = lane & 7, li = lane >> 3;
+    const long long gf = group * kFramesPerGroup + q;
+    double* out = a.s + group * (long long)a.Lp * kFramesPerGroup;
+    const bool live = gf < total;
+    const double* P = a.psd + (live ? gf : 0) * a.nb;
+    const int l0 = wave * (8 * VPL) + li;
+    double v[VPL];
+    double ss = 0.0;
+    // branch-free in batches of 8 grid points: all index loads, then all bin loads, then the arithmetic of
+    // grid_value() with its early-outs turned into selects (clamped indices keep every load in bounds)
+    constexpr int B = 8;
+    static_assert(VPL % B == 0, "batching");
+#pragma unroll
+    for (int i0 = 0; i0 < VPL; i0 += B) {
+        int j[B];
+        double xq[B], p0[B], p1[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const int lc = min(l0 + 8 * (i0 + i), a.L - 1);
+            j[i] = a.jidx[lc];
+            xq[i] = a.freqs[lc];
+        }
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            p0[i] = P[j[i]];
+            p1[i] = P[min(j[i] + 1, a.nb - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const int l = l0 + 8 * (i0 + i);
+            const double m0 = sqrt(p0[i]) * (double)a.N;
+            const double m1 = sqrt(p1[i]) * (double)a.N;
+            const double x0 = (double)j[i] * a.binw;
+            const double slope = (m1 - m0) / ((double)(j[i] + 1) * a.binw - x0);
+            const double r = slope * (xq[i] - x0) + m0;
+            const double g = (j[i] >= a.nb - 1 || x0 == xq[i]) ? m0 : r;
+            const bool on = live && l < a.L;
+            v[i0 + i] = on ? g : 0.0;
+            ss += on ? g * g : 0.0;
+        }
+    }
+    for (int o = 8; o < 64; o <<= 1) ss += __shfl_xor(ss, o, 64);
+    if (li == 0) part[wave][q] = ss;
+    __syncthreads();
+    ss = (part[0][q] + part[1][q]) + (part[2][q] + part[3][q]);
+    const double rms = sqrt(ss / (double)a.L);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int l = l0 + 8 * i;
+        out[l * kFramesPerGroup + q] = (live && l < a.L) ? v[i] / rms : 0.0;
+    }
 }
 
 // frame level: 20 log10(sqrt(mean(frame^2)) + eps)   (:399-400).  One wavefront per frame.
@@ -504,7 +568,10 @@ extern "C" int frt_pitch_track(frt_pitch* h, const double* x, int64_t T, int64_t
         const unsigned groups = (unsigned)((total + kFramesPerGroup - 1) / kFramesPerGroup);
         const unsigned blocks = (unsigned)((total + kFramesPerBlock - 1) / kFramesPerBlock);
         // the strength kernel reads whole 8-frame groups: have the grid kernel fill every group a block touches
-        hipLaunchKernelGGL(pitch_loggrid_kernel, dim3(blocks * (kFramesPerBlock / kFramesPerGroup)), dim3(256), 0, h->stream, a);
+        if (h->Lp == 1024 && !getenv("FRT_PITCH_GRID_2PASS"))
+            hipLaunchKernelGGL(pitch_loggrid_reg_kernel<32>, dim3(blocks * (kFramesPerBlock / kFramesPerGroup)), dim3(256), 0, h->stream, a);
+        else
+            hipLaunchKernelGGL(pitch_loggrid_kernel, dim3(blocks * (kFramesPerBlock / kFramesPerGroup)), dim3(256), 0, h->stream, a);
         if (h->N % h->hop == 0 && h->N / h->hop >= 2) {
             const int per_frame = h->N / h->hop;
             const long long n_blocks = fc + per_frame - 1;             // hop-sized blocks the chunk's frames cover
