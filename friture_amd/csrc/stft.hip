@@ -616,17 +616,17 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     if (big_ok && a.vec2 && !h->force_generic) {
         int brun = h->run_length;
         if (brun <= 0) {
-            // every thread keeps its window, twiddle and weight factors in registers for the whole run, so runs
-            // should be long — as long as the groups still fill the chip several times over.  Measured (run sweep
-            // with tools/stft_selftest bench): 8-16 frames per group is the plateau for every size.
-            const long long total = (long long)F * h->n_channels;
-            const int gpb_big = (M / 16) < 256 ? 256 / (M / 16) : 1;
-            (void)total;
-            brun = h->log2m >= 13 ? 16 : 8;
-            // ... unless that leaves fewer lane groups than one round of workgroups (N = 16384: one workgroup
-            // per CU) or two rounds (smaller sizes)
-            const long long need = (long long)device_cu_count() * (h->log2m >= 13 ? 1 : 2) * gpb_big;
-            while (brun > 1 && ((F + brun - 1) / brun) * h->n_channels < need) brun /= 2;
+            // every thread keeps its window, twiddle and weight factors in registers for the whole run (94 table loads
+            // against 16 sample loads per frame), so runs should be long — as long as the groups still fill the chip.
+            // Measured (run sweep with tools/stft_selftest bench, one frame per workgroup): 8 frames is the plateau at
+            // N = 4096 / 8192, 16 at N = 16384; N = 2048 keeps gaining up to 32 (+6 % over 8) provided two full
+            // rounds of groups remain.
+            const int resident = h->log2m >= 13 ? 1 : h->log2m == 12 ? 2 : h->log2m == 11 ? 4 : 8;   // groups per CU
+            const long long need = (long long)device_cu_count() * resident;
+            auto groups = [&](int r) { return ((F + r - 1) / r) * h->n_channels; };
+            brun = h->log2m >= 13 ? 16 : h->log2m == 10 ? 32 : 8;
+            while (h->log2m == 10 && brun > 8 && groups(brun) < 2 * need) brun /= 2;
+            while (brun > 1 && groups(brun) < need) brun /= 2;
         }
         if (brun > F) brun = (int)F;
         a.run = brun;

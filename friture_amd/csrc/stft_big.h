@@ -364,10 +364,25 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
                               a.kind == FRT_STFT_PSD ? (T)0 : weight_at(M - t - q * MS));
                 }
             } else {
-#pragma unroll 2
-                for (int q = 0; q < 8; ++q)
-                    pair(q, twn[t + q * MS + zero], a.kind == FRT_STFT_PSD ? (T)0 : weight_at(t + q * MS),
-                         a.kind == FRT_STFT_PSD ? (T)0 : weight_at(M - t - q * MS));
+                // float64: the eight unpack factors (and the weights of the dB kinds) are ALL requested before the
+                // first row store — a table load issued between the stores of two bin pairs is only complete, for
+                // the in-order vector-memory counter, once those stores are acknowledged
+                C twl[8];
+                T wl[16];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) twl[q] = twn[t + q * MS + zero];
+                if (a.kind != FRT_STFT_PSD && wgt) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        wl[q] = wgt[t + q * MS + zero];
+                        wl[8 + q] = wgt[M - t - q * MS + zero];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) wl[q] = (T)0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pair(q, twl[q], wl[q], wl[8 + q]);
             }
             if (t == 0) {
                 const C zm = zat(M / 2);
