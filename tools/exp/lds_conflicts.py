@@ -29,7 +29,7 @@ def model(log2m, pad, rs_extra):
     M = 1 << log2m
     MS = M // 16
     TPFS = MS // 8
-    RS = pad(MS - 1) + 1 + rs_extra
+    RS = max(pad(i) for i in range(MS)) + 1 + rs_extra      # regions must not overlap
     BLOCK = max(256, MS)
     nw = BLOCK // 64
     res = {}
