@@ -168,3 +168,32 @@ def test_streaming_tracker_mirror(golden, pt):
     assert abs(tr2.estimate_pitch(x[None, :4096]) - g["N4096_jump_f0"][0]) <= TOL_F0 * 200
     kat = pt.PitchTracker(RingBuffer(), fft_size=32, overlap=0.5)
     assert np.isnan(kat.estimate_pitch(g["kat32_frame"][None, :]))   # what the reference returns today (see the oracle)
+
+
+def test_other_grids_and_both_log_grid_kernels(pt, monkeypatch):
+    """The widget's grid (1023 points) runs the register-resident log-grid kernel; any other grid, and
+    FRT_PITCH_GRID_2PASS=1, the two-pass one.  Both are the same arithmetic: identical bits on the widget's
+    grid, oracle parity on a coarser and a finer grid (pitch_tracker.py:334-355 with other min_freq / cres)."""
+    n_fft, hop, frames = 2048, 512, 48
+    n = n_fft + hop * (frames - 1)
+    t = np.arange(n)
+    phase = 2 * np.pi * np.cumsum(180.0 * 2 ** (1.0 * t / n)) / 48000.0
+    x = 0.2 * (np.sin(phase) + 0.5 * np.sin(2 * phase) + 0.25 * np.sin(3 * phase)) + 1e-3 * np.random.default_rng(5).standard_normal(n)
+    fast, fast_raw = pt.PitchEngine(n_fft, hop).track(x, with_raw=True)
+    monkeypatch.setenv("FRT_PITCH_GRID_2PASS", "1")
+    slow, slow_raw = pt.PitchEngine(n_fft, hop).track(x, with_raw=True)
+    monkeypatch.delenv("FRT_PITCH_GRID_2PASS")
+    assert np.array_equal(fast, slow, equal_nan=True) and np.array_equal(fast_raw, slow_raw, equal_nan=True)
+    window = dsp.hann_symmetric(n_fft)
+    for min_freq, max_freq, cres in [(100, 800, 20), (65, 1047, 7)]:
+        freqs, kernels = dsp.swipe_tables(min_freq=min_freq, max_freq=max_freq, cres=cres)
+        assert len(freqs) != 1023
+        grid, _, kern = pt.swipe_tables(min_freq=min_freq, max_freq=max_freq, cres=cres)
+        assert np.array_equal(grid, freqs) and np.array_equal(kern, kernels)
+        f0, raw = pt.PitchEngine(n_fft, hop, grid=grid, kernels=kern).track(x, with_raw=True)
+        for f in range(frames):
+            r0, c, db = dsp.pitch_candidate(x[f * hop:f * hop + n_fft], window, freqs, kernels)
+            assert abs(raw[0, 0, f] - r0) <= TOL_F0 * r0 and abs(raw[1, 0, f] - c) <= TOL_CONF and abs(raw[2, 0, f] - db) <= TOL_DB, (cres, f)
+        gate = dsp.PitchGate()
+        want = np.array([gate.step(raw[0, 0, f], raw[1, 0, f], raw[2, 0, f]) for f in range(frames)])
+        assert np.array_equal(want, f0[0], equal_nan=True)
