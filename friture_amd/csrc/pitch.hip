@@ -216,8 +216,8 @@ __global__ void __launch_bounds__(256) pitch_level_from_blocks_kernel(const Pitc
 // first use, i.e. after the next pair was requested, draining it as well).  The next pair's 64-byte S rows and
 // matrix elements are then in flight during the 64 FMAs of the current pair.
 __global__ void __launch_bounds__(256) pitch_strength_kernel(const double* __restrict__ kt, const double* __restrict__ s,
-                                                             double* __restrict__ strength, int L, int Lp, int Kp,
-                                                             long long n_frames) {
+                                                             double* __restrict__ strength, const int* __restrict__ lrange,
+                                                             int L, int Lp, int Kp, long long n_frames) {
     static_assert(kFramesPerWave == kFramesPerGroup && kCandPerLane == 4, "tile: 4 candidates x 8 frames per lane");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -258,9 +258,13 @@ __global__ void __launch_bounds__(256) pitch_strength_kernel(const double* __res
         }
     };
     constexpr int kLgkm0 = 0xC07F;     // s_waitcnt lgkmcnt(0), vmcnt / expcnt untouched
+    // The kernel matrix is banded (a candidate's kernel is zero below a quarter of its frequency and above its
+    // last harmonic: 26 % exact zeros on the widget's grid): the rows in which ALL 256 candidates of this block
+    // are zero are skipped — exact, since S is finite (or NaN throughout, which any live row propagates).
+    const int l_begin = lrange[2 * blockIdx.y], l_end = lrange[2 * blockIdx.y + 1];      // multiples of 4
     Pair a, b;
-    fetch(0, a);
-    for (int l = 0; l < Lp; l += 4) {
+    fetch(l_begin, a);
+    for (int l = l_begin; l < l_end; l += 4) {
         // sched_barrier: keep the machine scheduler from sinking the look-ahead loads down to their first use
         __builtin_amdgcn_s_waitcnt(kLgkm0);
         fetch(l + 2, b);
@@ -413,13 +417,13 @@ struct frt_pitch {
     frt_stft* stft = nullptr;
     hipStream_t stream = nullptr;
     size_t scratch_limit = 1ull << 30;
-    DeviceBuffer freqs, jidx, kt, psd, s, strength, raw, prev, eb, stage_in, stage_out;
+    DeviceBuffer freqs, jidx, kt, lrange, psd, s, strength, raw, prev, eb, stage_in, stage_out;
 };
 
 extern "C" void frt_pitch_destroy(frt_pitch* h) {
     if (!h) return;
     if (h->stft) frt_stft_destroy(h->stft);
-    DeviceBuffer* bufs[] = {&h->freqs, &h->jidx, &h->kt, &h->psd, &h->s, &h->strength, &h->raw, &h->prev, &h->eb, &h->stage_in, &h->stage_out};
+    DeviceBuffer* bufs[] = {&h->freqs, &h->jidx, &h->kt, &h->lrange, &h->psd, &h->s, &h->strength, &h->raw, &h->prev, &h->eb, &h->stage_in, &h->stage_out};
     for (auto* b : bufs) b->release();
     delete h;
 }
@@ -493,8 +497,25 @@ extern "C" int frt_pitch_create(frt_pitch** out, int fft_size, int hop, int n_ch
     std::vector<double> kt((size_t)(h->Lp + 4) * h->Kp, 0.0);      // rows L .. Lp+3 stay zero (look-ahead of the strength kernel)
     for (int c = 0; c < n_candidates; ++c)
         for (int l = 0; l < n_log; ++l) kt[(size_t)l * h->Kp + c] = kernels[(size_t)c * n_log + l];
+    // grid rows [begin, end) in which a block of 256 candidates has any non-zero factor, widened to multiples of 4
+    std::vector<int> lrange(2 * (h->Kp / kCandPerWave), 0);
+    for (int blk = 0; blk < h->Kp / kCandPerWave; ++blk) {
+        int first = -1, last = -1;
+        for (int l = 0; l < n_log; ++l) {
+            bool any = false;
+            for (int c = blk * kCandPerWave; c < (blk + 1) * kCandPerWave && !any; ++c) any = kt[(size_t)l * h->Kp + c] != 0.0;
+            if (any) {
+                if (first < 0) first = l;
+                last = l;
+            }
+        }
+        if (first >= 0) {
+            lrange[2 * blk] = first / 4 * 4;
+            lrange[2 * blk + 1] = (last + 4) / 4 * 4;          // <= Lp
+        }
+    }
     std::vector<double> fr(log_freqs, log_freqs + n_log);
-    if ((rc = upload(h->freqs, fr)) || (rc = upload(h->jidx, jidx)) || (rc = upload(h->kt, kt)) ||
+    if ((rc = upload(h->freqs, fr)) || (rc = upload(h->jidx, jidx)) || (rc = upload(h->kt, kt)) || (rc = upload(h->lrange, lrange)) ||
         (rc = h->prev.reserve(n_channels * sizeof(double))) || (rc = frt_pitch_reset(h))) {
         frt_pitch_destroy(h);
         return rc;
@@ -583,7 +604,7 @@ extern "C" int frt_pitch_track(frt_pitch* h, const double* x, int64_t T, int64_t
         } else {
             hipLaunchKernelGGL(pitch_level_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, h->stream, a);
         }
-        hipLaunchKernelGGL(pitch_strength_kernel, dim3(blocks, h->Kp / kCandPerWave), dim3(256), 0, h->stream, a.kt, a.s, a.strength,
+        hipLaunchKernelGGL(pitch_strength_kernel, dim3(blocks, h->Kp / kCandPerWave), dim3(256), 0, h->stream, a.kt, a.s, a.strength, h->lrange.as<int>(),
                            h->L, h->Lp, h->Kp, total);
         hipLaunchKernelGGL(pitch_pick_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, h->stream, a);
         FRT_HIP_CHECK(hipGetLastError());
