@@ -17,12 +17,6 @@
 // Three barriers per frame, 74 KB of LDS for N = 16384 -> two 512-thread workgroups per CU.
 #pragma once
 
-#ifndef FRT_BIG10_STREAM
-#define FRT_BIG10_STREAM 0
-#endif
-#ifndef FRT_BIG10_RS
-#define FRT_BIG10_RS 0
-#endif
 #ifndef FRT_BIG_ABLATE          // experiment builds only: 1 no row stores, 2 no sample loads after the first frame, 4 no sub-transforms
 #define FRT_BIG_ABLATE 0
 #endif
@@ -69,7 +63,7 @@ struct BigPlan {
     static constexpr int LOG2MS = LOG2M - 4;
     static constexpr int MS = M / 16;                       // threads per frame = sub-transform length
     static constexpr int TPFS = MS / 8;                     // threads per sub-transform
-    static constexpr int RS = (FRT_BIG10_RS && MS == 64) ? FRT_BIG10_RS : lds_padded_size(MS) + 2;   // region stride (complex): conflict-free column reads
+    static constexpr int RS = lds_padded_size(MS) + 2;      // region stride (complex): conflict-free column reads
     // One frame per workgroup.  (Workgroups of 256 threads serving 4 / 2 frames at N = 2048 / 4096 tied unrelated
     // frames to the same three barriers per frame: a wave held up behind its row stores held up three others — 19 %
     // at N = 2048.  At N = 2048 the workgroup is one wavefront and the barriers compile to nothing.)
@@ -134,24 +128,18 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
     // 8-16 frames: +37 % at N = 16384 (one 512-thread workgroup per CU either way), +9...15 % at 4096 / 8192 (two
     // 256-thread workgroups per CU instead of three), +3 % at 2048.
     constexpr bool HOIST1 = LOG2M >= 10 && sizeof(T) == 4;
-    // experiment (-DFRT_BIG10_STREAM=1): at N = 2048 the window pairs and inter-stage twiddles are re-read from L1/L2
-    // every frame (62 registers less: three waves per SIMD instead of two)
-    constexpr bool HOISTA = HOIST1 && !(FRT_BIG10_STREAM && LOG2M == 10);
-    C tw1[HOISTA ? 15 : 1];
-    C winr[HOISTA ? 16 : 1];                    // the thread's 16 window pairs, same condition
+    C tw1[HOIST1 ? 15 : 1];
+    C winr[HOIST1 ? 16 : 1];                    // the thread's 16 window pairs, same condition
     C twur[HOIST1 ? 8 : 1];                     // and the 8 unpack factors exp(-2 pi i k / N), k = t + q Ms
     // ... and the dB / colour-index offsets of the thread's 16 bins
     constexpr bool HOISTW = HOIST1;
     T wgr[HOISTW ? 16 : 1];
-    T wg_nyq = (T)0;                            // weight of bin N/2 (thread 0 stores it)
-    wg_nyq = (wgt && a.kind != FRT_STFT_PSD) ? wgt[M / 2] : (T)0;
-    if constexpr (HOISTA) {
+    const T wg_nyq = (wgt && a.kind != FRT_STFT_PSD) ? wgt[M / 2] : (T)0;      // weight of bin N/2 (thread 0 stores it)
+    if constexpr (HOIST1) {
 #pragma unroll
         for (int k0 = 1; k0 < 16; ++k0) tw1[k0 - 1] = tw[(t * k0) & (M - 1)];
 #pragma unroll
         for (int j = 0; j < 16; ++j) winr[j] = win[t + j * MS];
-    }
-    if constexpr (HOIST1) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             twur[q] = twn[t + q * MS];
@@ -172,12 +160,7 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
 #pragma unroll
         for (int j = 0; j < 16; ++j) nx[j] = nfr > 0 ? x0[j * MS] : C{(T)0, (T)0};
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            C w;
-            if constexpr (HOISTA) w = winr[j];
-            else w = win[t + j * MS];
-            nx[j] = C{nx[j].x * w.x, nx[j].y * w.y};
-        }
+        for (int j = 0; j < 16; ++j) nx[j] = C{nx[j].x * winr[j].x, nx[j].y * winr[j].y};      // nx holds WINDOWED samples
     }
     // one frame = M complex = 8 M bytes = M / 128 wave-instructions of 1 KB, dealt round-robin to the wavefronts
     auto stage_frame = [&](long long frame) {
@@ -207,11 +190,6 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
         // butterfly ahead of the arithmetic so that at most two groups of samples + window are in flight
         // (all sixteen at once would need 64 more registers and halve the occupancy)
         C v[16];
-        int zero_s = zero;
-        auto wv = [&](int j) -> C {
-            if constexpr (HOISTA) return winr[j];
-            else return win[t + j * MS + zero_s];
-        };
         if constexpr (PREFETCH) {
             // the frame's 16 samples were requested during the previous frame's sub-transforms (or before the loop)
 #pragma unroll
@@ -240,7 +218,7 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 d[p] = valid ? xf[(4 * p) * MS] : C{(T)0, (T)0};
-                if constexpr (HOISTA) w[p] = winr[4 * p];
+                if constexpr (HOIST1) w[p] = winr[4 * p];
                 else w[p] = wf[(4 * p) * MS];
             }
 #pragma unroll
@@ -249,7 +227,7 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         dn[p] = valid ? xf[(m + 1 + 4 * p) * MS] : C{(T)0, (T)0};
-                        if constexpr (HOISTA) wn[p] = winr[m + 1 + 4 * p];
+                        if constexpr (HOIST1) wn[p] = winr[m + 1 + 4 * p];
                         else wn[p] = wf[(m + 1 + 4 * p) * MS];
                     }
                 }
@@ -266,7 +244,7 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
         // ---- 2. twiddle exp(-2 pi i t k0 / M), transpose through LDS ----------------------------------------
 #pragma unroll
         for (int k0 = 1; k0 < 16; ++k0) {
-            if constexpr (HOISTA) v[k0] = cmul(v[k0], tw1[k0 - 1]);
+            if constexpr (HOIST1) v[k0] = cmul(v[k0], tw1[k0 - 1]);
             else v[k0] = cmul(v[k0], tw[((t * k0) & (M - 1)) + zero]);
         }
 #pragma unroll
@@ -319,11 +297,9 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
             // guarded by vmcnt(0) = wait for the acknowledgement of every store of every frame (measured: the stores
             // then cost 44 % of the kernel's time at N = 2048).  Here vmcnt(0) covers loads that have had both
             // sub-transform rounds to arrive, plus stores that are a whole frame old.
-            zero_s = 0;
-            asm volatile("s_mov_b32 %0, 0" : "=s"(zero_s));
 #pragma unroll
             for (int j2 = 0; j2 < 16; ++j2) {
-                const C w = wv(j2);
+                const C w = winr[j2];
                 nx[j2] = C{nx[j2].x * w.x, nx[j2].y * w.y};
                 asm volatile("" : "+v"(nx[j2].x), "+v"(nx[j2].y));      // the products exist here: not sunk to their use
             }
