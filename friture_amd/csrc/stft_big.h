@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
         __syncthreads();
         if constexpr (DMA) {
             // every thread has read its samples of this frame: the staging buffer is free for the next one
-            if (g + 1 < nfr) stage_frame(f0 + g + 1);
+            if (g + 1 < nfr && !((FRT_BIG_ABLATE & 2) && a.n_frames > 0)) stage_frame(f0 + g + 1);
         }
         // ---- 3. sixteen wave-local transforms of length Ms over t, two rounds of eight ----------------------
 #pragma unroll 1
