@@ -88,6 +88,10 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
     __shared__ C lds[GPB * 16 * RS];
     __shared__ uint32_t lut_lds[256];
     __shared__ __attribute__((aligned(16))) C stage[DMA ? M : 1];
+    // float64 re-reads its sub-transform twiddles at every use (no registers to hold them): from a copy of the table
+    // in LDS — a global load there is an exposed L2 round trip per pass, and it queues behind the row stores
+    constexpr bool TWLDS = sizeof(T) == 8;
+    __shared__ __attribute__((aligned(16))) C tws_lds[TWLDS ? MS : 1];
 
     const int tid = threadIdx.x;
     const int grp = tid / MS;
@@ -96,6 +100,9 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
 
     if (a.kind == FRT_STFT_IMAGE) {
         for (int q = tid; q < 256; q += BLOCK) lut_lds[q] = a.lut[q];
+    }
+    if constexpr (TWLDS) {
+        for (int q = tid; q < MS; q += BLOCK) tws_lds[q] = ((const C*)a.tws)[q];      // visible after the loop's first barrier
     }
 
     const int gg = blockIdx.x * GPB + grp;
@@ -278,7 +285,7 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
             if constexpr (TWREG) {
                 fft_pow2_forward<T, B::LOG2MS, true>(u, buf, si, twr);
             } else {
-                TwTable<T, B::LOG2MS> twt{(const C*)a.tws, zero};
+                TwTable<T, B::LOG2MS> twt{tws_lds, zero};
                 fft_pow2_forward<T, B::LOG2MS, true>(u, buf, si, twt);
             }
             pass_sync<true>();
