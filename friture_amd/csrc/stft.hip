@@ -18,6 +18,7 @@
 // wave).  For N <= 1024 a frame lives inside one wavefront: pass exchanges need no barrier and the
 // conjugate-symmetric unpack is done with wavefront shuffles instead of LDS.
 #include <cmath>
+#include <type_traits>
 
 #include "common.h"
 #include "fft_core.h"
@@ -47,6 +48,12 @@ struct StftArgs {
     int vec2;              // 1: 2-sample vector loads are aligned
     double norm_off;       // -spec_min
     double norm_scale;     // 1 / (spec_max - spec_min)
+    // float32 IMAGE kind, exact colour indices (see exact_colour_index)
+    const double* edge_pow;// [256] power at which the unweighted index value reaches n: 10^((min + n (max - min)/255)/10)
+    const double* bin_pow; // [M+1] 10^(-weight[k]/10)
+    float edge2;           // width of the zone above an index edge that is decided in float64
+    int rising;            // max > min: the index grows with the power
+    int eps_free;          // P + 1e-30 == P in float32 wherever it matters: the add is skipped
 #ifdef FRT_ABLATE
     int ablate;            // experiment switches: 1 no stores, 2 no loads, 4 no FFT, 8 no unpack shuffles
 #endif
@@ -64,6 +71,39 @@ __device__ __forceinline__ double log2_t(double v) { return log2(v); }
 template <typename T>
 __device__ __forceinline__ T shfl_t(T v, int lane) { return __shfl(v, lane, 64); }
 
+// ---- colour index of the IMAGE kind --------------------------------------------------------------------------
+// The reference computes, in float64 (spectrogram.py:119-129, color_tranform.py:48-51, lookup_table.py:50-52),
+//     idx = int(clip((10 log10(P + 1e-30) + w[k] - min) / (max - min), 0, 1) * 255).
+// The float32 instances evaluate q = gain * log2(P + 1e-30) + wimage[k] (one v_log_f32 and one fma per bin;
+// wimage carries weight, range and a margin `thr`), whose distance from the float64 value is below `thr` (bound
+// derived in frt_stft_set_epilogue).  So floor(q) IS the reference's index unless q lies within 2 thr above an
+// integer n (about 3e-4 of all bins); there the index is n or n - 1, and because the reference's expression is
+// monotonic in P the choice is one float64 comparison:  idx >= n  <=>  P + 1e-30 >= 10^((min + n (max-min)/255 - w[k])/10)
+// = edge_pow[n] * bin_pow[k] (host tables, 1e-16 relative).  The colour index is therefore exact given the float32
+// power P — what remains against the reference's image is the float32 transform's own error in P.
+// Such bins are served one at a time with wave-uniform operands: the two table values arrive through SCALAR loads
+// (lgkmcnt).  A vector load here would have to be waited for with vmcnt(0), i.e. behind the acknowledgement of every row
+// store still in flight — measured: +7 % on the whole kernel for a path that one frame in five enters.
+__device__ __forceinline__ int exact_colour_index(bool near_edge, float p, int k, int n, const StftArgs& a) {
+    unsigned long long todo = __ballot(near_edge);
+    const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int ks = __builtin_amdgcn_readlane(k, src), ns = __builtin_amdgcn_readlane(n, src);
+        const float ps = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p), src));
+        // constant address space + uniform index = s_load_dwordx2 (the tables are never written by a kernel)
+        typedef const double __attribute__((address_space(4))) * ktable;
+        const double edge = ((ktable)(uintptr_t)a.edge_pow)[ns] * ((ktable)(uintptr_t)a.bin_pow)[ks];
+        const bool at_least = ((double)ps + 1e-30 >= edge) == (a.rising != 0);
+        if (lane == src) n = at_least ? ns : ns - 1;
+    }
+    return n;
+}
+// q clamped into the LUT's range: [0, 0.5) and everything below share index 0 (no edge there), 255.5 maps to 255
+__device__ __forceinline__ float clamp_index(float q) { return __builtin_amdgcn_fmed3f(q, 0.5f, 255.5f); }
+__device__ __forceinline__ double clamp_index(double q) { return fmin(fmax(q, 0.5), 255.5); }
+
 // Row stores.  Plain by default.  Non-temporal stores (-DFRT_NT_STORES) keep the rows from evicting the samples
 // out of L2 / the Infinity Cache: a batch that is re-used or was just produced is then read 15 % faster, but a batch
 // read cold from HBM — the benchmark's case — runs 3 % slower and writes 5 % more bytes (the L2 lets go of
@@ -78,6 +118,14 @@ __device__ __forceinline__ void stream_store(T* p, T v) {
 }
 
 // TIN: sample type in HBM; T: arithmetic type; SHIFT: register slots a hop advances (0 = reload all)
+// three waves per SIMD for the one-wave-per-frame instances: the float64 fix-up of the IMAGE kind would otherwise push the
+// N = 512 / 1024 instances two registers over the 168 that three waves allow (no spills at hop N/2 and N/4)
+#ifndef FRT_WAVE_MIN_WAVES
+#define FRT_WAVE_MIN_WAVES 3
+#endif
+#ifndef FRT_EXACT_MODE      // experiments (tools/exp): 0 no edge check, 1 check with an empty rare path, 2 the product
+#define FRT_EXACT_MODE 2
+#endif
 template <typename TIN, typename T, int LOG2M, int SHIFT>
 __global__ void
 #if defined(FRT_WAVE_MIN_WAVES)
@@ -158,7 +206,12 @@ stft_kernel(const StftArgs a) {
     auto load_slot = [&](long long f, int j) -> C {
         const long long s = f * a.hop + 2 * (i + j * TPF);
         if (a.vec2) {
+#ifdef FRT_NT_LOADS
+            typedef TIN vin2 __attribute__((ext_vector_type(2)));
+            vin2 v = __builtin_nontemporal_load((const vin2*)(xc + s));
+#else
             CIN v = *(const CIN*)(xc + s);
+#endif
             return {(T)v.x, (T)v.y};
         }
         return {(T)xc[s], (T)xc[s + 1]};
@@ -168,6 +221,8 @@ stft_kernel(const StftArgs a) {
     C raw[8], nxt[NEW];
 #pragma unroll
     for (int j = 0; j < 8; ++j) raw[j] = {(T)0, (T)0};
+#pragma unroll
+    for (int t = 0; t < NEW; ++t) nxt[t] = {(T)0, (T)0};
     if (nfr > 0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) raw[j] = load_slot(f0, j);
@@ -275,11 +330,18 @@ stft_kernel(const StftArgs a) {
         // Advance the register window by one hop *before* the stores are issued: the wait for the
         // prefetched samples then sits behind a whole transform (latency hidden) and ahead of this
         // frame's stores, so it never has to wait for store acknowledgements.
-        if (g + 1 < nfr) {
+        // (Unconditional although only meaningful when a prefetch was issued: with the shift under the prefetch's own
+        // condition the compiler's wait-count pass sees a path "loads issued, wait skipped" into the next trip and,
+        // depending on register assignment, guards the top of the loop with vmcnt(0..3) — i.e. with the acknowledgement
+        // of this frame's row stores: +5 % when the IMAGE kind's rare path changed the assignment.)
+        {
 #pragma unroll
             for (int j = 0; j < 8 - NEW; ++j) raw[j] = raw[j + NEW];
 #pragma unroll
             for (int t = 0; t < NEW; ++t) raw[8 - NEW + t] = nxt[t];
+            // the new slots exist HERE, in front of the stores (otherwise the moves sink to the loop latch, behind them)
+#pragma unroll
+            for (int t = 0; t < NEW; ++t) asm volatile("" : "+v"(raw[8 - NEW + t].x), "+v"(raw[8 - NEW + t].y));
         }
 
 #ifdef FRT_ABLATE
@@ -319,17 +381,120 @@ stft_kernel(const StftArgs a) {
                 if (a.kind == FRT_STFT_IMAGE) {
                     // colour words are 4 bytes whatever the arithmetic type
                     uint32_t* prow = (uint32_t*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
-                    auto pix = [&](T p, T w) -> uint32_t {
-                        T v = image_gain * log2_t(p + (T)1e-30) + w;
-                        v = fmin(fmax(v, (T)0), (T)255);      // NaN -> 0
-                        return lut_lds[(int)v];
-                    };
+                    // float32: with the dB floor below the LUT's range everywhere, P + 1e-30 rounds to P for every P that
+                    // is not clamped to index 0 anyway, and the add is left out (eps_free, frt_stft_set_epilogue)
+                    auto colour_row = [&](auto eps_free) {
+                        constexpr bool EPS_FREE = decltype(eps_free)::value;
+                        auto index_value = [&](T pw, T w) -> T {
+                            if constexpr (EPS_FREE) return clamp_index(image_gain * log2_t(pw) + w);
+                            else return clamp_index(image_gain * log2_t(pw + (T)1e-30) + w);
+                        };
+                        T q[9];
+                        uint32_t colour[9];
+#ifdef FRT_EXACT_STASH
+                        // the nine powers wait in the frame's (idle) FFT scratch for the rare path instead of in registers
+                        float* stash = (float*)buf;
+                        if constexpr (WAVE && sizeof(T) == 4) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        stream_store(prow + klo + j * TPF, pix(res[j], wl[j]));
-                        stream_store(prow + khi - j * TPF, pix(res[4 + j], wh[j]));
-                    }
-                    if (i == 0) stream_store(prow + M / 2, pix(res_mid, wdb_mid));
+                            for (int j = 0; j < 8; ++j) stash[j * TPF + i] = res[j];
+                            stash[8 * TPF + i] = res_mid;
+                        }
+#endif
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            q[j] = index_value(res[j], wl[j]);
+                            q[4 + j] = index_value(res[4 + j], wh[j]);
+                        }
+                        q[8] = index_value(res_mid, wdb_mid);               // stored by thread 0 only
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) colour[j] = lut_lds[(int)q[j]];
+#ifdef FRT_EXACT_DEFER
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            stream_store(prow + klo + j * TPF, colour[j]);
+                            stream_store(prow + khi - j * TPF, colour[4 + j]);
+                        }
+                        if (i == 0) stream_store(prow + M / 2, colour[8]);
+#endif
+                        if constexpr (sizeof(T) == 4 && FRT_EXACT_MODE != 0) {
+                            // Bins within 2 thr above an index edge (3e-4 of them) are decided in float64 (exact_colour_index).
+                            // The LUT reads above are issued first, with the float32 index, so that the frame's only branch
+                            // sits behind them and in front of nothing but the stores; the rare path recomputes what it
+                            // needs from the powers (nothing but those nine values and the colours stays live across it).
+                            float fmin9 = i == 0 ? __builtin_amdgcn_fractf(q[8]) : 1.f;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) fmin9 = fminf(fmin9, __builtin_amdgcn_fractf(q[j]));
+#if FRT_EXACT_MODE == 1
+                            if (__any(fmin9 < a.edge2)) colour[0] ^= 1u;
+#elif FRT_EXACT_MODE == 2
+                            if (__any(fmin9 < a.edge2)) {
+                                // ONE instance of the float64 decision: every lane with such a bin picks its first one
+                                // (select chains over the nine register slots), the wave serves those lanes one after the
+                                // other (exact_colour_index), and the colour goes back through a select chain; a lane with
+                                // two such bins in one frame (1e-5 of the frames) goes round again.
+                                // (the index values are recomputed from the powers here — bit-identical, same operations —
+                                // so that only the nine powers, not the nine index values as well, stay live across the branch)
+                                uint32_t pend = 0;
+#ifdef FRT_EXACT_STASH
+                                pass_sync<true>();
+                                auto power = [&](int j) -> T { return WAVE ? (T)stash[j * TPF + i] : j < 8 ? res[j] : res_mid; };
+#else
+                                auto power = [&](int j) -> T { return j < 8 ? res[j] : res_mid; };
+#endif
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    pend |= (__builtin_amdgcn_fractf(index_value(power(j), wl[j])) < a.edge2 ? 1u : 0u) << j;
+                                    pend |= (__builtin_amdgcn_fractf(index_value(power(4 + j), wh[j])) < a.edge2 ? 1u : 0u) << (4 + j);
+                                }
+                                if (i == 0) pend |= (__builtin_amdgcn_fractf(index_value(power(8), wdb_mid)) < a.edge2 ? 1u : 0u) << 8;
+#pragma unroll 1
+                                while (__any(pend != 0)) {
+                                    const int jsel = pend ? __ffs(pend) - 1 : 0;
+                                    T psel = power(8), wsel = wdb_mid;
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) {
+#ifndef FRT_EXACT_STASH
+                                        psel = jsel == j ? res[j] : jsel == 4 + j ? res[4 + j] : psel;
+#endif
+                                        wsel = jsel == j ? wl[j] : jsel == 4 + j ? wh[j] : wsel;
+                                    }
+#ifdef FRT_EXACT_STASH
+                                    if constexpr (WAVE) {
+                                        psel = (T)stash[jsel * TPF + i];
+                                    } else {
+#pragma unroll
+                                        for (int j = 0; j < 8; ++j) psel = jsel == j ? res[j] : psel;
+                                    }
+#endif
+                                    const T qsel = index_value(psel, wsel);
+                                    const int ksel = jsel < 4 ? klo + jsel * TPF : jsel < 8 ? khi - (jsel - 4) * TPF : M / 2;
+                                    const uint32_t c = lut_lds[exact_colour_index(pend != 0, psel, ksel, (int)qsel, a)];
+#ifdef FRT_EXACT_DEFER
+                                    if (pend != 0) stream_store(prow + ksel, c);
+#else
+#pragma unroll
+                                    for (int j = 0; j < 9; ++j) colour[j] = (pend != 0 && jsel == j) ? c : colour[j];
+#endif
+                                    pend &= pend - 1;
+                                }
+                            }
+#endif
+                        }
+#ifndef FRT_EXACT_DEFER
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            stream_store(prow + klo + j * TPF, colour[j]);
+                            stream_store(prow + khi - j * TPF, colour[4 + j]);
+                        }
+                        if (i == 0) stream_store(prow + M / 2, colour[8]);
+#endif
+                    };
+#ifdef FRT_NO_EPSFREE
+                    if (false) colour_row(std::true_type{});
+#else
+                    if (sizeof(T) == 4 && a.eps_free) colour_row(std::true_type{});
+#endif
+                    else colour_row(std::false_type{});
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -433,7 +598,9 @@ struct frt_stft {
     int run_length = 0;
     bool force_generic = false;   // A/B and tests: a negative run length selects the generic kernel
     hipStream_t stream = nullptr;
-    DeviceBuffer window, tw, twn, tws, weight, wimage, lut;
+    DeviceBuffer window, tw, twn, tws, weight, wimage, edge_pow, bin_pow, lut;
+    bool eps_free = false;
+    float edge2 = 0.f;            // see exact_colour_index
     bool has_weight = false, has_lut = false;
     double spec_min = -140.0, spec_max = 0.0;
     DeviceBuffer stage_in, stage_out;
@@ -504,6 +671,8 @@ extern "C" void frt_stft_destroy(frt_stft* h) {
     h->tws.release();
     h->weight.release();
     h->wimage.release();
+    h->edge_pow.release();
+    h->bin_pow.release();
     h->lut.release();
     h->stage_in.release();
     h->stage_out.release();
@@ -533,12 +702,39 @@ extern "C" int frt_stft_set_epilogue(frt_stft* h, const double* weight_db, doubl
     // per-bin offset of the colour index (IMAGE kind), weighting and dB range folded in
     const double span = spec_max - spec_min;
     if (h->precision == 32) {
+        // q = fma(gain, L, wimage[k]) in float32, L = v_log_f32(P + 1e-30), against v * 255 in float64.  Error terms, in
+        // index units, for a q inside the LUT's range (|q| < 256, hence |gain L| < |wimage| + 256):
+        //   v_log_f32: 1 ulp of its result (ISA), |L| < 128                      gain * 2^-17
+        //   P + 1e-30 rounded (or left out: eps_free, relative 2^-24.7)          gain * 1.45 * 2^-24
+        //   gain rounded to float32                                              2^-24 (|wimage| + 256)
+        //   wimage[k] rounded to float32                                         2^-24 |wimage|
+        //   the fma's single rounding                                            2^-24 * 256
+        // thr = their sum (+5 %); wimage carries +thr, so the float64 value lies in (q - 2 thr, q) and the kernel
+        // re-decides exactly the bins with fract(q) < 2 thr.
+        const double gain = std::fabs(255.0 * 3.01029995663981195 / span);
+        double wmax = 0.0;
+        for (int k = 0; k < nb; ++k)
+            wmax = std::fmax(wmax, std::fabs(255.0 * ((weight_db ? weight_db[k] : 0.0) - spec_min) / span));
+        const double eps24 = 1.0 / 16777216.0;
+        const double thr = 1.05 * (gain * (1.0 / 131072.0 + 1.5 * eps24) + eps24 * (2.0 * (wmax + 1.0) + 512.0));
+        h->edge2 = (float)(2.0 * thr);
         std::vector<float> w(nb), wi(nb);
+        std::vector<double> bp(nb), ep(256);
+        double wmax_db = -1e300;
         for (int k = 0; k < nb; ++k) {
-            w[k] = weight_db ? (float)weight_db[k] : 0.f;
-            wi[k] = (float)(255.0 * ((weight_db ? weight_db[k] : 0.0) - spec_min) / span);
+            const double wk = weight_db ? weight_db[k] : 0.0;
+            w[k] = (float)wk;
+            wi[k] = (float)(255.0 * (wk - spec_min) / span + thr);
+            bp[k] = std::pow(10.0, -wk / 10.0);
+            wmax_db = std::fmax(wmax_db, wk);
         }
-        if ((rc = upload(h->weight, w)) || (rc = upload(h->wimage, wi))) return rc;
+        for (int n = 0; n < 256; ++n) ep[n] = std::pow(10.0, (spec_min + n * (span / 255.0)) / 10.0);
+        // P < 2^-75 (2.6e-23) is where P + 1e-30 differs from P in float32; if even there, with the largest weight, the
+        // index value stays below 0, every such bin is clamped to index 0 with or without the 1e-30
+        h->eps_free = span > 0 && (10.0 * std::log10(2.7e-23) + wmax_db - spec_min) / span * 255.0 + thr < 0.0;
+        if ((rc = upload(h->weight, w)) || (rc = upload(h->wimage, wi)) || (rc = upload(h->edge_pow, ep)) ||
+            (rc = upload(h->bin_pow, bp)))
+            return rc;
     } else {
         std::vector<double> w(nb), wi(nb);
         for (int k = 0; k < nb; ++k) {
@@ -551,6 +747,7 @@ extern "C" int frt_stft_set_epilogue(frt_stft* h, const double* weight_db, doubl
     if (lut256) {
         std::vector<uint32_t> l(lut256, lut256 + 256);
         if ((rc = upload(h->lut, l))) return rc;
+
     }
     h->spec_min = spec_min;
     h->spec_max = spec_max;
@@ -585,6 +782,12 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     a.vec2 = (h->hop % 2 == 0) && (x_stride % 2 == 0) && (((uintptr_t)d_x) % (2 * esz) == 0);
     a.norm_off = -h->spec_min;
     a.norm_scale = 1.0 / (h->spec_max - h->spec_min);
+    a.edge_pow = h->edge_pow.as<double>();
+    a.bin_pow = h->bin_pow.as<double>();
+    a.edge2 = h->edge2;
+    if (const char* e = getenv("FRT_EDGE_SCALE")) a.edge2 *= (float)atof(e);      // experiments only (tools/exp)
+    a.rising = h->spec_max > h->spec_min;
+    a.eps_free = h->eps_free;
 #ifdef FRT_ABLATE
     a.ablate = getenv("FRT_ABLATE") ? atoi(getenv("FRT_ABLATE")) : 0;
 #endif

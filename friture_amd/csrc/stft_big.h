@@ -78,7 +78,7 @@ struct BigPlan {
 // T: float (every optimisation below) or double (the transform structure only: no register-resident constants, no
 // prefetch, no staging — the float64 instance serves the drop-in / pitch-tracker path, twice the registers and LDS).
 template <typename T, int LOG2M, bool DMA>
-__global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const StftArgs a) {
+__global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK, sizeof(T) == 4 ? 2 : 1) stft_big_kernel(const StftArgs a) {
     using B = BigPlan<LOG2M>;
     using C = cpx<T>;
     static_assert(!DMA || sizeof(T) == 4, "LDS staging is a float32 feature");
@@ -320,9 +320,14 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
                 if (a.kind == FRT_STFT_PSD) {
                     row[k] = p;
                 } else if (a.kind == FRT_STFT_IMAGE) {
-                    T vv = image_gain * log2_t(p + (T)1e-30) + w;
-                    vv = fmin(fmax(vv, (T)0), (T)255);
-                    prow[k] = lut_lds[(int)vv];
+                    const T vv = clamp_index(image_gain * log2_t(p + (T)1e-30) + w);
+                    int idx = (int)vv;
+                    if constexpr (sizeof(T) == 4) {
+                        // within 2 thr above an index edge: one float64 comparison decides (stft.hip, exact_colour_index)
+                        const bool near_edge = __builtin_amdgcn_fractf(vv) < a.edge2;
+                        if (__any(near_edge)) idx = exact_colour_index(near_edge, p, k, idx, a);
+                    }
+                    prow[k] = lut_lds[idx];
                 } else {
                     T vv = db10<T>(p) + w;
                     if (a.kind == FRT_STFT_NORM) vv = (vv + norm_off) * norm_scale;
@@ -330,21 +335,65 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK) stft_big_kernel(const S
                 }
             };
             auto weight_at = [&](int k) -> T { return wgt ? wgt[k + zero] : (T)0; };
-            auto pair = [&](int q, C wk, T wlo, T whi) {
+            auto pair_powers = [&](int q, C wk, T& plo, T& phi) {
                 const int k = t + q * MS;                    // k < M/2
                 const C A = zat(k), Bc = cconj(zat(M - k));
                 const C S = A + Bc, D = A - Bc;
                 const C tt = cmul(wk, D);
                 const T ar = S.x + tt.y, ai = S.y - tt.x, br = S.x - tt.y, bi = S.y + tt.x;
-                finish_store(k, ar * ar + ai * ai, wlo);
-                finish_store(M - k, br * br + bi * bi, whi);
+                plo = ar * ar + ai * ai;
+                phi = br * br + bi * bi;
+            };
+            auto pair = [&](int q, C wk, T wlo, T whi) {
+                T plo, phi;
+                pair_powers(q, wk, plo, phi);
+                finish_store(t + q * MS, plo, wlo);
+                finish_store(M - t - q * MS, phi, whi);
+            };
+            // IMAGE kind, float32: four bins at a time — index values, LUT reads (issued with the float32 index), ONE
+            // near-edge test for the four, stores.  A test per bin put a branch, and behind it an exposed LUT read,
+            // between every two of the thread's 17 stores (+8 % on the kernel).
+            auto image4 = [&](const int (&k)[4], const T (&pw)[4], const T (&w)[4]) {
+                T vv[4];
+                uint32_t c[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vv[e] = clamp_index(image_gain * log2_t(pw[e] + (T)1e-30) + w[e]);
+                    c[e] = lut_lds[(int)vv[e]];
+                }
+                if constexpr (sizeof(T) == 4) {
+                    const float m = fminf(fminf(__builtin_amdgcn_fractf(vv[0]), __builtin_amdgcn_fractf(vv[1])),
+                                          fminf(__builtin_amdgcn_fractf(vv[2]), __builtin_amdgcn_fractf(vv[3])));
+                    if (__any(m < a.edge2)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const bool near_edge = __builtin_amdgcn_fractf(vv[e]) < a.edge2;
+                            const int n = exact_colour_index(near_edge, pw[e], k[e], (int)vv[e], a);
+                            if (near_edge) c[e] = lut_lds[n];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) prow[k[e]] = c[e];
             };
             if constexpr (HOIST1) {
+                if (sizeof(T) == 4 && HOISTW && a.kind == FRT_STFT_IMAGE && !(FRT_BIG_ABLATE & 1)) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    if constexpr (HOISTW) pair(q, twur[q], wgr[q], wgr[8 + q]);
-                    else pair(q, twur[q], a.kind == FRT_STFT_PSD ? (T)0 : weight_at(t + q * MS),
-                              a.kind == FRT_STFT_PSD ? (T)0 : weight_at(M - t - q * MS));
+                    for (int q = 0; q < 8; q += 2) {
+                        T pw[4];
+                        pair_powers(q, twur[q], pw[0], pw[1]);
+                        pair_powers(q + 1, twur[q + 1], pw[2], pw[3]);
+                        const int k[4] = {t + q * MS, M - t - q * MS, t + (q + 1) * MS, M - t - (q + 1) * MS};
+                        const T w[4] = {wgr[q], wgr[8 + q], wgr[q + 1], wgr[8 + q + 1]};
+                        image4(k, pw, w);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if constexpr (HOISTW) pair(q, twur[q], wgr[q], wgr[8 + q]);
+                        else pair(q, twur[q], a.kind == FRT_STFT_PSD ? (T)0 : weight_at(t + q * MS),
+                                  a.kind == FRT_STFT_PSD ? (T)0 : weight_at(M - t - q * MS));
+                    }
                 }
             } else {
                 // float64: the eight unpack factors (and the weights of the dB kinds) are ALL requested before the

@@ -131,6 +131,49 @@ def colour_pixels(lut: np.ndarray, values: np.ndarray) -> np.ndarray:
     return lut[(v * 255).astype(np.intp)]
 
 
+def colour_index(psd, weight_db, spec_min, spec_max):
+    """The reference's float64 epilogue applied to a given power spectrum: returns (idx, v255) with
+    v255 = clip((10 log10(P + 1e-30) + w - min)/(max - min), 0, 1) * 255 and idx = int(v255)
+    — friture/spectrogram.py:119-129,161-162, friture/signal/color_tranform.py:48-51,
+    friture/signal/lookup_table.py:50-52."""
+    db = log_spectrum(np.asarray(psd, np.float64))
+    if weight_db is not None:
+        db = db + np.asarray(weight_db)[None, :]
+    v255 = np.clip(normalise(db, spec_min, spec_max), 0.0, 1.0) * 255
+    return v255.astype(np.intp), v255
+
+
+def image_parity(image, psd_same_path, psd_reference, weight_db, spec_min, spec_max, lut, edge=1e-6):
+    """Parity accounting of a colour image (pixel-exact except where v*255 is within
+    `edge` of an integer).  `psd_same_path` is the power spectrum the image was derived from (the
+    float32 PSD of the same frames), `psd_reference` the reference's float64 PSD or None.  Separates
+    the two sources of a differing pixel: the epilogue itself (dB -> normalise -> index -> LUT, which
+    must be exact given its input) and the float32 transform's error in P moving a bin across an edge."""
+    lut = np.asarray(lut)
+    image = np.asarray(image).view(np.uint32)
+    idx, v255 = colour_index(psd_same_path, weight_db, spec_min, spec_max)
+    frac = v255 - np.floor(v255)
+    near = (frac < edge) | (frac > 1.0 - edge)
+    bad = image != lut[idx]
+    out = {"pixels_checked": int(image.size),
+           "epilogue_mismatched": int(np.sum(bad)),
+           "epilogue_mismatch_outside_edge": int(np.sum(bad & ~near)),
+           "edge": edge}
+    if psd_reference is not None:
+        ridx, r255 = colour_index(psd_reference, weight_db, spec_min, spec_max)
+        rfrac = r255 - np.floor(r255)
+        rnear = (rfrac < edge) | (rfrac > 1.0 - edge)
+        rbad = image != lut[ridx]
+        out["pixels_mismatched"] = int(np.sum(rbad))
+        out["mismatch_outside_edge"] = int(np.sum(rbad & ~rnear))
+        # how far the float32 power moved the index value of the differing pixels
+        out["max_index_shift_of_mismatch"] = float(np.max(np.abs(v255 - r255)[rbad])) if np.any(rbad) else 0.0
+        ref = np.asarray(psd_reference, np.float64)
+        out["psd_rel_max"] = float(np.max(np.max(np.abs(np.asarray(psd_same_path, np.float64) - ref), axis=-1)
+                                          / np.max(ref, axis=-1)))
+    return out
+
+
 def spectrogram_image(x, n_fft, hop, weight_db, spec_min, spec_max, lut):
     """STFT -> dB + weighting -> normalise -> colour, without the screen-space resamplers
     (friture/spectrogram.py:147-162 followed directly by Color_Transform.push)."""
