@@ -1043,7 +1043,19 @@ extern "C" int frt_octbank_filter(frt_octbank* h, const double* x, int n, double
     const int64_t plen = frt_octbank_packed_length(h, n);
     const bool dx = is_device_pointer(x), dy = is_device_pointer(y_packed);
     FRT_REQUIRE(dx == dy, "frt_octbank_filter: input and output must both be host or both be device memory");
-    if (h->mode == 1) FRT_REQUIRE(n <= 1024, "frt_octbank_filter: the FFT bank takes blocks of at most 1024 samples (got %d)", n);
+    // mode 1: up to 1024 samples is the reference's own call (one overlap-add block, its FFT sizes); a longer input is
+    // processed AS IF fed in 1024-sample blocks (the reference itself would crop it to its first stage's FFT size)
+    if (h->mode == 1 && n > 1024) {
+        if (dx) return frt_ola_filter_batch(h, x, 0, n, y_packed, plen, nullptr, 0, 0, nullptr);
+        int rc;
+        const size_t in_bytes = (size_t)h->n_channels * n * sizeof(double), out_bytes = (size_t)h->n_channels * plen * sizeof(double);
+        if ((rc = h->xin.reserve(in_bytes)) || (rc = h->ypacked.reserve(out_bytes))) return rc;
+        FRT_HIP_CHECK(hipMemcpyAsync(h->xin.ptr, x, in_bytes, hipMemcpyHostToDevice, h->stream));
+        if ((rc = frt_ola_filter_batch(h, h->xin.ptr, 0, n, h->ypacked.as<double>(), plen, nullptr, 0, 0, nullptr))) return rc;
+        FRT_HIP_CHECK(hipMemcpyAsync(y_packed, h->ypacked.ptr, out_bytes, hipMemcpyDeviceToHost, h->stream));
+        FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+        return FRT_OK;
+    }
     if (dx) return h->mode == 1 ? frt_ola_filter(h, x, n, y_packed, plen) : run_stages(h, x, 0, n, n, y_packed, plen, nullptr, 0, 0);
     return filter_host(h, x, n, y_packed, plen);
 }
@@ -1051,8 +1063,8 @@ extern "C" int frt_octbank_filter(frt_octbank* h, const double* x, int n, double
 extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, int block, const double* alphas,
                                     const double* weight_db, int as_db, float* energy_out) {
     FRT_REQUIRE(h && h->bpo >= 1, "frt_octbank_energies: needs a handle with bands");
-    FRT_REQUIRE(h->mode == 0, "frt_octbank_energies: batch energies run on the exact IIR bank (mode 0)");
     FRT_REQUIRE(block >= 256 && (block & (block - 1)) == 0, "frt_octbank_energies: block %d must be a power of two >= 256", block);
+    FRT_REQUIRE(h->mode == 0 || block <= 1024, "frt_octbank_energies: the FFT bank's cadence is blocks of at most 1024 samples");
     FRT_REQUIRE(n > 0 && n % block == 0 && n < (1ll << 31), "frt_octbank_energies: n must be a positive multiple of block");
     FRT_REQUIRE(h->chunk0 == 0 || h->chunk0 % block == 0, "frt_octbank_energies: chunk must be a multiple of block");
     FRT_REQUIRE(x && alphas && energy_out, "frt_octbank_energies: null buffer");
@@ -1081,7 +1093,9 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
         d_x = h->xin.ptr;
         d_out = h->eout.as<float>();
     }
-    if ((rc = run_stages(h, d_x, 1, n, (int)n, nullptr, 0, h->eblock.as<double>(), block, nblocks))) return rc;
+    if (h->mode == 1) rc = frt_ola_filter_batch(h, d_x, 1, n, nullptr, 0, h->eblock.as<double>(), block, nblocks, alphas);
+    else rc = run_stages(h, d_x, 1, n, (int)n, nullptr, 0, h->eblock.as<double>(), block, nblocks);
+    if (rc) return rc;
     hipLaunchKernelGGL(energy_scan_kernel, dim3(h->n_channels), dim3(kEnergyThreads), 0, h->stream, h->eblock.as<double>(),
                        h->decay_n.as<double>(), h->smooth.as<double>(), (void*)d_out, 1, nblocks, h->nbands,
                        weight_db ? h->weight.as<double>() : nullptr, as_db);

@@ -25,6 +25,15 @@ struct frt_ola_state {
     frt::MixedPlan plan[frt::kNOctave];
     frt::DeviceBuffer tw[frt::kNOctave], twl[frt::kNOctave], H[frt::kNOctave];
     frt::DeviceBuffer pending;          // [9][C][nfilt][511]
+    // batched path (ola.hip, ola_batch_kernel): one transform size for every stage, tables built at the first batched call;
+    // its launches read the tails of `pending` and write the new ones to `pending_next`, then the two swap
+    frt::DeviceBuffer pending_next;
+    frt::MixedPlan bplan;
+    frt::DeviceBuffer btw, btwl, bH, ewt;
+    std::vector<long long> ewt_off;     // per band: offset of its smoothing weights in ewt
+    int ewt_block = 0;
+    std::vector<double> ewt_alpha;
+    std::vector<double> h_taps;         // [nfilt][512] kept for the lazily built tables
 };
 
 struct frt_octbank {
@@ -66,3 +75,7 @@ int frt_ola_create(frt_octbank* h, const double* boct_fir, const double* bdec_fi
 void frt_ola_destroy(frt_octbank* h);
 int frt_ola_reset(frt_octbank* h);
 int frt_ola_filter(frt_octbank* h, const double* d_x, int n, double* d_y, int64_t y_cstride);
+// batched: x [C][n] (float when x_f32) as if fed in blocks of <= 1024 samples; band signals to d_y (nullable) and / or
+// zero-state block energies for blocks of eblock0 input samples to d_eblock [C][nblocks][nbands] (nullable)
+int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, double* d_y, int64_t y_cstride,
+                         double* d_eblock, int eblock0, int nblocks, const double* alphas);

@@ -149,6 +149,9 @@ int frt_ola_create(frt_octbank* h, const double* boct_fir, const double* bdec_fi
     h->ola = o;
     const int nfilt = h->nfilt;
     int rc;
+    o->h_taps.resize((size_t)nfilt * kFirLength);
+    for (int f = 0; f < nfilt; ++f)
+        memcpy(&o->h_taps[(size_t)f * kFirLength], f < h->bpo ? boct_fir + (size_t)f * kFirLength : bdec_fir, kFirLength * sizeof(double));
     for (int j = 0; j < kNOctave; ++j) {
         const int F = next_smooth_size((1024 >> j) + kFirLength - 1);     // filter_design.py:399-402
         const int M = F / 2;
@@ -192,6 +195,11 @@ void frt_ola_destroy(frt_octbank* h) {
         h->ola->H[j].release();
     }
     h->ola->pending.release();
+    h->ola->pending_next.release();
+    h->ola->btw.release();
+    h->ola->btwl.release();
+    h->ola->bH.release();
+    h->ola->ewt.release();
     delete h->ola;
     h->ola = nullptr;
 }
@@ -232,5 +240,265 @@ int frt_ola_filter(frt_octbank* h, const double* d_x, int n, double* d_y, int64_
         hipLaunchKernelGGL(ola_stage_kernel, dim3(h->nfilt, h->n_channels), dim3(kOlaThreads), 0, h->stream, a);
         FRT_HIP_CHECK(hipGetLastError());
     }
+    return FRT_OK;
+}
+
+
+// ---- batched overlap-add bank ---------------------------------------------------------------------------------------
+// Octave_Filters.filter fed block after block (octavefilters.py:49-58 -> filter.py:136-247) IS, per stage, the running
+// convolution of the stage input with a 512-tap FIR: the per-block overlap-add (pending tails added into the next blocks,
+// filter.py:213-245) only fixes the order in which the same products are summed, and every block of the 1024-sample
+// cadence has an even length at every stage, so the per-block decimation y[:N_s:2] picks the even samples of the whole
+// stream.  Nothing in a stage depends on an earlier block of the SAME stage except through those 511-sample tails — no
+// recurrence — so a stage of a long batch is one launch over (block, filter group, channel):
+//   * a workgroup takes kObL = 3072 output samples of the stage and reads their 3072 + 511 input samples (overlap-save:
+//     the 511 samples in front replace the neighbour's tail; in front of the batch they are zeros and the carried tails
+//     `pend_in` are added to the first 511 outputs instead, exactly the reference's state),
+//   * ONE forward real FFT of length 4096 (complex 2048, fft_mixed.h), kept in LDS as X[0..2048],
+//   * per filter of its group: Y = X H_f, inverse, then band output / decimated stage output / block energies straight
+//     from LDS; the workgroup holding the end of the stage also writes the new tails (its window ends in 511 + zeros).
+// 4096 = 3072 + 511 + 511 + 2: the circular convolution never wraps into a sample that is used.
+constexpr int kObF = 4096, kObM = kObF / 2, kObL = 3072, kObThreads = 256, kObMaxB = (kObM / 2 + kObThreads - 1) / kObThreads;
+
+struct OlaBatchArgs {
+    const void* x;             // [C][x_stride] stage input: float (x_f32) or double
+    int x_f32;
+    long long x_stride;
+    long long n;               // samples of this stage per channel
+    MixedPlan plan;
+    const double* tw;          // [M] exp(-2 pi i t / M)
+    const double* twl;         // [M+1] exp(-2 pi i k / F)
+    const double* H;           // [nfilt][M+1]
+    const double* pend_in;     // [C][nfilt][kTail]
+    double* pend_out;
+    int nfilt, dec_filter, gsize;
+    double* y;                 // packed band outputs or null
+    long long y_cstride;
+    long long y_off[kMaxFilters];
+    double* xnext;             // [C][xnext_stride] or null
+    long long xnext_stride;
+    double* eblock;            // [C][nblocks][nbands] or null
+    int elen;                  // samples of this stage per energy block (power of two, divides kObL)
+    int nblocks, nbands;
+    int band_index[kMaxFilters];
+    const double* ewt;         // smoothing weights alpha (1 - alpha)^(elen - 1 - i), per band at ewt_off
+    long long ewt_off[kMaxFilters];
+};
+
+__global__ void __launch_bounds__(kObThreads) ola_batch_kernel(const OlaBatchArgs a) {
+    using C = cpx<double>;
+    __shared__ C buf[kObM];
+    __shared__ C spec[kObM + 1];
+    constexpr int M = kObM, F = kObF;
+    const int tid = threadIdx.x;
+    const int blk = blockIdx.x, grp = blockIdx.y, c = blockIdx.z;
+    const long long o0 = (long long)blk * kObL;                  // first output sample of this workgroup
+    const int Lb = (int)((a.n - o0) < kObL ? (a.n - o0) : kObL); // its outputs
+    const bool first = blk == 0, last = o0 + Lb == a.n;
+    const C* tw = (const C*)a.tw;
+    const C* twl = (const C*)a.twl;
+
+    // window position p <-> stage sample o0 - 511 + p; z[q] = w[2q] + i w[2q+1]
+    {
+        const long long s0 = o0 - kTail;
+        const float* xf = (const float*)a.x + (long long)c * a.x_stride;
+        const double* xd = (const double*)a.x + (long long)c * a.x_stride;
+        auto sample = [&](long long s) -> double {
+            if (s < 0 || s >= a.n) return 0.0;
+            return a.x_f32 ? (double)xf[s] : xd[s];
+        };
+        for (int q = tid; q < M; q += kObThreads) buf[q] = {sample(s0 + 2 * q), sample(s0 + 2 * q + 1)};
+    }
+    __syncthreads();
+    fft_mixed_forward<double, kObMaxB>(buf, tw, a.plan, tid, kObThreads);
+    for (int k = tid; k <= M; k += kObThreads) {                 // X[k], k = 0..M
+        const C A = buf[k == M ? 0 : k];
+        const C B = cconj(buf[k == 0 ? 0 : M - k]);
+        const C S = A + B, D = A - B;
+        const C t = cmul(twl[k], D);
+        spec[k] = {0.5 * (S.x + t.y), 0.5 * (S.y - t.x)};
+    }
+    __syncthreads();
+
+    double* out = (double*)buf;                                  // the finished window, plain doubles, after each inverse
+    const double inv = 1.0 / (double)M;
+    for (int fi = 0; fi < a.gsize; ++fi) {
+        const int f = grp * a.gsize + fi;
+        if (f >= a.nfilt) break;
+        const C* H = (const C*)a.H + (size_t)f * (M + 1);
+        // Y = X H packed for the inverse: Z[k] = ((A + B) + i conj(w^k) (A - B)) / 2 with A = Y[k], B = conj Y[M-k], conjugated
+        for (int k = tid; k < M; k += kObThreads) {
+            C A = cmul(spec[k], H[k]);
+            C Bm = cmul(spec[M - k], H[M - k]);
+            if (k == 0) { A.y = 0.0; Bm.y = 0.0; }              // irfft ignores the imaginary part of the edge bins
+            const C B = cconj(Bm);
+            const C S = A + B, D = A - B;
+            const C t = cmul(cconj(twl[k]), D);
+            buf[k] = {0.5 * (S.x - t.y), -0.5 * (S.y + t.x)};
+        }
+        __syncthreads();
+        fft_mixed_forward<double, kObMaxB>(buf, tw, a.plan, tid, kObThreads);     // conj(FFT(conj Z)) = M ifft(Z)
+        const double* pin = a.pend_in + ((size_t)c * a.nfilt + f) * kTail;
+        // finish the window in place: scale / sign, carried tails on the first 511 outputs of the batch
+        for (int q = tid; q < M; q += kObThreads) {
+            const C v = buf[q];
+            double e = v.x * inv, o = -v.y * inv;
+            if (first) {
+                const int t0 = 2 * q - kTail;                    // output index of the even slot
+                if (t0 >= 0 && t0 < kTail && t0 < Lb) e += pin[t0];
+                if (t0 + 1 >= 0 && t0 + 1 < kTail && t0 + 1 < Lb) o += pin[t0 + 1];
+            }
+            buf[q] = {e, o};
+        }
+        __syncthreads();
+        const double* res = out + kTail;                         // res[t]: output o0 + t, t < Lb (t >= Lb: the tail)
+        if (f == a.dec_filter) {
+            if (a.xnext) {
+                double* xn = a.xnext + (long long)c * a.xnext_stride + o0 / 2;      // o0 is even
+                for (int m = tid; 2 * m < Lb; m += kObThreads) xn[m] = res[2 * m];
+            }
+        } else {
+            if (a.y) {
+                double* y = a.y + (long long)c * a.y_cstride + a.y_off[f] + o0;
+                for (int t = tid; t < Lb; t += kObThreads) y[t] = res[t];
+            }
+            if (a.eblock) {
+                // zero-state block energies alpha sum_i (1-alpha)^(m-1-i) y_i^2 (exp_smoothing.py:40-56): groups of
+                // w = min(m, 64) lanes per energy block, fixed summation order
+                const int m = a.elen, w = m < 64 ? m : 64, per_wave = 64 / w;
+                const int lane = tid & 63, wave = tid >> 6, sub = lane / w, li = lane - sub * w;
+                const double* wt = a.ewt + a.ewt_off[f];
+                const int ne = Lb / m;
+                double* eo = a.eblock + ((size_t)c * a.nblocks + (size_t)(o0 / m)) * a.nbands + a.band_index[f];
+                for (int e0 = wave * per_wave; e0 < ne; e0 += (kObThreads / 64) * per_wave) {
+                    const int le = e0 + sub;
+                    double acc = 0.0;
+                    if (le < ne)
+                        for (int i2 = li; i2 < m; i2 += w) {
+                            const double v = res[le * m + i2];
+                            acc += wt[i2] * (v * v);
+                        }
+                    for (int d = w >> 1; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+                    if (le < ne && li == 0) eo[(size_t)le * a.nbands] = acc;
+                }
+            }
+        }
+        if (last) {
+            double* po = a.pend_out + ((size_t)c * a.nfilt + f) * kTail;
+            for (int t = tid; t < kTail; t += kObThreads) {
+                double v = res[Lb + t];                          // 511 + Lb + 510 < 4096
+                if (first && a.n + t < kTail) v += pin[a.n + t]; // a batch shorter than the tails it inherited
+                po[t] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static int ola_batch_tables(frt_octbank* h) {
+    frt_ola_state* o = h->ola;
+    if (o->bH.ptr) return FRT_OK;
+    FRT_REQUIRE(make_mixed_plan(kObM, &o->bplan), "ola batch: bad FFT size");
+    int rc;
+    if ((rc = upload(o->btw, make_twiddles<double>(kObM))) || (rc = upload(o->btwl, make_twiddles<double>(kObF, kObM + 1)))) return rc;
+    // H_f[k] = sum_t h_f[t] exp(-2 pi i k t / F): the rfft of the zero-padded taps (filter_design.py computes the same
+    // with numpy at the reference's own sizes)
+    const int nfilt = h->nfilt;
+    std::vector<long double> ct(kObF), st(kObF);
+    const long double pi2 = 6.283185307179586476925286766559L;
+    for (int t = 0; t < kObF; ++t) {
+        ct[t] = cosl(pi2 * t / kObF);
+        st[t] = sinl(pi2 * t / kObF);
+    }
+    std::vector<double> Hh((size_t)nfilt * (kObM + 1) * 2);
+    for (int f = 0; f < nfilt; ++f) {
+        const double* taps = &o->h_taps[(size_t)f * kFirLength];
+        for (int k = 0; k <= kObM; ++k) {
+            long double re = 0, im = 0;
+            for (int t = 0; t < kFirLength; ++t) {
+                const int idx = (k * t) & (kObF - 1);
+                re += taps[t] * ct[idx];
+                im -= taps[t] * st[idx];
+            }
+            Hh[((size_t)f * (kObM + 1) + k) * 2] = (double)re;
+            Hh[((size_t)f * (kObM + 1) + k) * 2 + 1] = (double)im;
+        }
+    }
+    if ((rc = upload(o->bH, Hh))) return rc;
+    if ((rc = o->pending_next.reserve(o->pending.bytes))) return rc;
+    return FRT_OK;
+}
+
+int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, double* d_y, int64_t y_cstride,
+                         double* d_eblock, int eblock0, int nblocks, const double* alphas) {
+    frt_ola_state* o = h->ola;
+    int rc;
+    if ((rc = ola_batch_tables(h))) return rc;
+    long long len[kNOctave];
+    len[0] = n;
+    for (int j = 1; j < kNOctave; ++j) len[j] = (len[j - 1] + 1) / 2;
+    for (int j = 1; j < kNOctave; ++j)
+        if ((rc = h->xbuf[j].reserve((size_t)h->n_channels * len[j] * sizeof(double)))) return rc;
+    std::vector<long long> band_off(h->nbands + 1, 0);
+    for (int k = 0; k < h->nbands; ++k) band_off[k + 1] = band_off[k] + len[kNOctave - 1 - k / h->bpo];
+    if (d_eblock) {
+        // smoothing weights per band: alpha (1 - alpha)^(m - 1 - i), m = eblock0 / dec (exp_smoothing.py:40-56 with the
+        // kernels of octavespectrum.py:77-81)
+        bool same = o->ewt_block == eblock0 && (int)o->ewt_alpha.size() == h->nbands;
+        for (int k = 0; same && k < h->nbands; ++k) same = o->ewt_alpha[k] == alphas[k];
+        if (!same) {
+            o->ewt_off.assign(h->nbands, 0);
+            std::vector<double> wt;
+            for (int k = 0; k < h->nbands; ++k) {
+                const int m = eblock0 >> (kNOctave - 1 - k / h->bpo);
+                o->ewt_off[k] = (long long)wt.size();
+                for (int i = 0; i < m; ++i) wt.push_back(alphas[k] * std::pow(1.0 - alphas[k], (double)(m - 1 - i)));
+            }
+            FRT_HIP_CHECK(hipStreamSynchronize(h->stream));      // the old table may still be read
+            if ((rc = upload(o->ewt, wt))) return rc;
+            o->ewt_block = eblock0;
+            o->ewt_alpha.assign(alphas, alphas + h->nbands);
+        }
+    }
+    const size_t stage_pend = (size_t)h->n_channels * h->nfilt * kTail;
+    for (int j = 0; j < kNOctave; ++j) {
+        OlaBatchArgs a{};
+        a.x = j == 0 ? d_x : h->xbuf[j].ptr;
+        a.x_f32 = j == 0 ? x_f32 : 0;
+        a.x_stride = len[j];
+        a.n = len[j];
+        a.plan = o->bplan;
+        a.tw = o->btw.as<double>();
+        a.twl = o->btwl.as<double>();
+        a.H = o->bH.as<double>();
+        a.pend_in = o->pending.as<double>() + (size_t)j * stage_pend;
+        a.pend_out = o->pending_next.as<double>() + (size_t)j * stage_pend;
+        a.nfilt = h->nfilt;
+        a.dec_filter = h->bpo;
+        a.y = d_y;
+        a.y_cstride = y_cstride;
+        a.eblock = d_eblock;
+        a.elen = d_eblock ? (eblock0 >> j) : 1;
+        a.nblocks = nblocks;
+        a.nbands = h->nbands;
+        a.ewt = o->ewt.as<double>();
+        for (int i = 0; i < h->bpo; ++i) {
+            const int band = (kNOctave - 1 - j) * h->bpo + i;
+            a.y_off[i] = band_off[band];
+            a.band_index[i] = band;
+            a.ewt_off[i] = d_eblock ? o->ewt_off[band] : 0;
+        }
+        a.xnext = j + 1 < kNOctave ? h->xbuf[j + 1].as<double>() : nullptr;
+        a.xnext_stride = j + 1 < kNOctave ? len[j + 1] : 0;
+        const long long nblk = (len[j] + kObL - 1) / kObL;
+        // filter groups: every workgroup repeats the forward transform of its window, so as few groups as still fill the chip
+        int groups = 1;
+        while (groups < h->nfilt && nblk * h->n_channels * groups < 2ll * device_cu_count()) ++groups;
+        a.gsize = (h->nfilt + groups - 1) / groups;
+        groups = (h->nfilt + a.gsize - 1) / a.gsize;
+        hipLaunchKernelGGL(ola_batch_kernel, dim3((unsigned)nblk, groups, h->n_channels), dim3(kObThreads), 0, h->stream, a);
+        FRT_HIP_CHECK(hipGetLastError());
+    }
+    std::swap(o->pending.ptr, o->pending_next.ptr);             // equal sizes; the streaming path and the graphs follow `pending`
     return FRT_OK;
 }

@@ -123,6 +123,45 @@ class IirBank:
         return out
 
 
+class FirBank(IirBank):
+    """One device-resident FFT overlap-add bank (the production bank of Octave_Filters.filter,
+    friture/octavefilters.py:49-58 -> friture/filter.py:136-247) for any number of channels and any batch
+    length: `filter(x)` / `energies(x, ...)` return what the reference returns when x is fed to it in blocks
+    of at most 1024 samples (512-tap minimum-phase FIRs of every IIR, 511-sample tails carried across calls).
+    Up to 1024 samples a call is the reference's own overlap-add block; longer inputs run every octave stage
+    as ONE launch over all blocks (ola_batch_kernel)."""
+
+    def __init__(self, bands_per_octave, n_channels=1, tables=None):
+        from . import filter_design
+        lib = _lib.init()
+        self._lib = lib
+        t = tables if tables is not None else filter_design.load_tables()
+        if "boct_%d" % bands_per_octave not in t:
+            raise Exception("Unknown bandsperoctave: %d" % (bands_per_octave))
+        self.bpo = bands_per_octave
+        self.nbands = NOCTAVE * self.bpo
+        self.n_channels = n_channels
+        boct = np.ascontiguousarray(np.asarray(t["boct_%d" % self.bpo], np.float64))
+        aoct = np.ascontiguousarray(np.asarray(t["aoct_%d" % self.bpo], np.float64))
+        bdec = np.ascontiguousarray(t["bdec"], np.float64)
+        adec = np.ascontiguousarray(t["adec"], np.float64)
+        fir = np.ascontiguousarray(np.asarray(t["boct_fir_%d" % self.bpo], np.float64))
+        fird = np.ascontiguousarray(t["bdec_fir"], np.float64)
+        self._h = ctypes.c_void_p()
+        _lib.check(lib.frt_octbank_create(ctypes.byref(self._h), self.bpo, n_channels, 1, boct.ctypes.data_as(_DP),
+                                          aoct.ctypes.data_as(_DP), bdec.ctypes.data_as(_DP), adec.ctypes.data_as(_DP),
+                                          fir.ctypes.data_as(_DP), fird.ctypes.data_as(_DP)))
+        self.state_length = 0
+
+    def set_chunk(self, chunk0: int):
+        raise NotImplementedError("the FIR bank has no recurrence to chunk")
+
+    def set_state(self, z):
+        raise NotImplementedError("the FIR bank's state is its pending tails: reset() zeroes them")
+
+    get_state = set_state
+
+
 def _bank_for(blow, alow, forward, feedback):
     key = (np.asarray(blow, np.float64).tobytes(), np.asarray(alow, np.float64).tobytes(),
            np.asarray(forward, np.float64).tobytes(), np.asarray(feedback, np.float64).tobytes())

@@ -86,3 +86,75 @@ def test_upstream_energy_property_on_gpu(hip):
                 e_f += [np.sum(v ** 2) for v in yf]
                 e_i += [np.sum(v ** 2) for v in yi]
         assert np.all(np.abs(e_f / e_i - 1) < 0.05)
+
+
+@pytest.mark.parametrize("bpo", [1, 3, 24])
+def test_batched_bank_equals_blockwise_reference(hip, bpo):
+    """FirBank on a long input = the reference fed in 1024-sample blocks (oracle OlaBank, pinned to
+    Octave_Filters.filter by make_golden): band signals to 1e-11 of each band's maximum, over two calls (the 511-sample
+    tails cross from a batched call into a batched call and into a streaming call), several channels."""
+    from friture_amd.filter import FirBank
+    C, n1, n2 = 2, 9 * 1024, 4 * 1024
+    x = np.stack([synth("noise", n1 + n2 + 700, 31 + c).astype(np.float64) for c in range(C)])
+    bank = FirBank(bpo, C)
+    refs = [dsp.OlaBank(bpo) for _ in range(C)]
+
+    def ref_blocks(c, seg):
+        parts = None
+        for b in range(0, seg.shape[0], 1024):
+            y, dec = refs[c].filter(seg[b:b + 1024])
+            parts = [[v] for v in y] if parts is None else [p + [v] for p, v in zip(parts, y)]
+        return [np.concatenate(p) for p in parts], dec
+
+    for seg in (x[:, :n1], x[:, n1:n1 + n2], x[:, n1 + n2:n1 + n2 + 700]):
+        got, dec = bank.filter(seg)
+        for c in range(C):
+            want, dref = ref_blocks(c, seg[c])
+            assert dec == dref
+            for k in range(9 * bpo):
+                assert got[c][k].shape == want[k].shape, (k, got[c][k].shape, want[k].shape)
+                scale = max(np.max(np.abs(want[k])), 1e-3)
+                assert np.max(np.abs(got[c][k] - want[k])) <= 1e-11 * scale, (c, k)
+
+
+def test_batched_bank_ragged_and_short_batches(hip):
+    """Batch lengths that are not multiples of 1024 or of the kernel's 3072-sample tile, odd lengths, and a batch
+    shorter than the tails it inherits (1025 .. 8191 samples), chained on one bank."""
+    from friture_amd.filter import FirBank
+    bank, ref = FirBank(3, 1), dsp.OlaBank(3)
+    x = synth("chirp", 40000, 5).astype(np.float64)
+    pos = 0
+    for n in (3073, 1025, 7777, 1024, 300, 6145, 2049):
+        seg = x[pos:pos + n]
+        pos += n
+        got, _ = bank.filter(seg[None, :])
+        parts = None
+        for b in range(0, n, 1024):
+            y, _ = ref.filter(seg[b:b + 1024])
+            parts = [[v] for v in y] if parts is None else [p + [v] for p, v in zip(parts, y)]
+        for k in range(27):
+            want = np.concatenate(parts[k])
+            assert got[0][k].shape == want.shape
+            assert np.max(np.abs(got[0][k] - want)) <= 1e-11 * max(np.max(np.abs(want)), 1e-3), (n, k)
+
+
+@pytest.mark.parametrize("bpo,block", [(3, 1024), (24, 1024), (3, 256)])
+def test_batched_bank_energies(hip, bpo, block):
+    """frt_octbank_energies on the FIR bank: smoothed band energies per block (octavespectrum.py:101-121) against the
+    oracle's OlaBank + exp smoothing fed block by block; 1e-5 is the north star's band-energy tolerance (measured 1e-12),
+    state carried across two calls."""
+    from friture_amd.filter import FirBank
+    C, nb = 2, 12
+    x = np.stack([synth("noise", 2 * nb * block, 77 + c) for c in range(C)])
+    alphas, kernels = dsp.band_smoothing_setup(bpo, 0.125)
+    bank = FirBank(bpo, C)
+    got = np.concatenate([bank.energies(x[:, :nb * block], block, alphas), bank.energies(x[:, nb * block:], block, alphas)], axis=1)
+    assert got.shape == (C, 2 * nb, 9 * bpo)
+    for c in range(C):
+        ref, prev = dsp.OlaBank(bpo), [0.0] * (9 * bpo)
+        for b in range(2 * nb):
+            y, _ = ref.filter(x[c, b * block:(b + 1) * block].astype(np.float64))
+            prev = dsp.band_energies(y, kernels, alphas, prev)
+            want = np.array(prev)
+            # (a band that has not responded yet holds rounding noise of the transform, 1e-30 of the loudest band)
+            assert np.all(np.abs(got[c, b] - want) <= 1e-5 * want + 1e-20 * want.max()), (c, b)
