@@ -90,25 +90,27 @@ __device__ __forceinline__ void dft5(cpx<T>& a0, cpx<T>& a1, cpx<T>& a2, cpx<T>&
 // Forward FFT of buf[0..n) in place; all `nthreads` threads of the workgroup must call it.
 // MAXB >= ceil((n/2) / nthreads) butterflies per thread per pass.  tw: exp(-2 pi i t / n), t < n.
 // Ends with a barrier: results are visible to the whole workgroup on return.
-template <typename T, int MAXB>
+// POW2: n is a power of two (radices 4 and 2 only): index arithmetic by masks instead of integer division.
+template <typename T, int MAXB, bool POW2 = false>
 __device__ void fft_mixed_forward(cpx<T>* buf, const cpx<T>* __restrict__ tw, const MixedPlan& plan, int tid, int nthreads) {
     const int n = plan.n;
     int p = 1;
     for (int pass = 0; pass < plan.npass; ++pass) {
         const int R = plan.radix[pass];
-        const int m = n / R;
-        const int step = n / (p * R);
+        // (POW2: R is 4 or 2 and p a power of two — shifts)
+        const int m = POW2 ? (R == 4 ? n >> 2 : n >> 1) : n / R;
+        const int step = POW2 ? (m >> (31 - __clz(p))) : n / (p * R);
         cpx<T> v[MAXB][5];
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) {
             const int j = tid + b * nthreads;
             if (j < m) {
-                const int k = j % p;
+                const int k = POW2 ? (j & (p - 1)) : j % p;
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {
                     if (q < R) {
                         cpx<T> a = buf[j + q * m];
-                        if (q > 0 && p > 1) a = cmul(a, tw[(q * k * step) % n]);
+                        if (q > 0 && p > 1) a = cmul(a, tw[POW2 ? ((q * k * step) & (n - 1)) : (q * k * step) % n]);
                         v[b][q] = a;
                     }
                 }
@@ -123,7 +125,7 @@ __device__ void fft_mixed_forward(cpx<T>* buf, const cpx<T>* __restrict__ tw, co
         for (int b = 0; b < MAXB; ++b) {
             const int j = tid + b * nthreads;
             if (j < m) {
-                const int k = j % p;
+                const int k = POW2 ? (j & (p - 1)) : j % p;
                 const int base = (j - k) * R + k;
 #pragma unroll
                 for (int q = 0; q < 5; ++q)

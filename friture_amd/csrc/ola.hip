@@ -254,18 +254,18 @@ int frt_ola_filter(frt_octbank* h, const double* d_x, int n, double* d_y, int64_
 //   * a workgroup takes kObL = 3072 output samples of the stage and reads their 3072 + 511 input samples (overlap-save:
 //     the 511 samples in front replace the neighbour's tail; in front of the batch they are zeros and the carried tails
 //     `pend_in` are added to the first 511 outputs instead, exactly the reference's state),
-//   * ONE forward real FFT of length 4096 (complex 2048, fft_mixed.h), kept in LDS as X[0..2048],
+//   * ONE forward real FFT of length 4096 (complex 2048: the STFT's radix-8 Stockham engine, fft_core.h, eight points
+//     per thread, float64), kept in LDS as X[0..2048],
 //   * per filter of its group: Y = X H_f, inverse, then band output / decimated stage output / block energies straight
 //     from LDS; the workgroup holding the end of the stage also writes the new tails (its window ends in 511 + zeros).
 // 4096 = 3072 + 511 + 511 + 2: the circular convolution never wraps into a sample that is used.
-constexpr int kObF = 4096, kObM = kObF / 2, kObL = 3072, kObThreads = 256, kObMaxB = (kObM / 2 + kObThreads - 1) / kObThreads;
+constexpr int kObF = 4096, kObM = kObF / 2, kObL = 3072, kObThreads = 256;
 
 struct OlaBatchArgs {
     const void* x;             // [C][x_stride] stage input: float (x_f32) or double
     int x_f32;
     long long x_stride;
     long long n;               // samples of this stage per channel
-    MixedPlan plan;
     const double* tw;          // [M] exp(-2 pi i t / M)
     const double* twl;         // [M+1] exp(-2 pi i k / F)
     const double* H;           // [nfilt][M+1]
@@ -287,18 +287,21 @@ struct OlaBatchArgs {
 
 __global__ void __launch_bounds__(kObThreads) ola_batch_kernel(const OlaBatchArgs a) {
     using C = cpx<double>;
-    __shared__ C buf[kObM];
-    __shared__ C spec[kObM + 1];
-    constexpr int M = kObM, F = kObF;
+    constexpr int M = kObM, F = kObF, LOG2M = 11;
+    using P = Pow2Plan<LOG2M>;
+    static_assert(P::M == M && P::TPF == kObThreads, "one thread per eight points of the 2048-point complex transform");
+    __shared__ C buf[lds_padded_size(M)];         // exchange buffer of the radix-8 passes; afterwards Z, then the finished window
+    __shared__ C spec[M + 1];                     // X[0..M]
     const int tid = threadIdx.x;
     const int blk = blockIdx.x, grp = blockIdx.y, c = blockIdx.z;
     const long long o0 = (long long)blk * kObL;                  // first output sample of this workgroup
     const int Lb = (int)((a.n - o0) < kObL ? (a.n - o0) : kObL); // its outputs
     const bool first = blk == 0, last = o0 + Lb == a.n;
-    const C* tw = (const C*)a.tw;
     const C* twl = (const C*)a.twl;
+    const TwTable<double, LOG2M> twt{(const C*)a.tw, 0};
 
-    // window position p <-> stage sample o0 - 511 + p; z[q] = w[2q] + i w[2q+1]
+    // window position p <-> stage sample o0 - 511 + p; z[q] = w[2q] + i w[2q+1]; thread tid holds q = tid + 256 j
+    C v[8];
     {
         const long long s0 = o0 - kTail;
         const float* xf = (const float*)a.x + (long long)c * a.x_stride;
@@ -307,10 +310,17 @@ __global__ void __launch_bounds__(kObThreads) ola_batch_kernel(const OlaBatchArg
             if (s < 0 || s >= a.n) return 0.0;
             return a.x_f32 ? (double)xf[s] : xd[s];
         };
-        for (int q = tid; q < M; q += kObThreads) buf[q] = {sample(s0 + 2 * q), sample(s0 + 2 * q + 1)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = tid + j * kObThreads;
+            v[j] = {sample(s0 + 2 * q), sample(s0 + 2 * q + 1)};
+        }
     }
+    fft_pow2_forward<double, LOG2M, false>(v, buf, tid, twt);    // v[j] = Z[tid + 256 j]
+    __syncthreads();                                             // the last pass's gathers are done: buf is free
+#pragma unroll
+    for (int j = 0; j < 8; ++j) buf[tid + j * kObThreads] = v[j];
     __syncthreads();
-    fft_mixed_forward<double, kObMaxB>(buf, tw, a.plan, tid, kObThreads);
     for (int k = tid; k <= M; k += kObThreads) {                 // X[k], k = 0..M
         const C A = buf[k == M ? 0 : k];
         const C B = cconj(buf[k == 0 ? 0 : M - k]);
@@ -327,28 +337,32 @@ __global__ void __launch_bounds__(kObThreads) ola_batch_kernel(const OlaBatchArg
         if (f >= a.nfilt) break;
         const C* H = (const C*)a.H + (size_t)f * (M + 1);
         // Y = X H packed for the inverse: Z[k] = ((A + B) + i conj(w^k) (A - B)) / 2 with A = Y[k], B = conj Y[M-k], conjugated
-        for (int k = tid; k < M; k += kObThreads) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = tid + j * kObThreads;
             C A = cmul(spec[k], H[k]);
             C Bm = cmul(spec[M - k], H[M - k]);
             if (k == 0) { A.y = 0.0; Bm.y = 0.0; }              // irfft ignores the imaginary part of the edge bins
             const C B = cconj(Bm);
             const C S = A + B, D = A - B;
             const C t = cmul(cconj(twl[k]), D);
-            buf[k] = {0.5 * (S.x - t.y), -0.5 * (S.y + t.x)};
+            v[j] = {0.5 * (S.x - t.y), -0.5 * (S.y + t.x)};
         }
+        fft_pow2_forward<double, LOG2M, false>(v, buf, tid, twt);               // conj(FFT(conj Z)) = M ifft(Z)
         __syncthreads();
-        fft_mixed_forward<double, kObMaxB>(buf, tw, a.plan, tid, kObThreads);     // conj(FFT(conj Z)) = M ifft(Z)
         const double* pin = a.pend_in + ((size_t)c * a.nfilt + f) * kTail;
-        // finish the window in place: scale / sign, carried tails on the first 511 outputs of the batch
-        for (int q = tid; q < M; q += kObThreads) {
-            const C v = buf[q];
-            double e = v.x * inv, o = -v.y * inv;
+        // finish the window: scale / sign, carried tails on the first 511 outputs of the batch; plain doubles in LDS
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = tid + j * kObThreads;
+            double e = v[j].x * inv, o = -v[j].y * inv;
             if (first) {
                 const int t0 = 2 * q - kTail;                    // output index of the even slot
                 if (t0 >= 0 && t0 < kTail && t0 < Lb) e += pin[t0];
                 if (t0 + 1 >= 0 && t0 + 1 < kTail && t0 + 1 < Lb) o += pin[t0 + 1];
             }
-            buf[q] = {e, o};
+            out[2 * q] = e;
+            out[2 * q + 1] = o;
         }
         __syncthreads();
         const double* res = out + kTail;                         // res[t]: output o0 + t, t < Lb (t >= Lb: the tail)
@@ -375,8 +389,8 @@ __global__ void __launch_bounds__(kObThreads) ola_batch_kernel(const OlaBatchArg
                     double acc = 0.0;
                     if (le < ne)
                         for (int i2 = li; i2 < m; i2 += w) {
-                            const double v = res[le * m + i2];
-                            acc += wt[i2] * (v * v);
+                            const double val = res[le * m + i2];
+                            acc += wt[i2] * (val * val);
                         }
                     for (int d = w >> 1; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
                     if (le < ne && li == 0) eo[(size_t)le * a.nbands] = acc;
@@ -386,9 +400,9 @@ __global__ void __launch_bounds__(kObThreads) ola_batch_kernel(const OlaBatchArg
         if (last) {
             double* po = a.pend_out + ((size_t)c * a.nfilt + f) * kTail;
             for (int t = tid; t < kTail; t += kObThreads) {
-                double v = res[Lb + t];                          // 511 + Lb + 510 < 4096
-                if (first && a.n + t < kTail) v += pin[a.n + t]; // a batch shorter than the tails it inherited
-                po[t] = v;
+                double val = res[Lb + t];                        // 511 + Lb + 510 < 4096
+                if (first && a.n + t < kTail) val += pin[a.n + t];      // a batch shorter than the tails it inherited
+                po[t] = val;
             }
         }
         __syncthreads();
@@ -398,7 +412,6 @@ __global__ void __launch_bounds__(kObThreads) ola_batch_kernel(const OlaBatchArg
 static int ola_batch_tables(frt_octbank* h) {
     frt_ola_state* o = h->ola;
     if (o->bH.ptr) return FRT_OK;
-    FRT_REQUIRE(make_mixed_plan(kObM, &o->bplan), "ola batch: bad FFT size");
     int rc;
     if ((rc = upload(o->btw, make_twiddles<double>(kObM))) || (rc = upload(o->btwl, make_twiddles<double>(kObF, kObM + 1)))) return rc;
     // H_f[k] = sum_t h_f[t] exp(-2 pi i k t / F): the rfft of the zero-padded taps (filter_design.py computes the same
@@ -467,7 +480,6 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
         a.x_f32 = j == 0 ? x_f32 : 0;
         a.x_stride = len[j];
         a.n = len[j];
-        a.plan = o->bplan;
         a.tw = o->btw.as<double>();
         a.twl = o->btwl.as<double>();
         a.H = o->bH.as<double>();
