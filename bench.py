@@ -11,21 +11,31 @@ samples resident in HBM (131 071 spectra per channel per step).  A step is one p
 path over one such batch; the steps rotate over --batches distinct batches (default 3, different
 seeds, separate output buffers) so that every step reads its samples from HBM — with a single
 268 MB batch re-processed every step, part of it can survive in the 256 MB Infinity Cache between
-steps (it does when the rows are stored non-temporally; reported separately as `same_batch`).
-Before anything is timed the GPU is brought to its sustained clocks with --prewarm-ms of the same
-launches: straight after start-up a 55-launch run sits inside the clock ramp and reads 17 % slow.  With N GPUs every rank owns its own channel(s) (weak scaling, no data-path
-collective); `value` is the whole-job spectra/s: total spectra of all ranks / max-over-ranks time.
+steps (reported separately as `same_batch`).  Before anything is timed the GPU is brought to its
+sustained clocks with --prewarm-ms of the same launches: straight after start-up a 55-launch run
+sits inside the clock ramp and reads 17 % slow.  With N GPUs every rank owns its own channel(s)
+(weak scaling, no data-path collective); `value` is the whole-job spectra/s: total spectra of all
+ranks / max-over-ranks time.
 
 One JSON line is printed by rank 0; besides the contract fields it carries
   roofline      HBM roofline of the dominant kernel (stft_kernel): algorithmic bytes per launch
                 (4*hop + 4*(N/2+1) = 4100 B per spectrum) / average launch duration measured with
                 HIP events on the launch stream, against the 8 TB/s peak
-  cpu_baseline  the oracle (numpy restatement of the reference path, 1 core) timed on a bounded
-                sample of the same input on this box's host
+  parity        the colour image of the timed batch against the oracle on a sample of frames:
+                pixels checked / differing, split into "the epilogue given its float32 PSD"
+                (exact) and "float32 PSD moved a bin across an index edge"
+  cpu_baseline  the oracle (numpy restatement of the reference path, 1 core and all cores) timed on
+                a bounded sample of the same input on this box's host
+  legs          the other BASELINE configurations on this GPU's shard, each with its own roofline:
+                configs[2] 1/3-octave bank 8 ch (exact IIR time-parallel, exact IIR sequential
+                = the bit-exact mode, FIR overlap-add bank), configs[3] 16384-point STFT 32 ch,
+                configs[4] GCC-PHAT 100 window pairs + 1/24-octave bank 8 ch
+  ranks_seen    the ranks an all-gather over the job's process group returned (RCCL on GPUs)
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -38,11 +48,21 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak (MI355X_MICROARCH.md)
+F64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X float64 vector peak (the matrix rate is the same on this chip)
+SIMDS, MAX_CLOCK_HZ = 1024, 2.4e9
 
 
 def synth_channel(channel: int, n: int) -> np.ndarray:
     """S-noise of SURVEY.md §8d: 0.25 * standard_normal, seed 42 + channel, float32 PCM."""
     return (0.25 * np.random.default_rng(42 + channel).standard_normal(n, dtype=np.float32)).astype(np.float32)
+
+
+def kernel_source_digest() -> str:
+    """Digest of the K1 kernel sources: a PMC traffic figure is only quoted for the sources it was measured on."""
+    h = hashlib.sha256()
+    for name in ("stft.hip", "stft_big.h", "fft_core.h"):
+        h.update((ROOT / "friture_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(x: np.ndarray, n_fft: int, hop: int, weight, lut, budget_s: float):
@@ -90,50 +110,191 @@ def cpu_baseline(x: np.ndarray, n_fft: int, hop: int, weight, lut, budget_s: flo
     return result
 
 
-def octave_band_leg(dev, world, rank, steps=10):
-    """Second half of the BASELINE metric: octave-bands/s of the exact IIR 1/3-octave bank
-    (BASELINE configs[2]: 8 ch per GPU, 48 kHz, 2^22 samples, band energies per 1024-sample block)."""
+def image_parity_report(eng, x, image, n_fft, hop, weight, lut, frames=4096):
+    """The timed batch's colour image against the oracle on its first `frames` frames of channel 0 (outside the timed
+    region).  Three ingredients: the image the timed launches wrote, the float32 PSD the same kernel produces for the
+    same samples (PSD kind), and the oracle's float64 PSD + epilogue."""
+    import torch
+    from oracle import dsp
+    frames = min(frames, image.shape[1])
+    T = n_fft + hop * (frames - 1)
+    xs = x[:1, :T].contiguous()
+    from friture_amd.stft import StftEngine
+    e1 = StftEngine(n_fft, hop, 1, 32)
+    e1.set_epilogue(weight, -140.0, 0.0, lut)
+    psd32 = e1.psd(xs)[0].cpu().numpy()
+    img = image[0, :frames].cpu().numpy().view(np.uint32)
+    torch.cuda.synchronize()
+    psd64 = dsp.stft_psd(xs[0].cpu().numpy().astype(np.float64), n_fft, hop)
+    rep = dsp.image_parity(img, psd32, psd64, weight, -140.0, 0.0, lut)
+    rep["frames_checked"] = frames
+    rep["note"] = ("epilogue_*: GPU pixels against the reference's float64 dB -> normalise -> index -> LUT applied to the GPU's "
+                   "own float32 PSD (exact outside 1e-6 of an index edge); pixels_mismatched: against the float64 reference "
+                   "image, i.e. bins the float32 PSD error (psd_rel_max of the frame maximum) carried across an edge")
+    return rep
+
+
+def timed(fn, steps, dev, distributed, torch):
+    """`steps` calls of fn bracketed by barrier + synchronize; returns (wall seconds, HIP-event ms per call)."""
+    torch.cuda.synchronize()
+    distributed.barrier(dev)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for k in range(steps):
+        fn(k)
+    ev1.record()
+    torch.cuda.synchronize()
+    distributed.barrier(dev)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
+
+
+def prewarm(fn, seconds, torch):
+    t0, k = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(4):
+            fn(k)
+            k += 1
+        torch.cuda.synchronize()
+
+
+def leg(fn, steps, dev, distributed, torch, prewarm_s=0.15):
+    prewarm(fn, prewarm_s, torch)
+    wall, ev_ms = timed(fn, steps, dev, distributed, torch)
+    return distributed.max_over_ranks(wall, dev) / steps, distributed.max_over_ranks(ev_ms, dev)
+
+
+def octave_legs(dev, world, rank, ch, bpo, log2n, tag, with_sequential):
+    """octave-bands/s of the three bank variants on `ch` channels per GPU x 2^log2n samples, energies per 1024 samples."""
     import torch
 
     from friture_amd import distributed, filter_design
-    from friture_amd.filter import IirBank
+    from friture_amd.filter import FirBank, IirBank
     t = filter_design.load_tables()
-    ch, bpo, n = 8, 3, 1 << 22
-    bank = IirBank(t["bdec"], t["adec"], list(t[f"boct_{bpo}"]), list(t[f"aoct_{bpo}"]), ch)
-    bank.set_chunk(2048)
+    n = 1 << log2n
     x = torch.from_numpy(np.stack([synth_channel(1000 + rank * ch + c, n) for c in range(ch)])).to(dev)
     decs = [2 ** j for j in range(9)[::-1] for _ in range(bpo)]
     alphas = np.array([1.0 - (1.0 - 0.65) ** (1.0 / (1.0 * 48000 / d + 1)) for d in decs])     # octavespectrum.py:145-153
     out = torch.empty((ch, n // 1024, 9 * bpo), dtype=torch.float32, device=dev)
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.25:                 # clock ramp, see main()
-        bank.energies(x, 1024, alphas, out=out)
-        torch.cuda.synchronize()
-    distributed.barrier(dev)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        bank.energies(x, 1024, alphas, out=out)
-    torch.cuda.synchronize()
-    distributed.barrier(dev)
-    dt = distributed.max_over_ranks(time.perf_counter() - t0, dev) / steps
     units = world * ch * (n // 1024) * 9 * bpo
-    return {"value": units / dt, "unit": "octave-bands/s", "ms_per_step": dt * 1e3,
-            "config": f"exact IIR 1/3-octave bank (27 bands), {ch} ch/GPU x 2^22 samples, energies per 1024-sample block, "
-                      f"time-parallel chunks of 2048", "algorithmic_GBps": world * ch * (n // 1024) * (4096 + 4 * 27) / dt / 1e9}
+    alg_bytes = ch * (n // 1024) * (4096 + 4 * 9 * bpo)
+    # recurrence steps of the exact bank: per stage j every channel runs bpo band filters and one decimator over n / 2^j
+    # samples; a wavefront steps 16 band filters (quad slots) or 4 decimators (row slots) with 15 float64 VALU
+    # instructions of 4 issue cycles per sample
+    wave_steps = sum((n >> j) * (-(-ch * bpo // 16) + -(-ch // 4)) for j in range(9))
+    issue_bound_s = wave_steps * 15 * 4 / (SIMDS * MAX_CLOCK_HZ)
+    legs = {}
+
+    def record(name, bank, steps, mode, extra):
+        dt, ev_ms = leg(lambda k: bank.energies(x, 1024, alphas, out=out), steps, dev, distributed, torch)
+        legs[f"{tag}_{name}"] = {"value": units / dt, "unit": "octave-bands/s", "ms_per_step": dt * 1e3, "mode": mode,
+                                 "config": f"{ch} ch/GPU x 2^{log2n} samples @ 48 kHz, {9 * bpo} bands (bpo {bpo}), smoothed "
+                                           f"energies per 1024-sample block",
+                                 "roofline": dict({"algorithmic_bytes_per_step": alg_bytes,
+                                                   "hbm_frac": alg_bytes / dt / 1e9 / HBM_PEAK_GBS}, **extra(dt))}
+
+    iir = IirBank(t["bdec"], t["adec"], list(t[f"boct_{bpo}"]), list(t[f"aoct_{bpo}"]), ch)
+    chunk = 2048 if bpo <= 3 else 4096
+    iir.set_chunk(chunk)
+    record("iir_time_parallel", iir, 5,
+           f"exact IIR bank, time-parallel chunks of {chunk} samples: the same recurrences re-associated, 1e-10 of the "
+           f"input scale from the sequential (bit-exact) mode, band energies within 1e-12 (bar 1e-5)",
+           lambda dt: {"bound": "f64_valu_issue", "unit": "s", "achieved": dt, "peak": issue_bound_s, "frac": issue_bound_s / dt,
+                       "model": "sum over stages of samples x wavefront slots (16 band filters or 4 decimators per wavefront) x 15 "
+                                "float64 VALU instructions x 4 issue cycles / (1024 SIMDs x 2.4 GHz): the output pass alone; the "
+                                "time-parallel mode adds the zero-state products and chunk scans on top"})
+    if with_sequential:
+        seq = IirBank(t["bdec"], t["adec"], list(t[f"boct_{bpo}"]), list(t[f"aoct_{bpo}"]), ch)
+        xs, outs = x[:, : 1 << 16].contiguous(), torch.empty((ch, 64, 9 * bpo), dtype=torch.float32, device=dev)
+        dt, _ = leg(lambda k: seq.energies(xs, 1024, alphas, out=outs), 3, dev, distributed, torch)
+        legs[f"{tag}_iir_sequential"] = {"value": world * ch * 64 * 9 * bpo / dt, "unit": "octave-bands/s", "ms_per_step": dt * 1e3,
+                                         "mode": "exact IIR bank, sequential in time: bit-identical to the reference's recurrence",
+                                         "config": f"{ch} ch/GPU x 2^16 samples"}
+    fir = FirBank(bpo, ch, t)
+    nfilt = bpo + 1
+    tiles = sum(-(-(n >> j) // 3072) for j in range(9)) * ch
+    flops = tiles * (1 + nfilt) * (5 * 2048 * 11 + 16 * 2048)       # complex FFTs of 2048 points + pack / unpack / multiply
+    record("fir_overlap_add", fir, 5,
+           "FFT overlap-add bank (the reference's production bank, 512-tap FIRs): batched, 1e-11 of the band maximum from the "
+           "reference fed in 1024-sample blocks",
+           lambda dt: {"bound": "f64_flops", "unit": "TFLOP/s", "achieved": flops / dt / 1e12, "peak": F64_VECTOR_PEAK_TFLOPS,
+                       "frac": flops / dt / 1e12 / F64_VECTOR_PEAK_TFLOPS,
+                       "model": "tiles of 3072 outputs x (1 forward + bpo + 1 inverse) complex FFTs of 2048 points x "
+                                "(5 M log2 M + 16 M) float64 operations"})
+    return legs
 
 
-def pmc_traffic(n_fft: int, hop: int, frames: int):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary of this command, if any."""
-    p = ROOT / "profiles" / "pmc_traffic.json"
-    if not p.exists():
-        return None
-    try:
-        rec = json.loads(p.read_text())
-        if rec.get("n_fft") == n_fft and rec.get("hop") == hop and rec.get("frames") == frames:
-            return rec.get("hbm_bytes_per_launch")
-    except Exception:
+def stft16384_leg(dev, world, rank, consts):
+    """configs[3]: 256-ch batched spectrogram with 16384-point frames, 32 channels per GPU x 2^20 samples, hop N/2."""
+    import torch
+
+    from friture_amd import distributed
+    from friture_amd.stft import StftEngine
+    n_fft, hop, ch, T = 16384, 8192, 32, 1 << 20
+    from friture_amd import tables
+    weight = tables.weighting_db(tables.rfft_frequencies(n_fft), 1e-50)[0]
+    xs = [torch.from_numpy(np.stack([synth_channel(5000 + 977 * b + rank * ch + c, T) for c in range(ch)])).to(dev) for b in range(3)]
+    eng = StftEngine(n_fft, hop, ch, 32)
+    eng.set_epilogue(weight, -140.0, 0.0, consts["lut"])
+    F = eng.frames_for(T)
+    legs = {}
+    bytes_per_launch = ch * F * (4 * hop + 4 * (n_fft // 2 + 1))
+    for kind, name in ((3, "image"), (0, "psd")):
+        outs = [torch.empty((ch, F, n_fft // 2 + 1), dtype=torch.int32 if kind == 3 else torch.float32, device=dev) for _ in range(3)]
+        dt, ev_ms = leg(lambda k: eng.run(kind, xs[k % 3], outs[k % 3]), 30, dev, distributed, torch)
+        legs[f"configs3_stft16384_{name}"] = {
+            "value": world * ch * F / dt, "unit": "spectra/s", "ms_per_step": dt * 1e3,
+            "config": f"{ch} ch/GPU x 2^20 samples, N = {n_fft}, hop {hop}, "
+                      f"{'dB + A-weighting + colour LUT -> u32 pixels' if kind == 3 else 'PSD'}, three batches rotated",
+            "roofline": {"bound": "hbm", "kernel": "stft_big_kernel", "unit": "GB/s", "achieved": bytes_per_launch / (ev_ms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "frac": bytes_per_launch / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": ev_ms}}
+        del outs
+    return legs
+
+
+def gcc_leg(dev, world, rank):
+    """configs[4], first half: GCC-PHAT of 100 window pairs of L = 24000 samples (float64) per GPU."""
+    import torch
+
+    from friture_amd import distributed
+    from friture_amd.signal.correlation import GccPhat
+    L, pairs = 24000, 100
+    rng = np.random.default_rng(4242 + rank)
+    d0 = 0.25 * rng.standard_normal((pairs, L))
+    d1 = np.roll(d0, 37, axis=1) + 0.025 * rng.standard_normal((pairs, L))
+    g = GccPhat(L, pairs)
+    a0, a1 = torch.from_numpy(d0).to(dev), torch.from_numpy(d1).to(dev)
+    dt, ev_ms = leg(lambda k: g.correlate(a0, a1), 10, dev, distributed, torch)
+    _, am = g.correlate(a0, a1)
+    nbytes = pairs * 24 * L
+    return {"configs4_gcc_phat": {"value": world * pairs / dt, "unit": "windows/s", "ms_per_step": dt * 1e3,
+                                  "config": f"{pairs} window pairs/GPU, L = {L}, float64, device resident; delay 37 samples found: "
+                                            f"{bool(int(am[0]) == 37)}",
+                                  "roofline": {"bound": "hbm", "kernel": "gcc_phat_kernel", "unit": "GB/s", "achieved": nbytes / dt / 1e9,
+                                               "peak": HBM_PEAK_GBS, "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS,
+                                               "algorithmic_bytes_per_step": nbytes}}}
+
+
+class StubEngine:
+    """CPU stand-in for StftEngine, selected by --stub-engine: lets the rank logic of this file (sharding, table
+    broadcast, barriers, max-over-ranks timing, digest gather) run end to end over gloo in tests/.  It computes nothing
+    of the hot path (every 'pixel' is the channel's first sample scaled) and its JSON line says data = "stub"."""
+
+    def __init__(self, n_fft, hop, n_channels, precision):
+        self.n_fft, self.hop, self.n_channels = n_fft, hop, n_channels
+
+    def set_epilogue(self, *a):
         pass
-    return None
+
+    def frames_for(self, T):
+        return (T - self.n_fft) // self.hop + 1
+
+    def run(self, kind, x, out):
+        out[:] = (x[:, :1, None] * 1000).to(out.dtype)
+        return out
 
 
 def main():
@@ -149,21 +310,48 @@ def main():
     ap.add_argument("--batches", type=int, default=3, help="distinct input batches the steps rotate over (1 = same batch every step)")
     ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed launches before the warm-up steps (GPU clock ramp)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--stub-engine", action="store_true", help="tests only: CPU stand-in engine over gloo, see StubEngine")
     args = ap.parse_args()
 
     import torch
 
-    from friture_amd import _lib, distributed, palette, tables
-    from friture_amd.stft import StftEngine
+    from friture_amd import distributed
 
-    rank, local_rank, world = distributed.init_process_group()
+    stub = args.stub_engine
+    rank, local_rank, world = distributed.init_process_group(backend="gloo" if stub else None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP backend has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    _lib.init(local_rank)
+    if stub:
+        dev = torch.device("cpu")
+        torch.cuda.synchronize = lambda *a, **k: None                           # the stub has no device queue
+
+        class _Ev:
+            def __init__(self, **k):
+                self.t = 0.0
+
+            def record(self):
+                self.t = time.perf_counter()
+
+            def elapsed_time(self, other):
+                return (other.t - self.t) * 1e3
+        torch.cuda.Event = _Ev
+        Engine = StubEngine
+        consts = {"weight": np.zeros(args.fft_size // 2 + 1), "lut": np.zeros(256, np.uint32)}
+        if rank == 0:
+            consts = {"weight": np.linspace(-30.0, 2.0, args.fft_size // 2 + 1), "lut": np.arange(256, dtype=np.uint32) | 0xFF000000}
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP backend has no CPU fallback)")
+        from friture_amd import _lib, palette, tables
+        from friture_amd.stft import StftEngine as Engine
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        _lib.init(local_rank)
+        consts = {"weight": np.zeros(args.fft_size // 2 + 1), "lut": np.zeros(256, np.uint32)}
+        if rank == 0:
+            consts["weight"] = tables.weighting_db(tables.rfft_frequencies(args.fft_size), 1e-50)[0]
+            consts["lut"] = palette.cmr_lut()
 
     n_fft = args.fft_size
     hop = args.hop or n_fft // 2
@@ -171,82 +359,71 @@ def main():
     cpg = args.channels_per_gpu
     n_channels = cpg * world
     my_channels = distributed.shard_channels(n_channels, rank, world)
-
-    # constant tables: computed on rank 0, broadcast over RCCL so every rank uses identical bits
-    consts = {"weight": np.zeros(n_fft // 2 + 1), "lut": np.zeros(256, np.uint32)}
-    if rank == 0:
-        consts["weight"] = tables.weighting_db(tables.rfft_frequencies(n_fft), 1e-50)[0]
-        consts["lut"] = palette.cmr_lut()
+    # constant tables: computed on rank 0, broadcast (RCCL) so every rank uses identical bits
     consts = distributed.broadcast_tables(consts, src=0, device=dev)
+    ranks_seen = distributed.gather_ranks(dev)
 
     host_x = [synth_channel(c, T) for c in my_channels]
     nbatch = max(1, args.batches)
     xs = [torch.from_numpy(np.stack(host_x)).to(dev)]
     for b in range(1, nbatch):                                  # further batches: same statistics, other seeds
         xs.append(torch.from_numpy(np.stack([synth_channel(100000 * b + c, T) for c in my_channels])).to(dev))
-    x = xs[0]
-    eng = StftEngine(n_fft, hop, len(my_channels), 32)
+    eng = Engine(n_fft, hop, len(my_channels), 32)
     eng.set_epilogue(consts["weight"], -140.0, 0.0, consts["lut"])
     kind = {"image": 3, "psd": 0, "db": 1}[args.kind]
     F = eng.frames_for(T)
     outs = [torch.empty((len(my_channels), F, n_fft // 2 + 1), dtype=torch.int32 if kind == 3 else torch.float32, device=dev)
             for _ in range(nbatch)]
-    out = outs[0]
 
-    def timed(steps, rotate):
-        """K launches bracketed by one HIP event pair on the launch stream; returns (wall s, kernel ms per launch)."""
-        torch.cuda.synchronize()
-        distributed.barrier(dev)
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        for k in range(steps):
-            b = k % nbatch if rotate else 0
-            eng.run(kind, xs[b], outs[b])         # one kernel launch on torch's current stream
-        ev1.record()
-        torch.cuda.synchronize()
-        distributed.barrier(dev)
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
+    def step(k, rotate=True):
+        b = k % nbatch if rotate else 0
+        eng.run(kind, xs[b], outs[b])             # one kernel launch on torch's current stream
 
     # Clock ramp: after idle the GPU needs tens of milliseconds of continuous work before it runs at its sustained
     # clocks; 55 launches (8 ms) straight after start-up read ~17 % slow.  Pre-warm with the same launches for
     # --prewarm-ms (default 300 ms, untimed), then the contract's W warm-up steps, then the K timed steps.
-    t_pre = time.perf_counter()
-    k = 0
-    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-        for _ in range(64):
-            eng.run(kind, xs[k % nbatch], outs[k % nbatch])
-            k += 1
-        torch.cuda.synchronize()
+    if not stub:
+        prewarm(step, args.prewarm_ms * 1e-3, torch)
     for k in range(args.warmup):
-        eng.run(kind, xs[k % nbatch], outs[k % nbatch])
-    # One HIP event pair brackets the K launches on the launch stream (torch's current stream, which
-    # the C ABI launches on): average launch duration = elapsed / K.  (An event pair *per launch*
-    # would put two barrier packets between consecutive kernels and cost ~15 us per step.)
-    wall, kernel_ms = timed(args.steps, rotate=True)
+        step(k)
+    # One HIP event pair brackets the K launches on the launch stream (torch's current stream, which the C ABI launches
+    # on): average launch duration = elapsed / K.  Repeated three times for the run-to-run spread; `value` is the FIRST.
+    wall, kernel_ms = timed(step, args.steps, dev, distributed, torch)
     elapsed = distributed.max_over_ranks(wall, dev)
     kernel_ms_max = distributed.max_over_ranks(kernel_ms, dev)
+    repeats = [kernel_ms_max] + [distributed.max_over_ranks(timed(step, args.steps, dev, distributed, torch)[1], dev) for _ in range(2)]
     same_batch_ms = None
     if nbatch > 1:
-        same_batch_ms = distributed.max_over_ranks(timed(args.steps, rotate=False)[1], dev)
+        same_batch_ms = distributed.max_over_ranks(timed(lambda k: step(k, False), args.steps, dev, distributed, torch)[1], dev)
     # the same transform with its plain PSD output (no dB / weighting / colour epilogue), for reference
     psd_ms = None
-    if kind == 3:
+    if kind == 3 and not stub:
         image_outs, kind = outs, 0
         outs = [o.view(torch.float32) for o in image_outs]
         for k in range(args.warmup):
-            eng.run(kind, xs[k % nbatch], outs[k % nbatch])
-        psd_ms = distributed.max_over_ranks(timed(args.steps, rotate=True)[1], dev)
+            step(k)
+        psd_ms = distributed.max_over_ranks(timed(step, args.steps, dev, distributed, torch)[1], dev)
         outs, kind = image_outs, 3
-        eng.run(kind, xs[0], outs[0])             # leave the image of batch 0 in place for the digest
+        for b in range(nbatch):
+            step(b)                               # the images back in place (digest, parity)
+    out = outs[0]
 
     # post-batch summary gather (outside the timed region): per-channel mean pixel/PSD digest
     digest = out.to(torch.float64).mean(dim=(1, 2)).reshape(-1, 1)
     digest_all = distributed.gather_channel_summaries(digest, n_channels)
 
-    octave = octave_band_leg(dev, world, rank) if n_fft == 1024 else None
+    parity = None
+    if rank == 0 and kind == 3 and not stub:
+        parity = image_parity_report(eng, xs[0], outs[0], n_fft, hop, consts["weight"], consts["lut"])
+
+    legs = {}
+    if not stub and not args.no_legs and n_fft == 1024:
+        del xs, outs, out
+        torch.cuda.empty_cache()
+        legs.update(octave_legs(dev, world, rank, 8, 3, 22, "configs2_bank", True))
+        legs.update(stft16384_leg(dev, world, rank, consts))
+        legs.update(gcc_leg(dev, world, rank))
+        legs.update(octave_legs(dev, world, rank, 8, 24, 20, "configs4_bank", False))
 
     if rank == 0:
         spectra_per_step = n_channels * F
@@ -254,6 +431,15 @@ def main():
         bytes_per_spectrum = 4 * hop + 4 * (n_fft // 2 + 1)
         bytes_per_launch = len(my_channels) * F * bytes_per_spectrum
         achieved = bytes_per_launch / (kernel_ms_max * 1e-3) / 1e9
+        traffic = None
+        if not stub:
+            p = ROOT / "profiles" / "pmc_traffic.json"
+            try:
+                rec = json.loads(p.read_text())
+                if (rec.get("n_fft"), rec.get("hop"), rec.get("frames")) == (n_fft, hop, F) and rec.get("kernel_sources") == kernel_source_digest():
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
         result = {
             "metric": "spectra/sec (1024-pt STFT)" if n_fft == 1024 else f"spectra/sec ({n_fft}-pt STFT)",
             "value": value,
@@ -266,7 +452,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "stub" if stub else "synthetic",
             "config": {"workload": f"rolling spectrogram: {n_fft}-pt Hann STFT, hop {hop}, "
                                    f"{'dB + A-weighting + colour LUT -> u32 pixels' if kind == 3 else args.kind}, "
                                    f"{cpg} ch/GPU x 2^{args.log2_samples} samples @ 48 kHz "
@@ -275,23 +461,27 @@ def main():
                        "parallelism": f"channel-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "stft_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(n_fft, hop, F),
+                         "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch from the rocprofv3 PMC passes of this command (tools/gpu_session.sh -> "
+                                         "profiles/pmc_traffic.json), quoted only when that file was measured on these kernel sources",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernel_ms": kernel_ms_max},
+                         "kernel_ms": kernel_ms_max, "kernel_ms_repeats": repeats},
+            "ranks_seen": ranks_seen,
             "digest": float(digest_all.sum().item()),
         }
+        if parity is not None:
+            result["parity"] = parity
         if psd_ms is not None:
             result["psd_output"] = {"kernel_ms": psd_ms, "spectra_per_s": spectra_per_step / (psd_ms * 1e-3),
                                     "frac_of_hbm_peak": bytes_per_launch / (psd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "note": "same launches writing the float PSD instead of colour pixels (same byte counts)"}
         if same_batch_ms is not None:
             result["same_batch"] = {"kernel_ms": same_batch_ms, "spectra_per_s": spectra_per_step / (same_batch_ms * 1e-3) / 1.0,
-                                    "note": "the same batch every step (what a naive loop measures); with the default plain row "
-                                            "stores the rows evict the samples and this equals the rotating figure, with the "
-                                            "-DFRT_NT_STORES build the samples partly survive in the Infinity Cache; not the headline"}
-        if octave is not None:
-            result["octave_bands"] = octave
-        if world == 1 and args.cpu_budget > 0:
+                                    "note": "the same batch every step (what a naive loop measures); not the headline"}
+        if legs:
+            result["legs"] = legs
+            result["octave_bands"] = legs.get("configs2_bank_iir_time_parallel")      # the metric's second half, as in round 1
+        if world == 1 and args.cpu_budget > 0 and not stub:
             result["cpu_baseline"] = cpu_baseline(host_x[0], n_fft, hop, consts["weight"], consts["lut"], args.cpu_budget)
         print(json.dumps(result), flush=True)
 

@@ -663,9 +663,13 @@ extern "C" int frt_stft_set_epilogue(frt_stft* h, const double* weight_db, doubl
         // thr = their sum (+5 %); wimage carries +thr, so the float64 value lies in (q - 2 thr, q) and the kernel
         // re-decides exactly the bins with fract(q) < 2 thr.
         const double gain = std::fabs(255.0 * 3.01029995663981195 / span);
+        // (|wimage| over the bins that can reach the LUT's range at all: with |log2| < 128 a bin whose offset lies more than
+        // 128 gain outside [0, 256] is clamped whatever its power — bin 0 of the A curve sits at -1000 dB — and needs no margin)
         double wmax = 0.0;
-        for (int k = 0; k < nb; ++k)
-            wmax = std::fmax(wmax, std::fabs(255.0 * ((weight_db ? weight_db[k] : 0.0) - spec_min) / span));
+        for (int k = 0; k < nb; ++k) {
+            const double wk = 255.0 * ((weight_db ? weight_db[k] : 0.0) - spec_min) / span;
+            if (wk + 128.0 * gain >= 0.0 && wk - 128.0 * gain <= 256.0) wmax = std::fmax(wmax, std::fabs(wk));
+        }
         const double eps24 = 1.0 / 16777216.0;
         const double thr = 1.05 * (gain * (1.0 / 131072.0 + 1.5 * eps24) + eps24 * (2.0 * (wmax + 1.0) + 512.0));
         h->edge2 = (float)(2.0 * thr);

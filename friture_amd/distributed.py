@@ -88,6 +88,19 @@ def gather_channel_summaries(local, n_channels: int):
     return torch.cat(rows, dim=0)
 
 
+def gather_ranks(device=None) -> list:
+    """The rank ids an all-gather over the job's process group returns ([0] for a single process): evidence that the
+    collective library (RCCL on GPUs) saw every rank."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [0]
+    mine = torch.tensor([dist.get_rank()], dtype=torch.int64, device=device)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [int(p.item()) for p in parts]
+
+
 def max_over_ranks(value: float, device=None) -> float:
     import torch
     import torch.distributed as dist

@@ -63,3 +63,46 @@ def test_two_rank_gloo_roundtrip():
         p.join(120)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def test_bench_rank_logic_two_ranks_gloo():
+    """bench.py end to end with WORLD_SIZE = 2 over gloo and its CPU stand-in engine (--stub-engine): channel sharding,
+    table broadcast from rank 0, barrier-bracketed timing with max over ranks, digest all-gather, ranks_seen — the
+    contract's launch line, one JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--stub-engine", "--log2-samples", "14", "--batches", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["ranks_seen"] == [0, 1] and rec["data"] == "stub"
+    F = (2 ** 14 - 1024) // 512 + 1
+    assert rec["config"]["channels"] == 2 and rec["config"]["spectra_per_step"] == 2 * F
+    # whole-job value = spectra of all ranks / max-over-ranks time
+    assert abs(rec["value"] - 2 * F * 3 / (rec["ms_per_step"] * 3e-3)) <= 1e-6 * rec["value"]
+    # digest: both ranks' channels arrived (the stub writes 1000 * first sample of each channel)
+    import numpy as np
+    want = sum(float(np.int32(1000 * (0.25 * np.random.default_rng(42 + c).standard_normal(2 ** 14, dtype=np.float32))[0]))
+               for c in range(2))
+    assert abs(rec["digest"] - want) < 1e-6
+
+
+def test_bench_stub_single_process():
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--stub-engine", "--log2-samples", "13", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 1 and rec["ranks_seen"] == [0] and rec["roofline"]["traffic"] is None

@@ -2,18 +2,24 @@
 # One GPU-box session: parity tests, smoke, bench, rocprofv3 kernel stats + PMC traffic.  Outputs -> gpurun_out/.
 set -u
 R=$GRAFT_REPO_ROOT
+TAG=${1:-r02}
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 echo "== selftest"; timeout 300 tools/bin/stft_selftest check | tail -2
 echo "== pytest -m gpu"; timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-echo "== bench (image)"; timeout 600 python bench.py --steps 50 --warmup 5 2>&1 | tail -1 | tee gpurun_out/bench_image.json
-echo "== bench (psd)"; timeout 600 python bench.py --steps 50 --warmup 5 --kind psd --cpu-budget 0 2>&1 | tail -1 | tee gpurun_out/bench_psd.json
+echo "== bench (image, all legs)"; timeout 900 python bench.py --steps 50 --warmup 5 2>gpurun_out/bench_image.err | tail -1 | tee gpurun_out/${TAG}_bench_image.json | cut -c1-400
+echo "== bench (psd)"; timeout 600 python bench.py --steps 50 --warmup 5 --kind psd --cpu-budget 0 --no-legs 2>&1 | tail -1 | tee gpurun_out/${TAG}_bench_psd.json | cut -c1-300
 echo "== rocprofv3 kernel stats of the bench command"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/stats -o bench -- python $R/bench.py --steps 20 --warmup 3 --cpu-budget 0 > $R/gpurun_out/prof/stats.log 2>&1 )
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/stats -o bench -- python $R/bench.py --steps 20 --warmup 3 --cpu-budget 0 > $R/gpurun_out/prof/stats.log 2>&1 )
+python tools/prof_summary.py stats gpurun_out/prof/stats/bench_results.db > gpurun_out/${TAG}_bench_kernel_stats.txt 2>/dev/null; head -12 gpurun_out/${TAG}_bench_kernel_stats.txt | cut -c1-200
 echo "== rocprofv3 PMC passes of the bench command (separate passes, kernel-trace only)"
+rm -rf gpurun_out/prof/pmc_bench
 for c in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum"; do
   n=$(echo $c | cut -d' ' -f1)
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/prof/pmc_bench/$n -o p --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --cpu-budget 0 --prewarm-ms 0 > $R/gpurun_out/prof/pmc_$n.log 2>&1 ); echo "pmc $n rc=$?"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/prof/pmc_bench/$n -o p --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --cpu-budget 0 --prewarm-ms 0 --no-legs > $R/gpurun_out/prof/pmc_$n.log 2>&1 ); echo "pmc $n rc=$?"
 done
-ls gpurun_out/prof/stats | tail -2
+python tools/pmc_traffic.py gpurun_out/prof/pmc_bench && cp profiles/pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json
+python tools/prof_summary.py pmc gpurun_out/prof/pmc_bench stft_kernel > gpurun_out/${TAG}_bench_pmc_traffic.txt
+echo "== bench once more with the traffic figure of this session"
+timeout 900 python bench.py --steps 50 --warmup 5 --cpu-budget 0 --no-legs 2>/dev/null | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(json.dumps(r['roofline']))"

@@ -16,14 +16,19 @@ def stats(db_path):
     db = sqlite3.connect(db_path)
     cur = db.cursor()
     print(f"# rocprofv3 --kernel-trace --stats  ({os.path.basename(db_path)})")
-    print("# name | calls | total_us | avg_us | min_us | max_us | % | vgpr | sgpr | lds_bytes | grid | workgroup")
+    print("# vgpr / agpr: registers allocated per lane = 2 x the trace's VGPR_Count / Accum_VGPR_Count fields (on gfx950 the trace")
+    print("#   reports the allocation in units of two registers: 76 for the 149 -> 152 registers of stft_kernel<9,4>; cross-checked")
+    print("#   against hipcc -Rpass-analysis=kernel-resource-usage); waves/SIMD = min(8, 512 // (vgpr + agpr))")
+    print("# name | calls | total_us | avg_us | min_us | max_us | % | vgpr | agpr | waves/SIMD | sgpr | lds_bytes | grid | workgroup")
     total = cur.execute("select sum(duration) from kernels").fetchone()[0]
-    q = ("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), vgpr_count, sgpr_count, "
+    q = ("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), vgpr_count, accum_vgpr_count, sgpr_count, "
          "lds_size, grid_x, workgroup_x from kernels group by name order by sum(duration) desc")
-    for name, n, tot, avg, mn, mx, vg, sg, lds, grid, wg in cur.execute(q):
+    for name, n, tot, avg, mn, mx, vg, ag, sg, lds, grid, wg in cur.execute(q):
         short = name if len(name) < 100 else name[:97] + "..."
+        vg, ag = 2 * (vg or 0), 2 * (ag or 0)
+        occ = min(8, 512 // max(vg + ag, 1))
         print(f"{short} | {n} | {tot/1e3:.1f} | {avg/1e3:.2f} | {mn/1e3:.2f} | {mx/1e3:.2f} | {100*tot/total:.1f} | "
-              f"{vg} | {sg} | {lds} | {grid} | {wg}")
+              f"{vg} | {ag} | {occ} | {sg} | {lds} | {grid} | {wg}")
 
 
 def pmc(root, needle):
