@@ -66,6 +66,7 @@ SIGNATURES = {
     "frt_gcc_readout": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_void_p, c_void_p]),
     "frt_freq_resample": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "frt_time_resample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "frt_fourier_resample": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int]),
     "frt_colour_map": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "frt_exp_smooth_2d": (c_int, [c_void_p, c_int, c_double, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "frt_spectrum_post": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_int, c_double, c_void_p, c_void_p,

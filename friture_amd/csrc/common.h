@@ -42,7 +42,11 @@ struct DeviceBuffer {
     size_t bytes = 0;
     int reserve(size_t n) {
         if (n <= bytes) return FRT_OK;
-        if (ptr) (void)hipFree(ptr);
+        // growing: kernels enqueued on a caller's (non-blocking) stream may still use the old allocation
+        if (ptr) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(ptr);
+        }
         ptr = nullptr;
         bytes = 0;
         FRT_HIP_CHECK(hipMalloc(&ptr, n));
@@ -63,6 +67,19 @@ int upload(DeviceBuffer& buf, const std::vector<T>& host) {
     int rc = buf.reserve(host.size() * sizeof(T));
     if (rc) return rc;
     FRT_HIP_CHECK(hipMemcpy(buf.ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return FRT_OK;
+}
+
+// Re-upload of a table that kernels already enqueued on `stream` may still be reading (torch side streams are
+// non-blocking: a copy on the null stream is not ordered behind them): only when the values changed, and then behind
+// a synchronisation of that stream.  `cache` keeps the host copy.
+template <typename T>
+int upload_if_changed(DeviceBuffer& buf, std::vector<T>& cache, const std::vector<T>& host, hipStream_t stream) {
+    if (buf.ptr && cache == host) return FRT_OK;
+    if (buf.ptr) FRT_HIP_CHECK(hipStreamSynchronize(stream));
+    int rc = upload(buf, host);
+    if (rc) return rc;
+    cache = host;
     return FRT_OK;
 }
 

@@ -1074,10 +1074,12 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
     std::vector<double> al(alphas, alphas + h->nbands), dn(h->nbands);
     for (int k = 0; k < h->nbands; ++k)      // (1 - alpha)^n with n = block / dec samples of the band
         dn[k] = std::pow(1.0 - al[k], (double)(block >> (kNOctave - 1 - k / h->bpo)));
-    if ((rc = upload(h->alpha, al)) || (rc = upload(h->decay_n, dn)) || (rc = h->eblock.reserve(ecount * sizeof(double)))) return rc;
+    if ((rc = upload_if_changed(h->alpha, h->alpha_host, al, h->stream)) || (rc = upload_if_changed(h->decay_n, h->decay_host, dn, h->stream)) ||
+        (rc = h->eblock.reserve(ecount * sizeof(double))))
+        return rc;
     if (weight_db) {
         std::vector<double> w(weight_db, weight_db + h->nbands);
-        if ((rc = upload(h->weight, w))) return rc;
+        if ((rc = upload_if_changed(h->weight, h->weight_host, w, h->stream))) return rc;
     }
     if (!h->smooth.ptr) {
         if ((rc = h->smooth.reserve((size_t)h->n_channels * h->nbands * sizeof(double)))) return rc;
@@ -1175,13 +1177,19 @@ extern "C" int frt_lfilter_f64(const double* b, const double* a, int n_coef, con
         coef[kMaxOrder + 1 + t] = a[t];
     }
     for (int s = 0; s < order; ++s) st[s] = zi[s];
-    DeviceBuffer dcoef, dorder, dstate, dx, dy;
+    // device scratch of this entry point: grow-only, kept per calling thread (the call is synchronous and stateless; the
+    // five buffers used to be allocated and freed on every call — two hipMalloc round trips per 512-sample chunk)
+    struct Scratch {
+        DeviceBuffer coef, order, state, x, y;
+        ~Scratch() { coef.release(); order.release(); state.release(); x.release(); y.release(); }
+    };
+    static thread_local Scratch scratch;
+    DeviceBuffer &dcoef = scratch.coef, &dorder = scratch.order, &dstate = scratch.state, &dx = scratch.x, &dy = scratch.y;
     std::vector<int> ord(1, order);
     int rc;
-    auto cleanup = [&]() { dcoef.release(); dorder.release(); dstate.release(); dx.release(); dy.release(); };
+    auto cleanup = [&]() {};
     if ((rc = upload(dcoef, coef)) || (rc = upload(dorder, ord)) || (rc = upload(dstate, st)) ||
         (rc = dx.reserve((size_t)n * sizeof(double))) || (rc = dy.reserve((size_t)n * sizeof(double)))) {
-        cleanup();
         return rc;
     }
     hipError_t e = hipMemcpy(dx.ptr, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice);

@@ -48,6 +48,7 @@ struct frt_octbank {
     int zs_rows = 0, zs_rows_padded = 0;
     bool zero_state_by_recurrence = false;   // A/B and tests: pass 1 as a second run of the recurrence
     frt::DeviceBuffer eblock, alpha, decay_n, smooth, weight, eout;
+    std::vector<double> alpha_host, decay_host, weight_host;     // what the three tables hold (upload_if_changed)
     int power_chunk0 = -1;
     int power_n = -1;
     frt_ola_state* ola = nullptr;

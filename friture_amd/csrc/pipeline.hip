@@ -115,6 +115,51 @@ struct Staged {
     }
 };
 
+
+// ---- Fourier resampling of a column (scipy_resample.py:51-141 as used by Online_Linear_2D_resampler.set_height,
+// online_linear_2D_resampler.py:45-55): X = fft(x); keep the N = min(n, m) lowest frequencies; y = ifft(Y) * m / n.
+// A resize event, n and m a few hundred to a few thousand and of any factorisation (screen heights): two direct DFT
+// sums with table twiddles — thread k forms X[k] for the kept bins, thread j forms y[j] — O(n m) multiply-adds, no
+// length restrictions, float64.
+// kept bins in their order in Y: pos = (N + 1) / 2 from the front of X, neg = N - pos... the reference's slices are
+//   Y[0 : (N+1)//2] = X[0 : (N+1)//2]   and   Y[-(N-1)//2 :] = X[-(N-1)//2 :]   with Python's floor division of the
+// NEGATIVE number, i.e. the last ceil((N-1)/2) entries (for even N that includes the bin at -N/2).
+__global__ void __launch_bounds__(256) fourier_bins_kernel(const double* __restrict__ x, int n, int count, int npos, int nneg,
+                                                           const double* __restrict__ wn /* [n] cos, -sin of 2 pi r / n */,
+                                                           double* __restrict__ X /* [count][npos + nneg] complex */) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+    if (b >= npos + nneg) return;
+    const int k = b < npos ? b : n - nneg + (b - npos);          // bin of X
+    const double* xv = x + (size_t)v * n;
+    double re = 0.0, im = 0.0;
+    int r = 0;                                                   // (k t) mod n
+    for (int t = 0; t < n; ++t) {
+        re += xv[t] * wn[2 * r];
+        im += xv[t] * wn[2 * r + 1];
+        r += k;
+        if (r >= n) r -= n;
+    }
+    double* o = X + ((size_t)v * (npos + nneg) + b) * 2;
+    o[0] = re;
+    o[1] = im;
+}
+
+__global__ void __launch_bounds__(256) fourier_synth_kernel(const double* __restrict__ X, int n, int m, int count, int npos, int nneg,
+                                                            const double* __restrict__ wm /* [m] cos, +sin of 2 pi r / m */,
+                                                            double* __restrict__ y /* [count][m] */) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+    if (j >= m) return;
+    const double* Xv = X + (size_t)v * (npos + nneg) * 2;
+    double acc = 0.0;
+    for (int b = 0; b < npos + nneg; ++b) {
+        const int kk = b < npos ? b : m - nneg + (b - npos);     // position in Y
+        const int r = (int)(((long long)kk * j) % m);
+        acc += Xv[2 * b] * wm[2 * r] - Xv[2 * b + 1] * wm[2 * r + 1];      // Re(X e^{+i...})
+    }
+    // ifft's 1/m times the reference's m/n
+    y[(size_t)v * m + j] = acc * ((1.0 / (double)m) * ((double)m / (double)n));
+}
+
 }  // namespace frt
 
 using namespace frt;
@@ -247,5 +292,48 @@ extern "C" int frt_exp_smooth_2d(const double* kernel, int nk, double alpha, con
     FRT_HIP_CHECK(hipGetLastError());
     if (staged) FRT_HIP_CHECK(hipMemcpy(out, d_out, (size_t)nf * sizeof(double), hipMemcpyDeviceToHost));
     else FRT_HIP_CHECK(hipDeviceSynchronize());
+    return FRT_OK;
+}
+
+
+extern "C" int frt_fourier_resample(const double* x, int n, int count, double* y, int m) {
+    // (min(n, m) = 1 is degenerate in the reference: its slice -(N-1)//2 = 0 selects the whole array, which broadcasts for
+    // n = 1 and raises for n > 1; the Python mirror reproduces both without a kernel)
+    FRT_REQUIRE(n >= 2 && m >= 2 && count >= 0 && n <= (1 << 20) && m <= (1 << 20), "frt_fourier_resample: bad lengths %d -> %d", n, m);
+    if (count == 0) return FRT_OK;
+    FRT_REQUIRE(x && y, "frt_fourier_resample: null buffer");
+    const int N = n < m ? n : m;
+    const int npos = (N + 1) / 2, nneg = N / 2;                 // ceil((N - 1) / 2) = N / 2
+    const long double pi2 = 6.283185307179586476925286766559L;
+    std::vector<double> wn(2 * (size_t)n), wm(2 * (size_t)m);
+    for (int r = 0; r < n; ++r) {
+        wn[2 * r] = (double)cosl(pi2 * r / n);
+        wn[2 * r + 1] = (double)(-sinl(pi2 * r / n));
+    }
+    for (int r = 0; r < m; ++r) {
+        wm[2 * r] = (double)cosl(pi2 * r / m);
+        wm[2 * r + 1] = (double)sinl(pi2 * r / m);
+    }
+    Staged st;
+    const double* d_x;
+    double* d_y;
+    bool staged;
+    int rc;
+    if ((rc = st.in(x, (size_t)count * n, &d_x)) || (rc = st.out(y, (size_t)count * m, &d_y, &staged))) return rc;
+    DeviceBuffer dwn, dwm, dX;
+    if ((rc = upload(dwn, wn)) || (rc = upload(dwm, wm)) || (rc = dX.reserve((size_t)count * N * 2 * sizeof(double)))) return rc;
+    hipLaunchKernelGGL(fourier_bins_kernel, dim3((N + 255) / 256, count), dim3(256), 0, nullptr, d_x, n, count, npos, nneg,
+                       dwn.as<double>(), dX.as<double>());
+    hipLaunchKernelGGL(fourier_synth_kernel, dim3((m + 255) / 256, count), dim3(256), 0, nullptr, dX.as<double>(), n, m, count, npos,
+                       nneg, dwm.as<double>(), d_y);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = staged ? hipMemcpy(y, d_y, (size_t)count * m * sizeof(double), hipMemcpyDeviceToHost) : hipDeviceSynchronize();
+    dwn.release();
+    dwm.release();
+    dX.release();
+    if (e != hipSuccess) {
+        set_last_error("frt_fourier_resample: %s", hipGetErrorString(e));
+        return FRT_ERR_HIP;
+    }
     return FRT_OK;
 }

@@ -649,6 +649,8 @@ extern "C" int frt_stft_set_epilogue(frt_stft* h, const double* weight_db, doubl
     FRT_REQUIRE(spec_max != spec_min, "frt_stft_set_epilogue: empty dB range");
     const int nb = h->fft_size / 2 + 1;
     int rc;
+    // launches already enqueued on the handle's stream may still read the tables replaced below
+    if (h->wimage.ptr) FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
     h->has_weight = weight_db != nullptr;
     // per-bin offset of the colour index (IMAGE kind), weighting and dB range folded in
     const double span = spec_max - spec_min;

@@ -227,18 +227,41 @@ class PitchTracker:
         return self._engine
 
     def _run(self, samples):
-        """All complete frames of one contiguous float64 run -> estimates; keeps prev_f0 in step."""
-        est = self._plan().track(samples)[0]
+        """All complete frames of one contiguous float64 run ([T] or [rows, T]) -> estimates; keeps prev_f0 in step.
+        The spectrum is row 0's; the level of the gate is the RMS over EVERY row of the frame (pitch_tracker.py:404-407:
+        `np.sqrt(np.mean(frame**2))` on the 2-D frame, two rows when the shared ring buffer is in dual-channel mode)."""
+        samples = np.asarray(samples, np.float64)
+        if samples.ndim == 1 or samples.shape[0] == 1:
+            est = self._plan().track(np.ascontiguousarray(samples.reshape(-1)))[0]
+        else:
+            # dual-channel frames: estimate, confidence on the device from row 0; the gate (one comparison chain per frame,
+            # sequential in prev_f0) on the host with the all-rows level
+            eng = self._plan()
+            _, raw = eng.track(np.ascontiguousarray(samples[0]), with_raw=True)
+            f0_raw, conf = raw[0, 0], raw[1, 0]
+            step, n = max(1, self._step()), self.fft_size
+            csum = np.concatenate([[0.0], np.cumsum(np.sum(samples * samples, axis=0))])
+            est = np.empty_like(f0_raw)
+            prev = self.prev_f0
+            for f in range(f0_raw.size):
+                rms = np.sqrt((csum[f * step + n] - csum[f * step]) / (samples.shape[0] * n))
+                dbfs = 20 * np.log10(rms + np.finfo(np.float64).eps)
+                f0 = f0_raw[f]
+                jump = 12 * np.abs(np.log2(f0 / prev)) if prev is not None else 0
+                if (dbfs < self.min_db) or (conf[f] < self.conf) or (jump > self.p_delta) or np.isnan(f0):
+                    prev, est[f] = None, np.nan
+                else:
+                    prev, est[f] = float(f0), f0
         if est.size:
             self.prev_f0 = None if np.isnan(est[-1]) else float(est[-1])
         return est
 
     def estimate_pitch(self, frame: np.ndarray):
-        """frame: [1, fft_size] (the spectrum and the level are taken from row 0).  Hz, or nan if unvoiced."""
-        row = np.ascontiguousarray(np.asarray(frame, np.float64)[0, :])
-        if row.size != self.fft_size:
-            raise ValueError(f"estimate_pitch expects {self.fft_size} samples, got {row.size}")
-        return float(self._run(row)[0])
+        """frame: [rows, fft_size]: spectrum from row 0, level from every row.  Hz, or nan if unvoiced."""
+        frame = np.asarray(frame, np.float64)
+        if frame.shape[-1] != self.fft_size:
+            raise ValueError(f"estimate_pitch expects {self.fft_size} samples, got {frame.shape[-1]}")
+        return float(self._run(frame)[0])
 
     def new_frames(self):
         assert self.input_buf.offset >= self.next_in_offset
@@ -257,7 +280,7 @@ class PitchTracker:
         if count:
             span = self.fft_size + (count - 1) * step
             run = self.input_buf.data_indexed(self.next_in_offset + span, span)
-            new = list(self._run(np.ascontiguousarray(run[0, :])))
+            new = list(self._run(np.ascontiguousarray(run)))
             self.next_in_offset += count * step
         self.out_buf.push(np.array([new]), 0)
         self.out_offset = self.out_buf.offset

@@ -42,7 +42,7 @@ def decimate_multiple(Ndec, bdec, adec, x, zis):
     """Decimate Ndec times by 2; zis is a list of Ndec state vectors (or None for zero state,
     in which case no state is returned)."""
     x = np.ascontiguousarray(x, np.float64)
-    if x.size == 0:
+    if x.size == 0 or Ndec == 0:          # nothing to filter: the reference's loop body never runs (decimate.py:56-71)
         return x, zis
     bdec = np.ascontiguousarray(bdec, np.float64)
     adec = np.ascontiguousarray(adec, np.float64)

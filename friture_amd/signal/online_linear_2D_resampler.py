@@ -4,12 +4,14 @@ spectrogram columns from the STFT rate to the pixel rate.
 The class keeps the reference's scalar bookkeeping (orig_index / resampled_index / ratio decide how
 many pixel columns each pushed column emits and with which weights) and hands the arithmetic of a
 whole push — out = data (1 - a) + old a for every emitted pixel column, linear_interp.py:57-60 —
-to one launch of time_resample_kernel (frt_time_resample)."""
+to one launch of time_resample_kernel (frt_time_resample); a height change Fourier-resamples the carried column on the
+device (frt_fourier_resample)."""
 from __future__ import annotations
 
 import numpy as np
 
 from .. import _lib
+from .scipy_resample import resample
 
 
 class Online_Linear_2D_resampler:
@@ -33,13 +35,12 @@ class Online_Linear_2D_resampler:
 
     def set_height(self, height):
         if self.height != height:
-            # the reference Fourier-resamples the carried column here (scipy_resample.py:51-141) to
-            # avoid a black line after a window resize; restarting from a linearly re-gridded column
-            # keeps the hot path on the device and differs for one pixel column per resize only
-            self.old_data = np.interp(np.linspace(0, 1, height), np.linspace(0, 1, self.height), self.old_data)
             self.height = height
             self.orig_index = 0.
             self.resampled_index = 0.
+            # the carried column is Fourier-resampled to the new height, as the reference does to avoid a black line
+            # after a resize (online_linear_2D_resampler.py:45-55, scipy_resample.py:51-141)
+            self.old_data = resample(self.old_data, self.height)
 
     def processable(self, m):
         return int(np.ceil((self.orig_index + m - (self.resampled_index + self.resampling_ratio)) / self.resampling_ratio))

@@ -97,8 +97,11 @@ int frt_stft_set_run_length(frt_stft* h, int frames_per_run);
  * octave on the j-times decimated signal, 12th-order elliptic decimator between octaves, carried
  * state.  Sequential mode is bit-identical to the reference; the time-parallel mode
  * (frt_octbank_set_chunk) evaluates the same recurrences chunk-wise and agrees to rounding.
- * mode 1 (the FFT overlap-add bank of Octave_Filters.filter, friture/octavefilters.py:49-58 /
- * friture/filter.py:136-247) is served by frt_olabank_* below.
+ * mode 1 is the FFT overlap-add bank of Octave_Filters.filter (friture/octavefilters.py:49-58 /
+ * friture/filter.py:136-247): 512-tap minimum-phase FIR of every IIR, 511-sample tails carried across calls; the same
+ * frt_octbank_filter / frt_octbank_energies entry points.  Up to 1024 samples a call is one overlap-add block at the
+ * reference's FFT sizes; a longer input is processed as if fed in 1024-sample blocks, every octave stage as one launch
+ * over all blocks (the reference itself would crop such an input to its first stage's FFT size).
  *
  * Band order everywhere is the reference's list order: band k = 0 is the lowest band
  * (dec = 256), band 9*bpo-1 the highest (dec = 1); dec[k] = 2^(8 - k / bpo). */
@@ -136,7 +139,7 @@ int frt_octbank_set_state(frt_octbank* h, const double* z);
  * widget's chunk), per block and band sp = alpha*sum_i (1-alpha)^(m-1-i) y_i^2 + sp_prev*(1-alpha)^m
  * (friture/signal/exp_smoothing.py:40-56; m = block/dec), carried across blocks and calls.
  * energy_out: float [n_channels][n/block][9*bpo]; as_db != 0 stores 10 log10(sp + 1e-30) + weight_db[k]
- * (weight_db may be NULL) instead of sp.  The band signals themselves are not written. */
+ * (weight_db may be NULL) instead of sp.  The band signals themselves are not written.  Mode 1: block <= 1024. */
 int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, int block, const double* alphas,
                          const double* weight_db, int as_db, float* energy_out);
 /* decimate_multiple (friture/signal/decimate.py:45-71) with carried state: n_stages chained
@@ -189,6 +192,11 @@ int frt_freq_resample(const double* freq, int n_bins, const double* targets, int
  * for column 0; data [height][n_cols], out [height][n_out]. */
 int frt_time_resample(const double* data, const double* old, int height, int n_cols, const int* src_col,
                       const double* a, int n_out, double* out);
+/* Fourier resampling of `count` real vectors x [count][n] -> y [count][m] (friture/signal/scipy_resample.py:51-141 with
+ * window = None, axis = the vector): the N = min(n, m) lowest frequencies of fft(x) are kept, y = ifft(Y) * m / n.  Any
+ * lengths (screen heights are arbitrary integers).  Used by Online_Linear_2D_resampler.set_height
+ * (friture/signal/online_linear_2D_resampler.py:45-55) for the carried column when the plot is resized. */
+int frt_fourier_resample(const double* x, int n, int count, double* y, int m);
 /* P7 Color_Transform.push (friture/signal/color_tranform.py:48-51): out[i] = lut[int(clip(v[i],0,1)*255)] */
 int frt_colour_map(const uint32_t* lut256, const double* values, int64_t count, uint32_t* out);
 /* P8 exp_smoothed_value_2d (friture/signal/exp_smoothing.py:91-107); nf = 1 gives exp_smoothed_value:

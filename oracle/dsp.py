@@ -603,10 +603,23 @@ def frequency_resample(targets, freq, data):
     return out
 
 
+def fourier_resample(x, num):
+    """Fourier-method resampling along axis 0 (window None): the min(n, num) lowest frequencies of fft(x) zero-padded /
+    truncated to num bins, y = ifft(Y) * num / n, real part  — friture/signal/scipy_resample.py:108-141."""
+    x = np.asarray(x, np.float64)
+    X = np.fft.fft(x, axis=0)
+    nx = x.shape[0]
+    n = int(min(num, nx))
+    Y = np.zeros((num,) + x.shape[1:], complex)
+    Y[0:(n + 1) // 2] = X[0:(n + 1) // 2]
+    Y[-(n - 1) // 2:] = X[-(n - 1) // 2:]          # floor division of the negative number, as the reference writes it
+    return (np.fft.ifft(Y, axis=0) * (float(num) / float(nx))).real
+
+
 class TimeResampler:
     """Stateful linear resampling along time to the pixel rate (ratio = L/M)
     — friture/signal/online_linear_2D_resampler.py:14-97, friture/signal/linear_interp.py:11-62.
-    (Height changes, which Fourier-resample the carried column, are not restated.)"""
+    A push of another height Fourier-resamples the carried column first (set_height, :45-55)."""
 
     def __init__(self, L, M, height):
         self.ratio = float(L) / M
@@ -619,6 +632,11 @@ class TimeResampler:
         return int(np.ceil((self.orig_index + m - (self.resampled_index + self.ratio)) / self.ratio))
 
     def push(self, data):
+        if data.shape[0] != self.height:
+            self.height = data.shape[0]
+            self.orig_index = 0.0
+            self.resampled_index = 0.0
+            self.old = fourier_resample(self.old, self.height)
         cols = data.shape[1]
         out = np.zeros((self.height, self._processable(cols)))
         w = 0

@@ -135,6 +135,25 @@ def main():
         same(f"time resample {tag} 1", mine.push(res["fr_mel"][:, :5]), a)
         same(f"time resample {tag} 2", mine.push(res["fr_mel"][:, 5:]), b)
         res[f"tr_{tag}_a"], res[f"tr_{tag}_b"] = a, b
+    # a resize between pushes: 100 -> 137 -> 64 rows (set_height Fourier-resamples the carried column, scipy_resample.py)
+    from friture.signal.scipy_resample import resample as ref_resample
+    for h_new in (137, 64, 100, 211):
+        col = res["fr_mel"][:, 7]
+        same(f"fourier resample 100 -> {h_new}", dsp.fourier_resample(col, h_new), ref_resample(col, h_new), tol=1e-13)
+        res[f"fourier_100_{h_new}"] = ref_resample(col, h_new)
+    tr = Online_Linear_2D_resampler(25, 16, 100)
+    mine = dsp.TimeResampler(25, 16, 100)
+    fr137 = Frequency_Resampler(fscales.Mel, 20.0, 20000.0, 137)
+    fr137.setfreq(freq)
+    fr64 = Frequency_Resampler(fscales.Mel, 20.0, 20000.0, 64)
+    fr64.setfreq(freq)
+    ncol = norm.shape[1]
+    c1, c2 = ncol // 3, 2 * ncol // 3
+    seq = [res["fr_mel"][:, :c1], fr137.push(norm)[:, c1:c2], fr64.push(norm)[:, c2:]]
+    for i, block in enumerate(seq):
+        a = tr.push(block)
+        same(f"time resample across resize {i}", mine.push(block), a, tol=0.0 if i == 0 else 1e-13)
+        res[f"tr_resize_in_{i}"], res[f"tr_resize_out_{i}"] = block, a
     res["norm"], res["freq"] = norm, freq
     np.savez_compressed(GOLD / "pipeline.npz", **res)
 

@@ -47,6 +47,15 @@ def test_resamplers(golden):
         tr = dsp.TimeResampler(L, M, 100)
         assert np.array_equal(tr.push(g["fr_mel"][:, :5]), g[f"tr_{tag}_a"])
         assert np.array_equal(tr.push(g["fr_mel"][:, 5:]), g[f"tr_{tag}_b"])
+    # a resize between pushes: the carried column is Fourier-resampled (scipy_resample.py:108-141)
+    col = g["fr_mel"][:, 7]
+    for h in (137, 64, 100, 211):
+        assert np.max(np.abs(dsp.fourier_resample(col, h) - g[f"fourier_100_{h}"])) <= 1e-13
+    tr = dsp.TimeResampler(25, 16, 100)
+    for i in range(3):
+        out = tr.push(g[f"tr_resize_in_{i}"])
+        assert out.shape == g[f"tr_resize_out_{i}"].shape
+        assert np.max(np.abs(out - g[f"tr_resize_out_{i}"])) <= 1e-13
 
 
 def test_exp_smoothing(golden):

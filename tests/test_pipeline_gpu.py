@@ -42,6 +42,35 @@ def test_time_resampler(golden, hip):
     assert np.array_equal(np.concatenate(parts, axis=1), ref.push(g["fr_mel"]))
 
 
+def test_time_resampler_across_a_resize(golden, hip):
+    """set_height (online_linear_2D_resampler.py:45-55): a push of another height Fourier-resamples the carried column
+    (scipy_resample.py:51-141).  Against the reference's own outputs over 100 -> 137 -> 64 rows; direct DFT sums on the
+    device against pocketfft: 1e-12 of the column maximum."""
+    from friture_amd.signal.online_linear_2D_resampler import Online_Linear_2D_resampler
+    from friture_amd.signal.scipy_resample import resample
+    g = golden("pipeline")
+    col = g["fr_mel"][:, 7]
+    for h in (137, 64, 100, 211):
+        ref = g[f"fourier_100_{h}"]
+        got = resample(col, h)
+        assert got.shape == ref.shape and np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref)), h
+    # awkward lengths: primes both ways, a single row, 2-D input along axis 0
+    rng = np.random.default_rng(3)
+    for n, m in [(997, 1009), (1009, 463), (1, 5), (2, 3), (3, 2), (480, 1080), (1080, 479)]:
+        x = rng.standard_normal((n, 3))
+        ref = dsp.fourier_resample(x, m)
+        got = resample(x, m)
+        assert got.shape == ref.shape and np.max(np.abs(got - ref)) <= 1e-12 * max(np.max(np.abs(ref)), 1e-300), (n, m)
+    with pytest.raises(ValueError):
+        resample(np.ones(7), 1)                      # the reference raises here too (its negative-frequency slice)
+    tr = Online_Linear_2D_resampler(25, 16, 100)
+    for i in range(3):
+        out = tr.push(g[f"tr_resize_in_{i}"])
+        ref = g[f"tr_resize_out_{i}"]
+        assert out.shape == ref.shape
+        assert np.max(np.abs(out - ref)) <= 1e-12 * np.max(np.abs(ref)), i
+
+
 def test_colour_transform_and_full_pipeline(golden, hip):
     from friture_amd.plotting import frequency_scales as fs
     from friture_amd.signal.color_tranform import Color_Transform

@@ -168,6 +168,29 @@ def test_streaming_tracker_mirror(golden, pt):
     assert abs(tr2.estimate_pitch(x[None, :4096]) - g["N4096_jump_f0"][0]) <= TOL_F0 * 200
     kat = pt.PitchTracker(RingBuffer(), fft_size=32, overlap=0.5)
     assert np.isnan(kat.estimate_pitch(g["kat32_frame"][None, :]))   # what the reference returns today (see the oracle)
+    # dual-channel frames (the shared ring buffer with a second input): spectrum from row 0, gate level from BOTH rows
+    # (pitch_tracker.py:404-407).  A tone 58 dB below full scale is unvoiced on its own and voiced beside a loud row.
+    n = 4096 + 3 * 1024
+    t = np.arange(n)
+    quiet = 0.0018 * (np.sin(2 * np.pi * 220.0 * t / 48000.0) + 0.5 * np.sin(2 * np.pi * 440.0 * t / 48000.0))
+    loud = 0.5 * np.random.default_rng(1).standard_normal(n)
+    tr3 = pt.PitchTracker(RingBuffer())
+    assert np.isnan(tr3.estimate_pitch(quiet[None, :4096]))
+    f2 = tr3.estimate_pitch(np.stack([quiet, loud])[:, :4096])
+    want2 = dsp.pitch_candidate(quiet[:4096], dsp.hann_symmetric(4096), tr3.logSpacedFreqs, tr3.kernels)[0]
+    assert abs(f2 - want2) <= TOL_F0 * want2 and abs(f2 - 220.0) < 2.0
+    buf2 = RingBuffer()
+    tr4 = pt.PitchTracker(buf2)
+    buf2.push(np.stack([quiet, loud]))
+    assert tr4.update()
+    got2 = tr4.get_estimates(3 * 1024 / 48000.0)
+    ref = dsp.PitchGate()
+    for f in range(4):
+        seg = np.stack([quiet, loud])[:, f * 1024:f * 1024 + 4096]
+        f0, c, _ = dsp.pitch_candidate(seg[0], dsp.hann_symmetric(4096), tr4.logSpacedFreqs, tr4.kernels)
+        db = 20 * np.log10(np.sqrt(np.mean(seg ** 2)) + np.finfo(np.float64).eps)
+        w = ref.step(f0, c, db)
+        assert (np.isnan(w) and np.isnan(got2[f])) or abs(got2[f] - w) <= TOL_F0 * w, f
 
 
 def test_other_grids_and_both_log_grid_kernels(pt, monkeypatch):
