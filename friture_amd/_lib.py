@@ -33,6 +33,7 @@ class FritureHipError(RuntimeError):
 # name -> (restype, argtypes); kept in one table so that tests can check the export list
 SIGNATURES = {
     "frt_init": (c_int, [c_int, POINTER(c_int), POINTER(c_int64)]),
+    "frt_device_properties": (c_int, [c_int, POINTER(c_int), POINTER(c_int64)]),
     "frt_last_error": (c_char_p, []),
     "frt_version": (c_char_p, []),
     "frt_is_device_pointer": (c_int, [c_void_p]),
@@ -125,11 +126,16 @@ def init(device: int | None = None) -> ctypes.CDLL:
     lib = load()
     if not _initialised:
         if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0"))
-            if "torch" in sys.modules:
-                import torch
-                if torch.cuda.is_available():
-                    device = torch.cuda.current_device()
+            # one process per GPU: the launcher's LOCAL_RANK decides; without it, the device torch was told to use
+            # (torch.cuda.current_device() is 0 until set_device is called, so it must not override LOCAL_RANK)
+            if "LOCAL_RANK" in os.environ:
+                device = int(os.environ["LOCAL_RANK"])
+            else:
+                device = 0
+                if "torch" in sys.modules:
+                    import torch
+                    if torch.cuda.is_available() and torch.cuda.is_initialized():
+                        device = torch.cuda.current_device()
         check(lib.frt_init(device, None, None))
         _initialised = True
     return lib
@@ -138,5 +144,5 @@ def init(device: int | None = None) -> ctypes.CDLL:
 def device_info(device: int = 0) -> tuple[int, int]:
     lib = load()
     ncu, hbm = c_int(0), c_int64(0)
-    check(lib.frt_init(device, ctypes.byref(ncu), ctypes.byref(hbm)))
+    check(lib.frt_device_properties(device, ctypes.byref(ncu), ctypes.byref(hbm)))      # does not rebind the process
     return ncu.value, hbm.value

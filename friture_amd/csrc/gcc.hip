@@ -20,6 +20,7 @@
 
 #include "common.h"
 #include "fft_mixed.h"
+#include "fft_core.h"
 
 namespace frt {
 
@@ -244,6 +245,307 @@ __global__ void __launch_bounds__(kGccThreads) gcc_readout_kernel(const double* 
     }
 }
 
+
+// ---- any window length: chirp-z (Bluestein) on a four-step power-of-two transform ----------------------------------
+// The delay-range spin box runs from 0.1 s to 1000 s in steps of 0.1 s (delay_estimator.py:222-226): windows of
+// L = 2400 r samples, r = 1..10000 — most of them neither 5-smooth nor small enough for the one-workgroup kernel above
+// (numpy's rfft takes any length).  Those windows go through the textbook identity
+//     X[k] = c[k] sum_n (x[n] c[n]) conj(c)[k - n],   c[n] = exp(-i pi n^2 / L),
+// a length-L DFT as a circular convolution of length P = 2^p >= 2L - 1.  Both signals ride in ONE complex transform
+// (z = d0 w + i d1 w, separated by conjugate symmetry), the PHAT-weighted cross spectrum is extended to its Hermitian
+// full length and goes back through the same machinery: xcorr = Re DFT(conj Y) / L.
+// The length-P transforms are four-step: P = R C (both 2^8 .. 2^13), index n = r C + c;
+//     forward:  column transforms over r  ->  x W_P^{k_r c}  ->  row transforms over c, result X[k_c R + k_r] AT [k_r][k_c]
+//     inverse:  row inverse over k_c  ->  x W_P^{-k_r c}  ->  column inverse over k_r, natural order
+// so the product with the chirp spectrum (same transposed layout) and the inverse row transform run in the kernel that
+// did the forward row transform, and nothing is ever transposed in memory: three launches per length-L DFT.  The
+// length-R / length-C transforms are the STFT's radix-8 engine (fft_core.h), one workgroup per column / row, float64.
+struct AnyArgs {
+    // geometry
+    int L, log2r, log2c;                 // P = R C
+    long long P;
+    // inputs of the signal-building load (src_mode 1) / of the spectrum load (src_mode 2)
+    const double* d0;                    // [pairs][L]
+    const double* d1;
+    const double* means;                 // [pairs][2]
+    const double* window;                // [L]
+    const double* chirp;                 // [L] complex: exp(-i pi n^2 / L)
+    const double* spec;                  // [pairs][L] complex (src_mode 2: a[n] = spec[n] chirp[n])
+    const double* plain;                 // [P] complex (src_mode 0)
+    double* work;                        // [pairs][P] complex, the four-step array
+    const double* bhat;                  // [P] complex: transform of the chirp filter, transposed layout
+    const double* twr;                   // [R] exp(-2 pi i t / R)
+    const double* twc;                   // [C]
+    // outputs of the final column pass
+    double* spec_out;                    // dst_mode 0: [pairs][L] complex X[n] = conv[n] chirp[n]
+    double* xcorr;                       // dst_mode 1: [pairs][L] real: Re(conv[n] chirp[n]) / L
+};
+
+__device__ __forceinline__ cpx<double> unit_root(long long num, long long den_pow2) {      // exp(-2 pi i num / den)
+    double s, c;
+    sincospi(-2.0 * ((double)num / (double)den_pow2), &s, &c);
+    return {c, s};
+}
+
+// column pass of the forward transform: A[k_r C + c] = W_P^{k_r c} sum_r src(r C + c) W_R^{r k_r}
+template <int LOG2R, int SRC>
+__global__ void __launch_bounds__(Pow2Plan<LOG2R>::TPF) any_col_fwd_kernel(const AnyArgs a) {
+    using C = cpx<double>;
+    using PL = Pow2Plan<LOG2R>;
+    constexpr int R = PL::M, TPF = PL::TPF;
+    __shared__ C buf[lds_padded_size(R)];
+    const int i = threadIdx.x, col = blockIdx.x, pair = blockIdx.y;
+    const long long Cn = 1ll << a.log2c;
+    const C* chirp = (const C*)a.chirp;
+    double m0 = 0.0, m1 = 0.0;
+    if (SRC == 1) { m0 = a.means[2 * pair]; m1 = a.means[2 * pair + 1]; }
+    C v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long long n = (long long)(i + j * TPF) * Cn + col;
+        C x = {0.0, 0.0};
+        if (SRC == 0) {
+            x = ((const C*)a.plain)[n];
+        } else if (n < a.L) {
+            if (SRC == 1) {
+                const double w = a.window[n];
+                x = {(a.d0[(size_t)pair * a.L + n] - m0) * w, (a.d1[(size_t)pair * a.L + n] - m1) * w};
+            } else {
+                x = ((const C*)a.spec)[(size_t)pair * a.L + n];
+            }
+            x = cmul(x, chirp[n]);
+        }
+        v[j] = x;
+    }
+    const TwTable<double, LOG2R> tw{(const C*)a.twr, 0};
+    fft_pow2_forward<double, LOG2R, false>(v, buf, i, tw);
+    C* A = (C*)a.work + (size_t)pair * a.P;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long long kr = i + j * TPF;
+        A[kr * Cn + col] = cmul(v[j], unit_root(kr * col, a.P));
+    }
+}
+
+// row pass: forward over c; MODE 0 stores the spectrum (transposed layout); MODE 1 multiplies by bhat, inverts over k_c,
+// applies W_P^{-k_r c} and stores in place: the array is then ready for the inverse column pass
+template <int LOG2C, int MODE>
+__global__ void __launch_bounds__(Pow2Plan<LOG2C>::TPF) any_row_kernel(const AnyArgs a) {
+    using C = cpx<double>;
+    using PL = Pow2Plan<LOG2C>;
+    constexpr int Cn = PL::M, TPF = PL::TPF;
+    __shared__ C buf[lds_padded_size(Cn)];
+    const int i = threadIdx.x, pair = blockIdx.y;
+    const long long kr = blockIdx.x;
+    C* row = (C*)a.work + (size_t)pair * a.P + kr * Cn;
+    C v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = row[i + j * TPF];
+    const TwTable<double, LOG2C> tw{(const C*)a.twc, 0};
+    fft_pow2_forward<double, LOG2C, false>(v, buf, i, tw);
+    if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) row[i + j * TPF] = v[j];
+        return;
+    }
+    const C* bh = (const C*)a.bhat + kr * Cn;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = cconj(cmul(v[j], bh[i + j * TPF]));       // conj trick for the inverse
+    __syncthreads();
+    fft_pow2_forward<double, LOG2C, false>(v, buf, i, tw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long long c = i + j * TPF;
+        row[c] = cmul(cconj(v[j]), cconj(unit_root(kr * c, a.P)));                // (1/C deferred to the last pass)
+    }
+}
+
+// inverse column pass and the chirp on the way out
+template <int LOG2R, int DST>
+__global__ void __launch_bounds__(Pow2Plan<LOG2R>::TPF) any_col_inv_kernel(const AnyArgs a) {
+    using C = cpx<double>;
+    using PL = Pow2Plan<LOG2R>;
+    constexpr int R = PL::M, TPF = PL::TPF;
+    __shared__ C buf[lds_padded_size(R)];
+    const int i = threadIdx.x, col = blockIdx.x, pair = blockIdx.y;
+    const long long Cn = 1ll << a.log2c;
+    if (col >= a.L) return;                                   // rows r >= 1 of such a column lie beyond L as well
+    const C* A = (const C*)a.work + (size_t)pair * a.P;
+    C v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = cconj(A[(long long)(i + j * TPF) * Cn + col]);
+    const TwTable<double, LOG2R> tw{(const C*)a.twr, 0};
+    fft_pow2_forward<double, LOG2R, false>(v, buf, i, tw);
+    const double invp = 1.0 / (double)a.P;
+    const C* chirp = (const C*)a.chirp;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long long n = (long long)(i + j * TPF) * Cn + col;
+        if (n < a.L) {
+            const C conv = {v[j].x * invp, -v[j].y * invp};
+            const C X = cmul(conv, chirp[n]);
+            if (DST == 0) ((C*)a.spec_out)[(size_t)pair * a.L + n] = X;
+            else a.xcorr[(size_t)pair * a.L + n] = X.x / (double)a.L;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) any_chirp_kernel(double* __restrict__ chirp, int L) {
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= L) return;
+    const unsigned long long r = ((unsigned long long)n * (unsigned long long)n) % (2ull * (unsigned long long)L);
+    double s, c;
+    sincospi(-(double)r / (double)L, &s, &c);                 // exp(-i pi n^2 / L), argument reduced exactly
+    chirp[2 * n] = c;
+    chirp[2 * n + 1] = s;
+}
+
+// the convolution's filter conj(c)[n] for |n| < L, wrapped to length P
+__global__ void __launch_bounds__(256) any_filter_kernel(const double* __restrict__ chirp, double* __restrict__ b, int L, long long P) {
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= P) return;
+    double re = 0.0, im = 0.0;
+    if (n < L) { re = chirp[2 * n]; im = -chirp[2 * n + 1]; }
+    else if (P - n < L) { re = chirp[2 * (P - n)]; im = -chirp[2 * (P - n) + 1]; }
+    b[2 * n] = re;
+    b[2 * n + 1] = im;
+}
+
+__global__ void __launch_bounds__(kGccThreads) any_means_kernel(const double* __restrict__ d0, const double* __restrict__ d1, int L,
+                                                                double* __restrict__ means, unsigned long long* __restrict__ gmax) {
+    __shared__ double red[16];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    for (int s = 0; s < 2; ++s) {
+        const double* x = (s ? d1 : d0) + (size_t)pair * L;
+        double acc = 0.0;
+        for (int t = tid; t < L; t += kGccThreads) acc += x[t];
+        const double m = block_sum(acc, red) / (double)L;
+        if (tid == 0) means[2 * pair + s] = m;
+    }
+    if (tid == 0) gmax[pair] = 0ull;
+}
+
+// Z = D0 + i D1 in natural order -> G = conj(D0) D1 for k = 0..L/2 (kept in place of Z[k]) and its largest magnitude
+__global__ void __launch_bounds__(256) any_cross_kernel(double* __restrict__ spec, int L, unsigned long long* __restrict__ gmax) {
+    using C = cpx<double>;
+    __shared__ double red[4];
+    const int pair = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    C* Z = (C*)spec + (size_t)pair * L;
+    double mag = 0.0;
+    C g = {0.0, 0.0};
+    C zk = {0.0, 0.0}, zm = {0.0, 0.0};
+    const bool in = k <= L / 2;
+    if (in) {
+        zk = Z[k];
+        zm = cconj(Z[k == 0 ? 0 : L - k]);
+    }
+    __syncthreads();
+    if (in) {
+        const C D0 = {0.5 * (zk.x + zm.x), 0.5 * (zk.y + zm.y)};
+        const C Dd = {0.5 * (zk.x - zm.x), 0.5 * (zk.y - zm.y)};      // i D1
+        const C D1 = {Dd.y, -Dd.x};
+        g = cmul(cconj(D0), D1);
+        mag = hypot(g.x, g.y);
+    }
+    // every Z[k], Z[L-k] pair is read by exactly this thread (k <= L/2): safe to overwrite Z[k] now
+    if (in) Z[k] = g;
+    for (int o = 32; o > 0; o >>= 1) mag = fmax(mag, __shfl_down(mag, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mag;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        atomicMax(gmax + pair, (unsigned long long)__double_as_longlong(m));      // non-negative doubles order like their bits
+    }
+}
+
+// PHAT weight, Hermitian extension, conjugated for the inverse: spec[k] = conj(Y[k]), spec[L-k] = Y[k]
+__global__ void __launch_bounds__(256) any_weight_kernel(double* __restrict__ spec, int L, const unsigned long long* __restrict__ gmax) {
+    using C = cpx<double>;
+    const int pair = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k > L / 2) return;
+    C* Z = (C*)spec + (size_t)pair * L;
+    const double m = __longlong_as_double((long long)gmax[pair]);
+    C g = Z[k];
+    const double w = 1.0 / (1e-10 * m + hypot(g.x, g.y));
+    g = {g.x * w, g.y * w};
+    if (k == 0 || k == L / 2) g.y = 0.0;                      // irfft ignores the imaginary part of the edge bins
+    Z[k] = cconj(g);
+    if (k != 0 && k != L / 2) Z[L - k] = g;
+}
+
+__global__ void __launch_bounds__(kGccThreads) any_argmax_kernel(const double* __restrict__ x, int L, int* __restrict__ argmax) {
+    __shared__ double red[16];
+    __shared__ int redi[16];
+    const int tid = threadIdx.x, pair = blockIdx.x;
+    const double* xp = x + (size_t)pair * L;
+    double best = -1.0;
+    int besti = 0;
+    for (int t = tid; t < L; t += kGccThreads) {
+        const double v = fabs(xp[t]);
+        if (v > best) { best = v; besti = t; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_down(best, o, 64);
+        const int oi = __shfl_down(besti, o, 64);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = best; redi[tid >> 6] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kGccThreads / 64; ++w)
+            if (red[w] > best || (red[w] == best && redi[w] < besti)) { best = red[w]; besti = redi[w]; }
+        argmax[pair] = besti;
+    }
+}
+
+template <int SRC>
+static int launch_col_fwd(const AnyArgs& a, int pairs, hipStream_t s) {
+    const dim3 grid((unsigned)(1u << a.log2c), pairs);
+    switch (a.log2r) {
+        case 8: hipLaunchKernelGGL((any_col_fwd_kernel<8, SRC>), grid, dim3(Pow2Plan<8>::TPF), 0, s, a); break;
+        case 9: hipLaunchKernelGGL((any_col_fwd_kernel<9, SRC>), grid, dim3(Pow2Plan<9>::TPF), 0, s, a); break;
+        case 10: hipLaunchKernelGGL((any_col_fwd_kernel<10, SRC>), grid, dim3(Pow2Plan<10>::TPF), 0, s, a); break;
+        case 11: hipLaunchKernelGGL((any_col_fwd_kernel<11, SRC>), grid, dim3(Pow2Plan<11>::TPF), 0, s, a); break;
+        case 12: hipLaunchKernelGGL((any_col_fwd_kernel<12, SRC>), grid, dim3(Pow2Plan<12>::TPF), 0, s, a); break;
+        case 13: hipLaunchKernelGGL((any_col_fwd_kernel<13, SRC>), grid, dim3(Pow2Plan<13>::TPF), 0, s, a); break;
+        default: set_last_error("gcc any-length: bad column size 2^%d", a.log2r); return FRT_ERR_UNSUPPORTED;
+    }
+    FRT_HIP_CHECK(hipGetLastError());
+    return FRT_OK;
+}
+template <int MODE>
+static int launch_row(const AnyArgs& a, int pairs, hipStream_t s) {
+    const dim3 grid((unsigned)(1u << a.log2r), pairs);
+    switch (a.log2c) {
+        case 8: hipLaunchKernelGGL((any_row_kernel<8, MODE>), grid, dim3(Pow2Plan<8>::TPF), 0, s, a); break;
+        case 9: hipLaunchKernelGGL((any_row_kernel<9, MODE>), grid, dim3(Pow2Plan<9>::TPF), 0, s, a); break;
+        case 10: hipLaunchKernelGGL((any_row_kernel<10, MODE>), grid, dim3(Pow2Plan<10>::TPF), 0, s, a); break;
+        case 11: hipLaunchKernelGGL((any_row_kernel<11, MODE>), grid, dim3(Pow2Plan<11>::TPF), 0, s, a); break;
+        case 12: hipLaunchKernelGGL((any_row_kernel<12, MODE>), grid, dim3(Pow2Plan<12>::TPF), 0, s, a); break;
+        case 13: hipLaunchKernelGGL((any_row_kernel<13, MODE>), grid, dim3(Pow2Plan<13>::TPF), 0, s, a); break;
+        default: set_last_error("gcc any-length: bad row size 2^%d", a.log2c); return FRT_ERR_UNSUPPORTED;
+    }
+    FRT_HIP_CHECK(hipGetLastError());
+    return FRT_OK;
+}
+template <int DST>
+static int launch_col_inv(const AnyArgs& a, int pairs, hipStream_t s) {
+    const dim3 grid((unsigned)(1u << a.log2c), pairs);
+    switch (a.log2r) {
+        case 8: hipLaunchKernelGGL((any_col_inv_kernel<8, DST>), grid, dim3(Pow2Plan<8>::TPF), 0, s, a); break;
+        case 9: hipLaunchKernelGGL((any_col_inv_kernel<9, DST>), grid, dim3(Pow2Plan<9>::TPF), 0, s, a); break;
+        case 10: hipLaunchKernelGGL((any_col_inv_kernel<10, DST>), grid, dim3(Pow2Plan<10>::TPF), 0, s, a); break;
+        case 11: hipLaunchKernelGGL((any_col_inv_kernel<11, DST>), grid, dim3(Pow2Plan<11>::TPF), 0, s, a); break;
+        case 12: hipLaunchKernelGGL((any_col_inv_kernel<12, DST>), grid, dim3(Pow2Plan<12>::TPF), 0, s, a); break;
+        case 13: hipLaunchKernelGGL((any_col_inv_kernel<13, DST>), grid, dim3(Pow2Plan<13>::TPF), 0, s, a); break;
+        default: set_last_error("gcc any-length: bad column size 2^%d", a.log2r); return FRT_ERR_UNSUPPORTED;
+    }
+    FRT_HIP_CHECK(hipGetLastError());
+    return FRT_OK;
+}
+
 }  // namespace frt
 
 using namespace frt;
@@ -255,12 +557,17 @@ struct frt_gcc {
     DeviceBuffer window, twm, tw2, twl, scratch;
     DeviceBuffer in0, in1, out, argmax, means, old, sm, stats;
     size_t lds_bytes = 0;
+    // any-length path (chirp-z): lengths the one-workgroup kernel does not take
+    bool any = false;
+    int log2r = 0, log2c = 0;
+    DeviceBuffer chirp, bhat, work, spec, twr, twc, gmax;
 };
 
 extern "C" void frt_gcc_destroy(frt_gcc* h) {
     if (!h) return;
     DeviceBuffer* bufs[] = {&h->window, &h->twm, &h->tw2, &h->twl, &h->scratch, &h->in0, &h->in1,
-                            &h->out, &h->argmax, &h->means, &h->old, &h->sm, &h->stats};
+                            &h->out, &h->argmax, &h->means, &h->old, &h->sm, &h->stats,
+                            &h->chirp, &h->bhat, &h->work, &h->spec, &h->twr, &h->twc, &h->gmax};
     for (auto* b : bufs) b->release();
     delete h;
 }
@@ -278,17 +585,53 @@ extern "C" int frt_gcc_create(frt_gcc** out, int length, int n_pairs) {
     while (h->M / R > kGccMaxM2 && R < kGccMaxR && h->M % (2 * R) == 0) R *= 2;
     h->R = R;
     h->M2 = h->M / R;
-    if (h->M2 > kGccMaxM2 || !make_mixed_plan(h->M2, &h->plan)) {
-        set_last_error("frt_gcc_create: length %d is not supported (L/2 = R * M2 with R <= %d, M2 <= %d and 5-smooth)",
-                       length, kGccMaxR, kGccMaxM2);
-        delete h;
-        return FRT_ERR_UNSUPPORTED;
-    }
     // numpy.hanning(L) = 0.5 - 0.5 cos(2 pi n / (L - 1))
     std::vector<double> win(length);
     const double pi = 3.14159265358979323846;
     for (int n = 0; n < length; ++n) win[n] = 0.5 - 0.5 * std::cos(2.0 * pi * n / (length - 1));
     int rc;
+    if (h->M2 > kGccMaxM2 || !make_mixed_plan(h->M2, &h->plan) || getenv("FRT_GCC_FORCE_ANY")) {
+        // any other length (numpy's rfft takes them all): chirp-z on a four-step power-of-two transform
+        FRT_REQUIRE(length <= (1 << 25), "frt_gcc_create: length %d above 2^25 samples", length);
+        h->any = true;
+        int p = 16;
+        while ((1ll << p) < 2ll * length - 1) ++p;
+        h->log2r = p / 2;
+        h->log2c = p - h->log2r;
+        const long long P = 1ll << p;
+        if ((rc = upload(h->window, win)) || (rc = upload(h->twr, make_twiddles<double>(1 << h->log2r))) ||
+            (rc = upload(h->twc, make_twiddles<double>(1 << h->log2c))) || (rc = h->chirp.reserve((size_t)length * 16)) ||
+            (rc = h->bhat.reserve((size_t)P * 16)) || (rc = h->work.reserve((size_t)n_pairs * P * 16)) ||
+            (rc = h->spec.reserve((size_t)n_pairs * length * 16)) || (rc = h->gmax.reserve((size_t)n_pairs * 8))) {
+            frt_gcc_destroy(h);
+            return rc;
+        }
+        // chirp, and the transform of the convolution's filter in the transposed layout of the four-step scheme
+        hipLaunchKernelGGL(any_chirp_kernel, dim3((length + 255) / 256), dim3(256), 0, nullptr, h->chirp.as<double>(), length);
+        hipLaunchKernelGGL(any_filter_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, nullptr, h->chirp.as<double>(),
+                           h->work.as<double>(), length, P);
+        AnyArgs a{};
+        a.L = length;
+        a.log2r = h->log2r;
+        a.log2c = h->log2c;
+        a.P = P;
+        a.plain = h->work.as<double>();
+        a.work = h->bhat.as<double>();
+        a.twr = h->twr.as<double>();
+        a.twc = h->twc.as<double>();
+        a.chirp = h->chirp.as<double>();
+        if ((rc = launch_col_fwd<0>(a, 1, nullptr)) || (rc = launch_row<0>(a, 1, nullptr))) {
+            frt_gcc_destroy(h);
+            return rc;
+        }
+        if (hipDeviceSynchronize() != hipSuccess) {
+            set_last_error("frt_gcc_create: chirp-z tables failed");
+            frt_gcc_destroy(h);
+            return FRT_ERR_HIP;
+        }
+        *out = h;
+        return FRT_OK;
+    }
     if ((rc = upload(h->window, win)) || (rc = upload(h->twm, make_twiddles<double>(h->M))) ||
         (rc = upload(h->tw2, make_twiddles<double>(h->M2))) || (rc = upload(h->twl, make_twiddles<double>(length, h->M + 1))) ||
         (rc = h->scratch.reserve((size_t)n_pairs * (4 * (size_t)h->M + 2) * 2 * sizeof(double)))) {
@@ -332,6 +675,38 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
         a.d1 = h->in1.as<double>();
         a.xcorr = h->out.as<double>();
     }
+    if (h->any) {
+        AnyArgs q{};
+        q.L = h->L;
+        q.log2r = h->log2r;
+        q.log2c = h->log2c;
+        q.P = 1ll << (h->log2r + h->log2c);
+        q.d0 = a.d0;
+        q.d1 = a.d1;
+        q.means = h->means.as<double>();
+        q.window = h->window.as<double>();
+        q.chirp = h->chirp.as<double>();
+        q.spec = h->spec.as<double>();
+        q.work = h->work.as<double>();
+        q.bhat = h->bhat.as<double>();
+        q.twr = h->twr.as<double>();
+        q.twc = h->twc.as<double>();
+        q.spec_out = h->spec.as<double>();
+        q.xcorr = a.xcorr;
+        unsigned long long* gm = h->gmax.as<unsigned long long>();
+        const dim3 halfgrid((h->L / 2 + 1 + 255) / 256, h->n_pairs);
+        hipLaunchKernelGGL(any_means_kernel, dim3(h->n_pairs), dim3(kGccThreads), 0, h->stream, q.d0, q.d1, h->L, h->means.as<double>(), gm);
+        if ((rc = launch_col_fwd<1>(q, h->n_pairs, h->stream)) || (rc = launch_row<1>(q, h->n_pairs, h->stream)) ||
+            (rc = launch_col_inv<0>(q, h->n_pairs, h->stream)))
+            return rc;
+        hipLaunchKernelGGL(any_cross_kernel, halfgrid, dim3(256), 0, h->stream, h->spec.as<double>(), h->L, gm);
+        hipLaunchKernelGGL(any_weight_kernel, halfgrid, dim3(256), 0, h->stream, h->spec.as<double>(), h->L, gm);
+        if ((rc = launch_col_fwd<2>(q, h->n_pairs, h->stream)) || (rc = launch_row<1>(q, h->n_pairs, h->stream)) ||
+            (rc = launch_col_inv<1>(q, h->n_pairs, h->stream)))
+            return rc;
+        hipLaunchKernelGGL(any_argmax_kernel, dim3(h->n_pairs), dim3(kGccThreads), 0, h->stream, a.xcorr, h->L, h->argmax.as<int>());
+        FRT_HIP_CHECK(hipGetLastError());
+    } else {
     a.argmax = h->argmax.as<int>();
     a.means = h->means.as<double>();
     a.window = h->window.as<double>();
@@ -346,6 +721,7 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
     a.R = h->R;
     hipLaunchKernelGGL(gcc_phat_kernel, dim3(h->n_pairs), dim3(kGccThreads), h->lds_bytes, h->stream, a);
     FRT_HIP_CHECK(hipGetLastError());
+    }
     if (!dev) FRT_HIP_CHECK(hipMemcpyAsync(xcorr_out, h->out.ptr, bytes, hipMemcpyDeviceToHost, h->stream));
     if (argmax_out) {
         const bool adev = is_device_pointer(argmax_out);

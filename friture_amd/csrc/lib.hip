@@ -44,6 +44,21 @@ extern "C" const char* frt_version(void) { return "friture_hip 0.1 (gfx950)"; }
 
 extern "C" int frt_is_device_pointer(const void* p) { return is_device_pointer(p) ? 1 : 0; }
 
+extern "C" int frt_device_properties(int device, int* n_cus_out, int64_t* hbm_bytes_out) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_last_error("frt_device_properties: no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return FRT_ERR_NO_DEVICE;
+    }
+    FRT_REQUIRE(device >= 0 && device < n, "frt_device_properties: device %d out of range (have %d)", device, n);
+    hipDeviceProp_t prop;
+    FRT_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (n_cus_out) *n_cus_out = prop.multiProcessorCount;
+    if (hbm_bytes_out) *hbm_bytes_out = (int64_t)prop.totalGlobalMem;
+    return FRT_OK;
+}
+
 extern "C" int frt_init(int device, int* n_cus_out, int64_t* hbm_bytes_out) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

@@ -39,6 +39,8 @@ extern "C" {
 /* Binds the calling process to HIP device `device` (one process per GPU) and verifies that it is
  * a gfx950 part.  n_cus_out / hbm_bytes_out may be NULL. */
 int frt_init(int device, int* n_cus_out, int64_t* hbm_bytes_out);
+/* The same two figures for any visible device WITHOUT binding the process to it (the current device is untouched). */
+int frt_device_properties(int device, int* n_cus_out, int64_t* hbm_bytes_out);
 const char* frt_last_error(void);
 const char* frt_version(void);
 /* 1 if `p` is device memory, 0 if host memory. */

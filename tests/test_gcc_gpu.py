@@ -53,11 +53,56 @@ def test_gcc_lengths_against_oracle(hip, L):
         assert list(am) == [lag] * 3 and x[2, lag] < 0 < x[0, lag]
 
 
+@pytest.mark.parametrize("L", [2640, 14336, 26400, 50400, 232800, 1_200_000])
+def test_gcc_any_window_length(hip, L):
+    """The delay-range spin box gives windows of 2400 r samples, r = 1..10000 (delay_estimator.py:114-115,222-226): most
+    are not 5-smooth (0.11 s -> 2640 = 2^4 3 5 11; 9.7 s -> 232800 = 2400 x 97) or too long for the one-workgroup kernel
+    (2.1 s -> 50400; 50 s -> 1.2 M).  numpy takes every length; those go through the chirp-z path: same tolerance."""
+    from friture_amd.signal.correlation import GccPhat
+    rng = np.random.default_rng(L)
+    P = 2 if L < 500000 else 1
+    d0 = 0.25 * rng.standard_normal((P, L))
+    d1 = np.roll(d0, 41, axis=1) + 0.02 * rng.standard_normal((P, L))
+    if P == 2:
+        d1[1] = -d1[1]
+    x, am = GccPhat(L, P).correlate(d0, d1)
+    for p in range(P):
+        ref, _, _ = dsp.gcc_phat(d0[p], d1[p])
+        assert rel_max(x[p], ref) <= 1e-9, (L, p, rel_max(x[p], ref))
+        assert am[p] == int(np.argmax(np.abs(ref))) == 41
+
+
+def test_gcc_chirp_path_equals_one_workgroup_path(hip, monkeypatch):
+    """L = 24000 (the widget's default window) through both implementations."""
+    from friture_amd.signal.correlation import GccPhat
+    rng = np.random.default_rng(5)
+    d0 = 0.25 * rng.standard_normal((2, 24000))
+    d1 = np.roll(d0, 37, axis=1) + 0.05 * rng.standard_normal((2, 24000))
+    x_fast, am_fast = GccPhat(24000, 2).correlate(d0, d1)
+    monkeypatch.setenv("FRT_GCC_FORCE_ANY", "1")
+    x_any, am_any = GccPhat(24000, 2).correlate(d0, d1)
+    assert list(am_fast) == list(am_any) == [37, 37]
+    assert rel_max(x_any, x_fast) <= 1e-10
+
+
+def test_delay_estimator_other_ranges(hip):
+    """Delay_Estimator mirror with a 0.3 s range (L = 7200) and a 1.1 s range (L = 26400, chirp-z path)."""
+    from friture_amd.delay_estimator import DelayEstimator
+    for rng_s in (0.3, 1.1):
+        de = DelayEstimator()
+        de.set_delayrange(rng_s)
+        rng = np.random.default_rng(int(rng_s * 10))
+        n = int(48000 * rng_s * 4.5)
+        a = (0.25 * rng.standard_normal(n)).astype(np.float32)
+        b = np.roll(a, 4 * 25) + (0.01 * rng.standard_normal(n)).astype(np.float32)     # 25 samples at the decimated rate
+        for pos in range(0, n - 512, 512):
+            de.handle_new_data(np.stack([a[pos:pos + 512], b[pos:pos + 512]]).astype(np.float64))
+        assert abs(de.delay_ms - 1e3 * 25 / 12000.0) < 0.2, (rng_s, de.delay_ms)
+
+
 def test_gcc_errors(hip):
     from friture_amd._lib import FritureHipError
     from friture_amd.signal.correlation import GccPhat, generalized_cross_correlation
-    with pytest.raises(FritureHipError):
-        GccPhat(2 * 7 * 1024, 1)         # 7 is not a supported radix
     with pytest.raises(FritureHipError):
         GccPhat(1001, 1)                 # odd length
     with pytest.raises(ValueError):
