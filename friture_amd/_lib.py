@@ -68,6 +68,13 @@ SIGNATURES = {
     "frt_freq_resample": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "frt_time_resample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "frt_fourier_resample": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int]),
+    "frt_specgram_create": (c_int, [POINTER(c_void_p), c_int, c_double, c_int]),
+    "frt_specgram_destroy": (None, [c_void_p]),
+    "frt_specgram_set_epilogue": (c_int, [c_void_p, POINTER(c_double), c_double, c_double, POINTER(c_uint32)]),
+    "frt_specgram_set_screen": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double), c_int]),
+    "frt_specgram_set_ratio": (c_int, [c_void_p, c_double, c_double]),
+    "frt_specgram_push": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, POINTER(c_int), POINTER(c_int)]),
+    "frt_specgram_reset": (c_int, [c_void_p]),
     "frt_colour_map": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "frt_exp_smooth_2d": (c_int, [c_void_p, c_int, c_double, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "frt_spectrum_post": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_int, c_double, c_void_p, c_void_p,

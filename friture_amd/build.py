@@ -31,6 +31,7 @@ CXXFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-W
 # stft.hip: packed fp32 VALU instructions (v_pk_fma_f32 ...) issue slower than the scalar pair they
 # replace on gfx950 (measured: +7 % kernel time), so SLP packing of the butterflies is off
 EXTRA_FLAGS = {"iir.hip": ["-ffp-contract=off"], "pipeline.hip": ["-ffp-contract=off"], "pitch.hip": ["-ffp-contract=off"],
+               "specgram.hip": ["-ffp-contract=off"],
                "stft.hip": ["-fno-slp-vectorize"]}
 
 

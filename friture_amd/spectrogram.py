@@ -70,3 +70,84 @@ class Spectrogram:
         self.screen_resampler.set_ratio(self.sfft_rate_frac, screen_rate_frac)
         self.frequency_resampler.setnsamples(self.screen_height)
         return self.audio_pipeline.push(norm_spectrogram)
+
+
+class SpectrogramStream:
+    """The same chain as ONE device-resident object (frt_specgram_*, specgram.hip): the samples' mirror ring, the spectra,
+    the frequency map, the time resampler's carried column and the LUT live in HBM; a chunk costs one upload of its own
+    samples, three launches and one download of the new pixel columns.  `handle_new_data` returns the block the widget
+    hands to CanvasScaledSpectrogram.addData AFTER its flip of the frequency axis (spectrogram_image.py:82-92):
+    uint32 [screen_height, columns], row 0 = highest frequency, or None when the chunk completed no frame."""
+
+    def __init__(self, fft_size=DEFAULT_FFT_SIZE, overlap=Fraction(3, 4), spec_min=-140., spec_max=0., weighting=0,
+                 scale=fscales.Mel, minfreq=20., maxfreq=20000., screen_width=800, screen_height=400,
+                 timerange_s=DEFAULT_TIMERANGE, ring_length=None):
+        import ctypes
+        from . import _lib
+        self._ct, self._libmod = ctypes, _lib
+        self._lib = _lib.init()
+        self.proc = audioproc()
+        self.overlap_frac = Fraction(overlap)
+        self.spec_min, self.spec_max, self.weighting = spec_min, spec_max, weighting
+        self.scale, self.minfreq, self.maxfreq = scale, minfreq, maxfreq
+        self.screen_width, self.screen_height, self.timerange_s = screen_width, screen_height, timerange_s
+        self._h = ctypes.c_void_p()
+        self._ring_length = ring_length
+        self._colors = Color_Transform().colors
+        self.setfftsize(fft_size)
+
+    def _release(self):
+        if self._h.value:
+            self._lib.frt_specgram_destroy(self._h)
+            self._h = self._ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def setfftsize(self, fft_size):
+        ct, check = self._ct, self._libmod.check
+        self._release()
+        self.fft_size = fft_size
+        self.proc.set_fftsize(fft_size)
+        self.freq = np.ascontiguousarray(self.proc.get_freq_scale(), np.float64)
+        ring = self._ring_length or max(10000, 4 * fft_size)           # ringbuffer.py:34 starts at 10000 and grows on demand
+        check(self._lib.frt_specgram_create(ct.byref(self._h), fft_size, float(self.overlap_frac), int(ring)))
+        A, B, C = self.proc.get_freq_weighting()
+        w = np.ascontiguousarray({0: np.zeros(A.shape), 1: A, 2: B}.get(self.weighting, C), np.float64)
+        lut = np.ascontiguousarray(self._colors, np.uint32)
+        DP, UP = ct.POINTER(ct.c_double), ct.POINTER(ct.c_uint32)
+        check(self._lib.frt_specgram_set_epilogue(self._h, w.ctypes.data_as(DP), float(self.spec_min), float(self.spec_max),
+                                                  lut.ctypes.data_as(UP)))
+        self.sfft_rate_frac = Fraction(SAMPLING_RATE, fft_size) / (Fraction(1) - self.overlap_frac) / 1000
+        self._screen = None
+
+    def _sync_screen(self):
+        ct, check = self._ct, self._libmod.check
+        key = (self.screen_height, self.scale, self.minfreq, self.maxfreq)
+        if key != self._screen:
+            lo, hi = self.scale.transform(self.minfreq), self.scale.transform(self.maxfreq)
+            targets = np.ascontiguousarray(self.scale.inverse(np.linspace(lo, hi, self.screen_height)), np.float64)
+            DP = ct.POINTER(ct.c_double)
+            check(self._lib.frt_specgram_set_screen(self._h, self.freq.ctypes.data_as(DP), targets.ctypes.data_as(DP), int(self.screen_height)))
+            self._screen = key
+        screen_rate_frac = Fraction(max(self.screen_width, 1), int(self.timerange_s * 1000))
+        # set_ratio(L, M) divides float(L) / M (online_linear_2D_resampler.py:38): the same division on the other side
+        check(self._lib.frt_specgram_set_ratio(self._h, float(self.sfft_rate_frac), float(screen_rate_frac)))
+
+    def handle_new_data(self, floatdata):
+        ct = self._ct
+        x = np.ascontiguousarray(np.asarray(floatdata, np.float64)[0])
+        self._sync_screen()
+        frames_max = x.size // max(1, int(self.fft_size * (1. - float(self.overlap_frac)))) + 2
+        ratio = float(self.sfft_rate_frac) / float(Fraction(max(self.screen_width, 1), int(self.timerange_s * 1000)))
+        max_cols = int(frames_max / ratio) + 4
+        out = np.empty((self.screen_height, max_cols), np.uint32)
+        n_cols, n_frames = ct.c_int(0), ct.c_int(0)
+        self._libmod.check(self._lib.frt_specgram_push(self._h, x.ctypes.data, x.size, out.ctypes.data, max_cols, ct.byref(n_cols),
+                                                        ct.byref(n_frames)))
+        if n_frames.value == 0:
+            return None
+        return out[:, :n_cols.value]

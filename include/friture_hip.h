@@ -152,6 +152,31 @@ int frt_decimate_multiple(frt_octbank* h, int n_stages, const double* x, int n, 
 int frt_lfilter_f64(const double* b, const double* a, int n_coef, const double* x, int n, const double* zi,
                     double* y, double* zf);
 
+/* ---- device-resident streaming spectrogram ------------------------------------------------
+ * One object does what Spectrogram_Widget.handle_new_data does per chunk (friture/spectrogram.py:131-177) and hands back
+ * the block CanvasScaledSpectrogram.addData draws (friture/spectrogram_image.py:82-129): a mirror ring of the samples in
+ * HBM (friture/ringbuffer.py:39-63; only the new chunk crosses PCIe), the realizable frames through the float64 STFT with
+ * the dB / weighting / normalise epilogue, np.interp onto the screen rows (friture/signal/frequency_resampler.py:67-83),
+ * the online time resampler with its carried column on the device (friture/signal/online_linear_2D_resampler.py:45-97),
+ * clip + LUT (friture/signal/color_tranform.py:48-51) and the flip of the frequency axis.  Float64, the reference's
+ * operations in the reference's order: the pixels are the reference's pixels.
+ * overlap as in the widget (0.75 default): needed = fft_size (1 - overlap), hop = int(needed).  ring_length >= 2 fft_size. */
+typedef struct frt_specgram frt_specgram;
+int frt_specgram_create(frt_specgram** h, int fft_size, double overlap, int ring_length);
+void frt_specgram_destroy(frt_specgram* h);
+/* weight_db [fft_size/2+1] or NULL, dB range, 256 colour words */
+int frt_specgram_set_epilogue(frt_specgram* h, const double* weight_db, double spec_min, double spec_max, const uint32_t* lut256);
+/* freq [fft_size/2+1] bin frequencies, targets [height] screen-row frequencies (Frequency_Resampler.xscaled).  A changed
+ * height Fourier-resamples the carried column (Online_Linear_2D_resampler.set_height). */
+int frt_specgram_set_screen(frt_specgram* h, const double* freq, const double* targets, int height);
+/* Online_Linear_2D_resampler.set_ratio: STFT rate / pixel rate as the two numbers the widget passes */
+int frt_specgram_set_ratio(frt_specgram* h, double interp_factor_L, double decim_factor_M);
+/* chunk: n new samples (host, float64).  pixels_out: [height][max_cols] uint32 (host or device), row 0 = highest frequency;
+ * *n_cols_out columns are written (often 0), *n_frames_out (nullable) spectra were computed. */
+int frt_specgram_push(frt_specgram* h, const double* chunk, int n, uint32_t* pixels_out, int max_cols, int* n_cols_out,
+                      int* n_frames_out);
+int frt_specgram_reset(frt_specgram* h);
+
 /* ---- K5: GCC-PHAT cross-correlation and the delay read-out --------------------------------------
  * frt_gcc_phat replaces generalized_cross_correlation (friture/signal/correlation.py:24-43): mean
  * removal, numpy.hanning window, two real FFTs, conj(D0) D1, PHAT weight 1/(1e-10 max|G| + |G|),

@@ -136,3 +136,38 @@ def test_spectrogram_chain(hip):
         mismatched += int(np.sum(got != want))
     # the GPU STFT differs from pocketfft in the last bits: a pixel can flip only at a LUT bin edge
     assert total_px > 0 and mismatched <= 1e-3 * total_px
+
+
+def test_spectrogram_stream_equals_host_chain(hip):
+    """SpectrogramStream (one device-resident object: ring, spectra, frequency map, carried column, LUT in HBM) against
+    the block-by-block chain of Spectrogram (three host-staged pipeline blocks): the same float64 operations in the same
+    order, so the SAME pixels — bit for bit, after the widget's flip of the frequency axis — over ragged chunks, more
+    samples than the ring holds, a resize of the plot, a change of the time range and of the frequency scale."""
+    from fractions import Fraction
+
+    from friture_amd.plotting import frequency_scales as fs
+    from friture_amd.spectrogram import Spectrogram, SpectrogramStream
+    kw = dict(fft_size=1024, overlap=Fraction(3, 4), weighting=1, screen_width=500, screen_height=137, timerange_s=3.0)
+    host, dev = Spectrogram(**kw), SpectrogramStream(ring_length=6000, **kw)
+    x = np.concatenate([synth("chirp", 30000, 4), synth("noise", 30000, 5), synth("tone", 20000, 6)]).astype(np.float64)
+    pos, blocks, cols = 0, 0, 0
+    for step, n in enumerate([512] * 20 + [100, 7, 3000, 512, 1, 1, 2048] + [512] * 60 + [1500, 37] * 8):
+        if step == 30:
+            host.screen_height = dev.screen_height = 211                    # window resized: Fourier-resampled carried column
+        if step == 45:
+            host.timerange_s = dev.timerange_s = 1.0                        # other pixel rate: indices restart
+        if step == 60:
+            host.frequency_resampler.setfreqscale(fs.Logarithmic)
+            dev.scale = fs.Logarithmic
+        if step == 75:
+            host.screen_height = dev.screen_height = 64
+        chunk = x[None, pos:pos + n]
+        pos += n
+        a, b = host.handle_new_data(chunk), dev.handle_new_data(chunk)
+        assert (a is None) == (b is None), step
+        if a is not None:
+            assert b.shape == a.shape and b.dtype == np.uint32, (step, a.shape, b.shape)
+            assert np.array_equal(b, a[::-1, :]), step
+            blocks += 1
+            cols += a.shape[1]
+    assert blocks > 50 and cols > 300 and pos > 6000 * 9          # the 6000-sample ring wrapped nine times

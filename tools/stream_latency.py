@@ -1,0 +1,78 @@
+#!/usr/bin/env python
+"""Per-push latency of the interactive chains: 1000 pushes of 512 samples (one audio chunk, 10.7 ms of signal).
+
+    python tools/stream_latency.py > gpurun_out/stream_latency.json
+
+For every chain: p50 / p99 / mean of the wall time of handle_new_data as the widget would call it — host buffer in, result
+on the host — for the device-resident object, for the block-by-block drop-in classes (each block its own host-staged call)
+and for the numpy oracle (the reference's arithmetic on this box's host, 1 core)."""
+import json
+import sys
+import time
+from fractions import Fraction
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def stats(ts):
+    ts = np.sort(np.asarray(ts)) * 1e6
+    return {"p50_us": float(ts[len(ts) // 2]), "p99_us": float(ts[int(len(ts) * 0.99)]), "mean_us": float(ts.mean()), "pushes": len(ts)}
+
+
+def time_pushes(fn, chunks):
+    out = []
+    for c in chunks:
+        t0 = time.perf_counter()
+        fn(c)
+        out.append(time.perf_counter() - t0)
+    return out
+
+
+def main():
+    from friture_amd import _lib
+    from friture_amd.spectrogram import Spectrogram, SpectrogramStream
+    from oracle import dsp
+    _lib.init(0)
+    rng = np.random.default_rng(0)
+    n_push, chunk = 1000, 512
+    x = 0.25 * rng.standard_normal((n_push + 50) * chunk)
+    chunks = [x[None, i * chunk:(i + 1) * chunk] for i in range(n_push + 50)]
+    res = {}
+    for n_fft in (1024, 4096):
+        kw = dict(fft_size=n_fft, overlap=Fraction(3, 4), weighting=1, screen_width=800, screen_height=400, timerange_s=10.0)
+        dev, host = SpectrogramStream(**kw), Spectrogram(**kw)
+        for name, obj in (("device_resident", dev), ("block_by_block", host)):
+            time_pushes(obj.handle_new_data, chunks[:50])                 # warm-up: allocations, first launches
+            res[f"spectrogram_N{n_fft}_{name}"] = stats(time_pushes(obj.handle_new_data, chunks[50:]))
+        # the oracle's chain (numpy float64, the reference's arithmetic)
+        lut = dsp.colour_lut(dsp.cmrmap())
+        w = dsp.weighting_curves(dsp.frequency_axis(n_fft))[0]
+        tg = dsp.frequency_targets("mel", 20.0, 20000.0, 400)
+        sfft = Fraction(48000, n_fft) / (Fraction(1) - Fraction(3, 4)) / 1000
+        tr = dsp.TimeResampler(sfft, Fraction(800, 10000), 400)
+        ring, state = dsp.MirrorRing(), {"old": 0}
+        hop, win, fax = n_fft // 4, dsp.hann_symmetric(n_fft), dsp.frequency_axis(n_fft)
+
+        def oracle_push(c):
+            ring.push(c)
+            realizable = int(np.floor((ring.offset - state["old"]) / float(hop)))
+            if realizable <= 0:
+                return None
+            cols = []
+            for _ in range(realizable):
+                cols.append(dsp.psd_frame(ring.data_indexed(state["old"], n_fft)[0], win))
+                state["old"] += hop
+            norm = dsp.normalise(dsp.log_spectrum(np.stack(cols, axis=1)) + w[:, None], -140.0, 0.0)
+            return dsp.colour_pixels(lut, tr.push(dsp.frequency_resample(tg, fax, norm)))[::-1, :]
+
+        time_pushes(oracle_push, chunks[:50])
+        res[f"spectrogram_N{n_fft}_numpy_oracle"] = stats(time_pushes(oracle_push, chunks[50:250]))
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
