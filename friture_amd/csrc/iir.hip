@@ -1063,7 +1063,9 @@ extern "C" int frt_octbank_filter(frt_octbank* h, const double* x, int n, double
 extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, int block, const double* alphas,
                                     const double* weight_db, int as_db, float* energy_out) {
     FRT_REQUIRE(h && h->bpo >= 1, "frt_octbank_energies: needs a handle with bands");
-    FRT_REQUIRE(block >= 256 && (block & (block - 1)) == 0, "frt_octbank_energies: block %d must be a power of two >= 256", block);
+    // mode 1, ONE block of any length up to 1024 = the octave-spectrum widget's chunk handler (octavespectrum.py:91-122)
+    const bool chunk_call = h->mode == 1 && n == block && block >= 1 && block <= 1024;
+    FRT_REQUIRE(chunk_call || (block >= 256 && (block & (block - 1)) == 0), "frt_octbank_energies: block %d must be a power of two >= 256", block);
     FRT_REQUIRE(h->mode == 0 || block <= 1024, "frt_octbank_energies: the FFT bank's cadence is blocks of at most 1024 samples");
     FRT_REQUIRE(n > 0 && n % block == 0 && n < (1ll << 31), "frt_octbank_energies: n must be a positive multiple of block");
     FRT_REQUIRE(h->chunk0 == 0 || h->chunk0 % block == 0, "frt_octbank_energies: chunk must be a multiple of block");
@@ -1072,8 +1074,15 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
     const size_t ecount = (size_t)h->n_channels * nblocks * h->nbands;
     int rc;
     std::vector<double> al(alphas, alphas + h->nbands), dn(h->nbands);
-    for (int k = 0; k < h->nbands; ++k)      // (1 - alpha)^n with n = block / dec samples of the band
-        dn[k] = std::pow(1.0 - al[k], (double)(block >> (kNOctave - 1 - k / h->bpo)));
+    {
+        long long slen[kNOctave];
+        slen[0] = block;
+        for (int j = 1; j < kNOctave; ++j) slen[j] = (slen[j - 1] + 1) / 2;
+        for (int k = 0; k < h->nbands; ++k) {    // (1 - alpha)^m with m = the band's samples per block (block / dec; ceil chain for a ragged chunk)
+            const int j = kNOctave - 1 - k / h->bpo;
+            dn[k] = std::pow(1.0 - al[k], (double)(chunk_call ? slen[j] : (long long)(block >> j)));
+        }
+    }
     if ((rc = upload_if_changed(h->alpha, h->alpha_host, al, h->stream)) || (rc = upload_if_changed(h->decay_n, h->decay_host, dn, h->stream)) ||
         (rc = h->eblock.reserve(ecount * sizeof(double))))
         return rc;

@@ -379,7 +379,8 @@ __global__ void __launch_bounds__(kObThreads) ola_batch_kernel(const OlaBatchArg
             if (a.eblock) {
                 // zero-state block energies alpha sum_i (1-alpha)^(m-1-i) y_i^2 (exp_smoothing.py:40-56): groups of
                 // w = min(m, 64) lanes per energy block, fixed summation order
-                const int m = a.elen, w = m < 64 ? m : 64, per_wave = 64 / w;
+                // (a power of two below 64: that many lanes per block and several blocks per wave; anything else: a whole wave)
+                const int m = a.elen, w = (m < 64 && (m & (m - 1)) == 0) ? m : 64, per_wave = 64 / w;
                 const int lane = tid & 63, wave = tid >> 6, sub = lane / w, li = lane - sub * w;
                 const double* wt = a.ewt + a.ewt_off[f];
                 const int ne = Lb / m;
@@ -445,6 +446,8 @@ static int ola_batch_tables(frt_octbank* h) {
 int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, double* d_y, int64_t y_cstride,
                          double* d_eblock, int eblock0, int nblocks, const double* alphas) {
     frt_ola_state* o = h->ola;
+    // one energy block = the whole call (the widget's chunk, any length): a band's block is its stage's whole output
+    const bool whole = d_eblock && nblocks == 1 && eblock0 == n;
     int rc;
     if ((rc = ola_batch_tables(h))) return rc;
     long long len[kNOctave];
@@ -462,8 +465,11 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
         if (!same) {
             o->ewt_off.assign(h->nbands, 0);
             std::vector<double> wt;
+            long long slen[kNOctave];
+            slen[0] = n;
+            for (int j = 1; j < kNOctave; ++j) slen[j] = (slen[j - 1] + 1) / 2;
             for (int k = 0; k < h->nbands; ++k) {
-                const int m = eblock0 >> (kNOctave - 1 - k / h->bpo);
+                const int m = whole ? (int)slen[kNOctave - 1 - k / h->bpo] : eblock0 >> (kNOctave - 1 - k / h->bpo);
                 o->ewt_off[k] = (long long)wt.size();
                 for (int i = 0; i < m; ++i) wt.push_back(alphas[k] * std::pow(1.0 - alphas[k], (double)(m - 1 - i)));
             }
@@ -490,7 +496,7 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
         a.y = d_y;
         a.y_cstride = y_cstride;
         a.eblock = d_eblock;
-        a.elen = d_eblock ? (eblock0 >> j) : 1;
+        a.elen = !d_eblock ? 1 : whole ? (int)len[j] : (eblock0 >> j);
         a.nblocks = nblocks;
         a.nbands = h->nbands;
         a.ewt = o->ewt.as<double>();

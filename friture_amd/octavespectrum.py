@@ -50,3 +50,30 @@ class OctaveSpectrum:
         w = {0: 0., 1: self.filters.A, 2: self.filters.B}.get(self.weighting, self.filters.C)
         db_spectrogram = 10 * np.log10(sp + 1e-30) + w
         return self.filters.flow, self.filters.fhigh, self.filters.f_nominal, db_spectrogram
+
+
+class OctaveSpectrumStream(OctaveSpectrum):
+    """The same chain with everything between the chunk and the 9 x bpo dB values on the device: the FIR bank's tails, the
+    smoothed energies and the weighting live in the bank object (frt_octbank_energies in mode 1, one block = the chunk);
+    a chunk costs one upload of its samples and one download of the band vector.  Values are float32 on the way out
+    (1e-7 relative; the north star's band-energy tolerance is 1e-5)."""
+
+    def __init__(self, bandsperoctave: int = DEFAULT_BANDSPEROCTAVE, weighting: int = 1,
+                 response_time: float = DEFAULT_RESPONSE_TIME):
+        super().__init__(bandsperoctave, weighting, response_time)
+        from .filter import FirBank
+        self._bank = FirBank(bandsperoctave, 1)
+
+    def setbandsperoctave(self, bandsperoctave):
+        super().setbandsperoctave(bandsperoctave)
+        from .filter import FirBank
+        self._bank = FirBank(bandsperoctave, 1)
+
+    def handle_new_data(self, floatdata):
+        n = floatdata.shape[1]
+        if n == 0:
+            return None
+        w = {0: np.zeros(len(self.alphas)), 1: self.filters.A, 2: self.filters.B}.get(self.weighting, self.filters.C)
+        x = np.ascontiguousarray(floatdata[0:1, :], np.float32)
+        db = self._bank.energies(x, n, np.asarray(self.alphas), weight_db=w, as_db=True)[0, 0]
+        return self.filters.flow, self.filters.fhigh, self.filters.f_nominal, db.astype(np.float64)

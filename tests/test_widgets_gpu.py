@@ -171,3 +171,20 @@ def test_spectrogram_stream_equals_host_chain(hip):
             blocks += 1
             cols += a.shape[1]
     assert blocks > 50 and cols > 300 and pos > 6000 * 9          # the 6000-sample ring wrapped nine times
+
+
+def test_octave_spectrum_stream_equals_host_chain(hip):
+    """OctaveSpectrumStream (FIR bank tails, smoothed energies, weighting all on the device; float32 band vector out)
+    against OctaveSpectrum (band signals back to the host, smoothing per decimation class) over the widget's 512-sample
+    chunks and ragged ones: 1e-5 on the energies = 4.3e-5 dB."""
+    from friture_amd.octavespectrum import OctaveSpectrum, OctaveSpectrumStream
+    for bpo in (3, 12):
+        a, b = OctaveSpectrum(bpo, weighting=1, response_time=0.125), OctaveSpectrumStream(bpo, weighting=1, response_time=0.125)
+        x = synth("noise", 20000, 40 + bpo).astype(np.float64)         # float32-representable, like captured audio
+        pos = 0
+        for n in [512] * 12 + [100, 333, 1024, 7, 512, 1, 640]:
+            chunk = x[None, pos:pos + n]
+            pos += n
+            ra, rb = a.handle_new_data(chunk), b.handle_new_data(chunk)
+            assert ra[2] == rb[2] and np.array_equal(ra[0], rb[0])
+            assert np.max(np.abs(ra[3] - rb[3])) <= 4.4e-5, (bpo, n, float(np.max(np.abs(ra[3] - rb[3]))))

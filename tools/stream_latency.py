@@ -71,6 +71,27 @@ def main():
 
         time_pushes(oracle_push, chunks[:50])
         res[f"spectrogram_N{n_fft}_numpy_oracle"] = stats(time_pushes(oracle_push, chunks[50:250]))
+    # ---- octave spectrum: 1/3 and 1/24 octave -------------------------------------------------------------------
+    from friture_amd.octavespectrum import OctaveSpectrum, OctaveSpectrumStream
+    xf = [c.astype(np.float32).astype(np.float64) for c in chunks]
+    for bpo in (3, 24):
+        dev, host = OctaveSpectrumStream(bpo, 1, 1.0), OctaveSpectrum(bpo, 1, 1.0)
+        for name, obj in (("device_resident", dev), ("block_by_block", host)):
+            time_pushes(obj.handle_new_data, xf[:50])
+            res[f"octave_bpo{bpo}_{name}"] = stats(time_pushes(obj.handle_new_data, xf[50:]))
+        bank = dsp.OlaBank(bpo)
+        alphas, kernels = dsp.band_smoothing_setup(bpo, 1.0)
+        fi, _, _ = dsp.octave_frequencies(9 * bpo, bpo)
+        A = dsp.band_weighting(fi)[0]
+        st = {"prev": [0.0] * (9 * bpo)}
+
+        def oracle_oct(c):
+            y, _ = bank.filter(c[0])
+            st["prev"] = dsp.band_energies(y, kernels, alphas, st["prev"])
+            return dsp.band_db(np.array(st["prev"]), A)
+
+        time_pushes(oracle_oct, xf[:20])
+        res[f"octave_bpo{bpo}_numpy_oracle"] = stats(time_pushes(oracle_oct, xf[50:250]))
     print(json.dumps(res, indent=1))
 
 
