@@ -14,16 +14,22 @@ from .constants import SAMPLING_RATE
 
 
 class RingBuffer:
-    def __init__(self):
+    """`zeros(shape)` makes the storage: numpy on the host (the default, what the widgets share), or — DeviceRingBuffer —
+    a torch CUDA tensor, in which case pushes, windows and the growth are device-to-device slices and the windows handed
+    out are device memory (same indices, same mirror layout, same growth rule: a view mutated in place, as
+    generalized_cross_correlation does to its arguments, changes the same copy of the same samples)."""
+
+    def __init__(self, zeros=None):
+        self._zeros = zeros or (lambda shape: np.zeros(shape))
         self.buffer_length = 10000
-        self.buffer = np.zeros((1, 2 * self.buffer_length))
+        self.buffer = self._zeros((1, 2 * self.buffer_length))
         self.offset = 0
         self.offset_time = 0
 
     def push(self, floatdata, input_time: float = 0.) -> None:
         channels, count = floatdata.shape
         if channels != self.buffer.shape[0]:
-            self.buffer = np.zeros((channels, 2 * self.buffer_length))   # mono <-> stereo switch starts afresh
+            self.buffer = self._zeros((channels, 2 * self.buffer_length))   # mono <-> stereo switch starts afresh
         self.grow_if_needed(count)
         size = self.buffer_length
         head = self.offset % size
@@ -64,10 +70,19 @@ class RingBuffer:
         if length <= self.buffer_length:
             return
         old, new = self.buffer_length, int(1.5 * length)
-        grown = np.zeros((self.buffer.shape[0], 2 * new))
+        grown = self._zeros((self.buffer.shape[0], 2 * new))
         shift = (self.offset % new - self.offset % old) % new            # keeps self.offset meaningful
         grown[:, shift:shift + old] = self.buffer[:, :old]
         straight = min(old, new - shift)
         grown[:, new + shift:new + shift + straight] = self.buffer[:, :straight]
         grown[:, :old - straight] = self.buffer[:, straight:old]
         self.buffer, self.buffer_length = grown, new
+
+
+class DeviceRingBuffer(RingBuffer):
+    """The same ring in HBM (float64 torch tensor on the current CUDA device)."""
+
+    def __init__(self):
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        super().__init__(lambda shape: torch.zeros(shape, dtype=torch.float64, device=dev))

@@ -66,9 +66,11 @@ class GccPhat:
             assert d0.is_cuda and d0.dtype == torch.float64 and d0.is_contiguous() and d1.is_contiguous()
             out = torch.empty_like(d0)
             am = torch.empty(self.n_pairs, dtype=torch.int32, device=d0.device)
+            self.means = torch.empty((self.n_pairs, 2), dtype=torch.float64, device=d0.device)      # of d0 / d1, per pair
             _lib.check(self._lib.frt_gcc_set_stream(self._h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
             _lib.check(self._lib.frt_gcc_phat(self._h, ctypes.c_void_p(d0.data_ptr()), ctypes.c_void_p(d1.data_ptr()),
-                                              ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(am.data_ptr()), None))
+                                              ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(am.data_ptr()),
+                                              ctypes.c_void_p(self.means.data_ptr())))
             return out, am
         d0 = np.ascontiguousarray(d0, np.float64).reshape(self.n_pairs, self.length)
         d1 = np.ascontiguousarray(d1, np.float64).reshape(self.n_pairs, self.length)
@@ -80,6 +82,16 @@ class GccPhat:
     def readout(self, xcorr, old_smoothed, sample_rate, delayrange_s, alpha=0.3):
         """Smoothing + peak pick + delay / confidence (delay_estimator.py:134-176).
         Returns (smoothed [n_pairs, length], list of DelayReadout)."""
+        if type(xcorr).__module__.startswith("torch"):
+            import torch
+            assert xcorr.is_cuda and xcorr.dtype == torch.float64 and xcorr.is_contiguous()
+            sm = torch.empty_like(xcorr)
+            ro = (_lib.DelayReadout * self.n_pairs)()
+            _lib.check(self._lib.frt_gcc_set_stream(self._h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            _lib.check(self._lib.frt_gcc_readout(self._h, ctypes.c_void_p(xcorr.data_ptr()),
+                                                 None if old_smoothed is None else ctypes.c_void_p(old_smoothed.data_ptr()), alpha,
+                                                 float(sample_rate), float(delayrange_s), ctypes.c_void_p(sm.data_ptr()), ctypes.byref(ro)))
+            return sm, list(ro)
         x = np.ascontiguousarray(xcorr, np.float64).reshape(self.n_pairs, self.length)
         old = None if old_smoothed is None else np.ascontiguousarray(old_smoothed, np.float64).reshape(x.shape)
         sm = np.empty_like(x)

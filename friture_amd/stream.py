@@ -15,19 +15,52 @@ from .stft import StftEngine
 
 
 class StftStream:
+    """The unconsumed samples live in a mirror ring in HBM (the layout of friture/ringbuffer.py:39-63: every sample is
+    stored at p and p + L, so any window of up to L samples is one contiguous slice): a push writes the new samples twice
+    and transforms, in place, every frame that became realizable — nothing is shifted or copied afterwards."""
+
     def __init__(self, fft_size: int, hop: int, n_channels: int = 1, max_chunk: int = 1 << 16):
         import torch
         self._torch = torch
         self.fft_size, self.hop, self.n_channels = fft_size, hop, n_channels
         self.engine = StftEngine(fft_size, hop, n_channels, 32)
         self._dev = torch.device("cuda", torch.cuda.current_device())
-        self._cap = fft_size + max_chunk + hop
-        self._buf = torch.zeros((n_channels, self._cap), dtype=torch.float32, device=self._dev)
-        self._fill = 0                       # valid samples at the head of the buffer
+        self._len = fft_size + max_chunk + hop                 # samples the ring retains
+        self._len += self._len & 1                             # even: windows keep the parity of their stream index
+        self._buf = torch.zeros((n_channels, 2 * self._len), dtype=torch.float32, device=self._dev)
+        self._offset = 0                                       # samples pushed so far
+        self._consumed = 0                                     # stream index of the first sample the next frame needs
         self.frames_emitted = 0
 
     def set_epilogue(self, *args, **kw):
         self.engine.set_epilogue(*args, **kw)
+
+    def _grow(self, need):
+        torch = self._torch
+        old_len, new_len = self._len, int(1.5 * need)
+        new_len += new_len & 1
+        grown = torch.zeros((self.n_channels, 2 * new_len), dtype=torch.float32, device=self._dev)
+        keep = self._offset - self._consumed                   # the unconsumed tail, re-laid at its new positions
+        if keep:
+            tail = self._window(self._consumed, keep).clone()
+            self._len, self._buf = new_len, grown
+            self._write(self._consumed, tail)
+        else:
+            self._len, self._buf = new_len, grown
+
+    def _window(self, start, length):
+        p = start % self._len
+        return self._buf[:, p:p + length]
+
+    def _write(self, start, data):
+        n, L = data.shape[1], self._len
+        p = start % L
+        straight = min(n, L - p)
+        self._buf[:, p:p + straight].copy_(data[:, :straight], non_blocking=True)
+        self._buf[:, p + L:p + L + straight].copy_(data[:, :straight], non_blocking=True)
+        if n > straight:
+            self._buf[:, :n - straight].copy_(data[:, straight:], non_blocking=True)
+            self._buf[:, L:L + n - straight].copy_(data[:, straight:], non_blocking=True)
 
     def push(self, chunk, kind: int = 0):
         """chunk: [C, n] float32 (numpy, uploaded; or a CUDA tensor).  Returns the new frames
@@ -38,25 +71,19 @@ class StftStream:
         if chunk.dim() == 1:
             chunk = chunk[None, :]
         n = chunk.shape[1]
-        if self._fill + n > self._cap:       # grow the device window like the host ring does (x1.5)
-            cap = int(1.5 * (self._fill + n))
-            grown = torch.zeros((self.n_channels, cap), dtype=torch.float32, device=self._dev)
-            grown[:, :self._fill] = self._buf[:, :self._fill]
-            self._buf, self._cap = grown, cap
-        self._buf[:, self._fill:self._fill + n].copy_(chunk, non_blocking=True)
-        self._fill += n
-        frames = self.engine.frames_for(self._fill)
+        if (self._offset - self._consumed) + n > self._len:
+            self._grow((self._offset - self._consumed) + n)
+        self._write(self._offset, chunk.to(self._dev, non_blocking=True) if not chunk.is_cuda else chunk)
+        self._offset += n
+        avail = self._offset - self._consumed
+        frames = self.engine.frames_for(avail)
         bins = self.fft_size // 2 + 1
         out_dtype = torch.int32 if kind == 3 else torch.float32
         out = torch.empty((self.n_channels, frames, bins), dtype=out_dtype, device=self._dev)
         if frames:
-            # the engine wants a contiguous [C, T] view: run on the filled prefix via the row stride
-            view = self._buf[:, :self._fill]
-            self._run_strided(kind, view, out)
-            consumed = frames * self.hop
-            keep = self._fill - consumed
-            self._buf[:, :keep] = self._buf[:, consumed:self._fill].clone()
-            self._fill = keep
+            span = self.fft_size + (frames - 1) * self.hop
+            self._run_strided(kind, self._window(self._consumed, span), out)
+            self._consumed += frames * self.hop
             self.frames_emitted += frames
         return out
 

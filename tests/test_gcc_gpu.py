@@ -189,3 +189,25 @@ def test_configs4_full_size_properties(hip):
     for w in (0, 41, 99):
         ref, _, _ = dsp.gcc_phat(d0[w].copy(), d1[w].copy())
         assert np.max(np.abs(x01n[w] - ref)) <= 1e-9 * np.max(np.abs(ref))
+
+
+def test_delay_estimator_stream_equals_host_chain(hip):
+    """DelayEstimatorStream (decimator states, 12 kHz rings, windows, correlation and read-out resident in HBM) against
+    DelayEstimator (host rings, every stage a host-staged call): the same read-out chunk after chunk — including the ring
+    growth of the default 1 s range (24000-sample windows in a 10000-sample ring) and the in-place mean removal."""
+    from friture_amd.delay_estimator import DelayEstimator, DelayEstimatorStream
+    for rng_s in (0.3, 1.0):
+        a, b = DelayEstimator(rng_s), DelayEstimatorStream(rng_s)
+        rng = np.random.default_rng(int(rng_s * 100))
+        n = int(48000 * rng_s * 5.2)
+        x0 = (0.25 * rng.standard_normal(n) + 0.01).astype(np.float32)        # a DC offset: the means matter
+        x1 = np.roll(x0, 4 * 31) - 0.02 + (0.01 * rng.standard_normal(n)).astype(np.float32)
+        windows = 0
+        for pos in range(0, n - 512, 512):
+            chunk = np.stack([x0[pos:pos + 512], x1[pos:pos + 512]]).astype(np.float64)
+            a.handle_new_data(chunk)
+            b.handle_new_data(chunk)
+            assert a.correlation == b.correlation and abs(a.delay_ms - b.delay_ms) <= 1e-12, (rng_s, pos)
+            assert abs(a.Xcorr_extremum - b.Xcorr_extremum) <= 1e-12 * max(abs(a.Xcorr_extremum), 1e-30)
+            windows += a.delay_ms != 0.
+        assert windows > 0 and abs(a.delay_ms - 1e3 * 31 / 12000.0) < 0.1

@@ -92,6 +92,33 @@ def main():
 
         time_pushes(oracle_oct, xf[:20])
         res[f"octave_bpo{bpo}_numpy_oracle"] = stats(time_pushes(oracle_oct, xf[50:250]))
+    # ---- delay estimator: 2 channels, default 1 s range (24000-sample windows every 12000 decimated samples) ------------
+    from friture_amd.delay_estimator import DelayEstimator, DelayEstimatorStream
+    from friture_amd import filter_design
+    t = filter_design.load_tables()
+    x2 = [np.stack([c[0], np.roll(c[0], 40)]) for c in xf]
+    for name, obj in (("device_resident", DelayEstimatorStream(1.0)), ("block_by_block", DelayEstimator(1.0))):
+        time_pushes(obj.handle_new_data, x2[:50])
+        res[f"delay_{name}"] = stats(time_pushes(obj.handle_new_data, x2[50:]))
+    bdec, adec = np.array(t["bdec"]), np.array(t["adec"])
+    z = [dsp.decimate_multiple_filtic(2, bdec, adec), dsp.decimate_multiple_filtic(2, bdec, adec)]
+    rings, st2 = [dsp.MirrorRing(), dsp.MirrorRing()], {"old_index": 0, "old": None}
+
+    def oracle_delay(c):
+        for ch in range(2):
+            d, z[ch] = dsp.decimate_multiple(2, bdec, adec, c[ch], z[ch])
+            rings[ch].push(d[None, :])
+        avail = rings[0].offset - st2["old_index"]
+        for _ in range(int(avail / 12000)):
+            st2["old_index"] += 12000
+            d0 = rings[0].data_indexed(st2["old_index"], 24000).reshape(-1)
+            d1 = rings[1].data_indexed(st2["old_index"], 24000).reshape(-1)
+            xc, _, _ = dsp.gcc_phat(d0, d1)
+            ro = dsp.delay_readout(xc, st2["old"], 12000.0, 1.0)
+            st2["old"] = ro["smoothed"]
+
+    time_pushes(oracle_delay, x2[:50])
+    res["delay_numpy_oracle"] = stats(time_pushes(oracle_delay, x2[50:450]))
     print(json.dumps(res, indent=1))
 
 
