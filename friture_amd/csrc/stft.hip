@@ -214,12 +214,17 @@ stft_kernel(const StftArgs a) {
         return {(T)xc[s], (T)xc[s + 1]};
     };
 
+    // The register window.  A hop advances the frame by NEW of its 8 slots; the other 8 - NEW were loaded for earlier
+    // frames.  The window is kept as NSETS = 8 / NEW physical sets of NEW slots whose ROLES rotate from frame to frame
+    // (frame g finds its logical block b in physical set (b + g) mod NSETS) instead of their contents being moved: the
+    // frame loop is unrolled NSETS times with the roles as compile-time constants, the set holding the oldest block is
+    // refilled as soon as the window multiply has read it, and no register is ever copied (the copies were 16 of the
+    // ~600 instructions a frame issues).
     constexpr int NEW = SHIFT == 0 ? 8 : SHIFT;       // slots fetched per frame
-    C raw[8], nxt[NEW];
+    constexpr int NSETS = 8 / NEW;
+    C raw[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) raw[j] = {(T)0, (T)0};
-#pragma unroll
-    for (int t = 0; t < NEW; ++t) nxt[t] = {(T)0, (T)0};
     if (nfr > 0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) raw[j] = load_slot(f0, j);
@@ -231,21 +236,15 @@ stft_kernel(const StftArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), other counters untouched
 
     const int nloop = a.run;                          // uniform trip count keeps barriers aligned
-    for (int g = 0; g < nloop; ++g) {
+    // one frame; `phase` = g mod NSETS as a compile-time constant; false = the run is finished
+    auto frame = [&](auto phase, const int g) -> bool {
+        constexpr int PH = decltype(phase)::value;
+        if (g >= nloop) return false;
         const bool valid = g < nfr;
         if (!WAVE) {
-            if (!__syncthreads_or(valid)) break;      // whole block finished
+            if (!__syncthreads_or(valid)) return false;      // whole block finished
         } else if (!__any(valid)) {
-            break;
-        }
-        // prefetch the new slots of the next frame
-#ifdef FRT_ABLATE
-        if (g + 1 < nfr && !(a.ablate & 2)) {
-#else
-        if (g + 1 < nfr) {
-#endif
-#pragma unroll
-            for (int t = 0; t < NEW; ++t) nxt[t] = load_slot(f0 + g + 1, 8 - NEW + t);
+            return false;
         }
 
         int zero = 0;
@@ -260,7 +259,26 @@ stft_kernel(const StftArgs a) {
             } else {
                 wj = ((const C*)wtab)[i + j * TPF + zero];
             }
-            v[j] = {raw[j].x * wj.x, raw[j].y * wj.y};
+            const C r = raw[((j / NEW + PH) % NSETS) * NEW + j % NEW];      // logical slot j of this frame
+            v[j] = {r.x * wj.x, r.y * wj.y};
+        }
+        // The set that held the oldest block has been read: request the next frame's new slots into it now, a whole
+        // transform ahead of their use.
+        // (Unconditional, with the frame index clamped to the run's last frame: a conditional refill makes every slot a
+        // merge of "old value" and "loaded value", which the register allocator resolves with copies at the loop's
+        // back-edge — the very moves this scheme removes.  The one redundant request per run re-reads slots this wave
+        // fetched a frame ago.)
+        if constexpr (NSETS > 1) {
+            long long gn = g + 1 < nfr ? g + 1 : nfr - 1;
+            if (gn < 0) gn = 0;
+#ifdef FRT_ABLATE
+            if (a.ablate & 2) gn = 0;
+#endif
+#pragma unroll
+            for (int t = 0; t < NEW; ++t) raw[PH * NEW + t] = load_slot(f0 + gn, 8 - NEW + t);
+        } else if (g + 1 < nfr) {       // a hop that reloads the whole frame: the redundant request would be a whole frame
+#pragma unroll
+            for (int t = 0; t < 8; ++t) raw[t] = load_slot(f0 + g + 1, t);
         }
 
 #ifdef FRT_ABLATE
@@ -324,22 +342,11 @@ stft_kernel(const StftArgs a) {
         }
         T res_mid = (v[4].x * v[4].x + v[4].y * v[4].y) * (T)4;               // bin M/2, meaningful for i == 0
 
-        // Advance the register window by one hop *before* the stores are issued: the wait for the
-        // prefetched samples then sits behind a whole transform (latency hidden) and ahead of this
-        // frame's stores, so it never has to wait for store acknowledgements.
-        // (Unconditional although only meaningful when a prefetch was issued: with the shift under the prefetch's own
-        // condition the compiler's wait-count pass sees a path "loads issued, wait skipped" into the next trip and,
-        // depending on register assignment, guards the top of the loop with vmcnt(0..3) — i.e. with the acknowledgement
-        // of this frame's row stores: +5 % when the IMAGE kind's rare path changed the assignment.)
-        {
+        // The prefetched slots are waited for HERE, in front of this frame's stores: the vector-memory counter retires in
+        // order, so a first use behind the stores (the next frame's window multiply) could only be guarded by vmcnt(0) —
+        // the acknowledgement of every row store.  The empty asm makes the loaded values a use at this point.
 #pragma unroll
-            for (int j = 0; j < 8 - NEW; ++j) raw[j] = raw[j + NEW];
-#pragma unroll
-            for (int t = 0; t < NEW; ++t) raw[8 - NEW + t] = nxt[t];
-            // the new slots exist HERE, in front of the stores (otherwise the moves sink to the loop latch, behind them)
-#pragma unroll
-            for (int t = 0; t < NEW; ++t) asm volatile("" : "+v"(raw[8 - NEW + t].x), "+v"(raw[8 - NEW + t].y));
-        }
+        for (int t = 0; t < NEW; ++t) asm volatile("" : "+v"(raw[PH * NEW + t].x), "+v"(raw[PH * NEW + t].y));
 
 #ifdef FRT_ABLATE
         if (a.ablate & 1) {
@@ -461,6 +468,17 @@ stft_kernel(const StftArgs a) {
                     store_all(row, [](T x) { return x; });
                 }
             }
+        }
+        return true;
+    };
+    for (int g = 0; g < nloop; g += NSETS) {
+        if (!frame(std::integral_constant<int, 0>{}, g)) break;
+        if constexpr (NSETS > 1) {
+            if (!frame(std::integral_constant<int, 1>{}, g + 1)) break;
+        }
+        if constexpr (NSETS > 2) {
+            if (!frame(std::integral_constant<int, 2>{}, g + 2)) break;
+            if (!frame(std::integral_constant<int, 3>{}, g + 3)) break;
         }
     }
 }
