@@ -246,6 +246,124 @@ __global__ void __launch_bounds__(kGccThreads) gcc_readout_kernel(const double* 
 }
 
 
+// ---- the same transform as three phases of SMALL workgroups ---------------------------------------------------------
+// gcc_phat_kernel keeps a window pair in one 1024-thread workgroup: a batch of 100 pairs (BASELINE configs[4]) then
+// occupies 100 of the 256 CUs.  For batches that do not fill the chip the work of a pair is dealt to more workgroups —
+// 2 R forward sub-transforms, the cross spectrum in slices, R inverse sub-transforms — at the price of four kernel
+// boundaries; every phase reads what the previous one left in the pair's scratch slab (same layout as above).
+__global__ void __launch_bounds__(kGccThreads) gcc_fwd_kernel(const GccArgs a, unsigned long long* __restrict__ gmax) {
+    using C = cpx<double>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    C* buf = (C*)smem;
+    double* red = (double*)(buf + a.M2);
+    const int tid = threadIdx.x, pair = blockIdx.y;
+    const int s = blockIdx.x / a.R, r = blockIdx.x - s * a.R;
+    const int L = a.L, M = a.M, M2 = a.M2, R = a.R;
+    const double* sig = (s ? a.d1 : a.d0) + (size_t)pair * L;
+    C* S = (C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2);
+    double acc = 0.0;
+    for (int t = tid; t < L; t += kGccThreads) acc += sig[t];
+    const double mean = block_sum(acc, red) / (double)L;
+    if (tid == 0 && r == 0) {
+        if (a.means) a.means[2 * pair + s] = mean;
+        if (s == 0) gmax[pair] = 0ull;
+    }
+    for (int m = tid; m < M2; m += kGccThreads) {
+        const int t = 2 * (R * m + r);
+        buf[m] = {(sig[t] - mean) * a.window[t], (sig[t + 1] - mean) * a.window[t + 1]};
+    }
+    __syncthreads();
+    fft_mixed_forward<double, kGccMaxB>(buf, (const C*)a.tw2, a.plan, tid, kGccThreads);
+    for (int k = tid; k < M2; k += kGccThreads) S[((size_t)s * R + r) * M2 + k] = buf[k];
+}
+
+__global__ void __launch_bounds__(256) gcc_cross_kernel(const GccArgs a, unsigned long long* __restrict__ gmax) {
+    using C = cpx<double>;
+    __shared__ double red[4];
+    const int pair = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    const int M = a.M, M2 = a.M2, R = a.R;
+    const C* S = (const C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2);
+    C* G = (C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2) + 2 * (size_t)M;
+    const C* twm = (const C*)a.twm;
+    const C* twl = (const C*)a.twl;
+    auto zfull = [&](int sg, int kk) -> C {
+        const int kp = kk % M2;
+        C acc = S[((size_t)sg * R) * M2 + kp];
+        for (int r = 1; r < R; ++r) acc = acc + cmul(twm[(int)(((long long)r * kk) % M)], S[((size_t)sg * R + r) * M2 + kp]);
+        return acc;
+    };
+    auto unpack = [&](int sg, int kk) -> C {
+        const C A = zfull(sg, kk == M ? 0 : kk);
+        const C B = cconj(zfull(sg, kk == 0 ? 0 : M - kk));
+        const C Sm = A + B, D = A - B;
+        const C t = cmul(twl[kk], D);
+        return {0.5 * (Sm.x + t.y), 0.5 * (Sm.y - t.x)};
+    };
+    double mag = 0.0;
+    if (k <= M) {
+        const C g = cmul(cconj(unpack(0, k)), unpack(1, k));
+        G[k] = g;
+        mag = sqrt(g.x * g.x + g.y * g.y);
+    }
+    for (int o = 32; o > 0; o >>= 1) mag = fmax(mag, __shfl_down(mag, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mag;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(gmax + pair, (unsigned long long)__double_as_longlong(fmax(fmax(red[0], red[1]), fmax(red[2], red[3]))));
+}
+
+__global__ void __launch_bounds__(256) gcc_pack_kernel(const GccArgs a, const unsigned long long* __restrict__ gmax) {
+    using C = cpx<double>;
+    const int pair = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    const int M = a.M;
+    if (k >= M) return;
+    const C* G = (const C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2) + 2 * (size_t)M;
+    C* Zi = (C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2) + 2 * (size_t)M + (M + 1);
+    const C* twl = (const C*)a.twl;
+    const double gm = __longlong_as_double((long long)gmax[pair]);
+    auto weighted = [&](int kk) -> C {
+        C g = G[kk];
+        const double w = 1.0 / (1e-10 * gm + sqrt(g.x * g.x + g.y * g.y));
+        g = {g.x * w, g.y * w};
+        if (kk == 0 || kk == M) g.y = 0.0;
+        return g;
+    };
+    const C A = weighted(k);
+    const C B = cconj(weighted(M - k));
+    const C Sm = A + B, D = A - B;
+    const C t = cmul(cconj(twl[k]), D);
+    Zi[k] = {0.5 * (Sm.x - t.y), 0.5 * (Sm.y + t.x)};
+}
+
+__global__ void __launch_bounds__(kGccThreads) gcc_inv_kernel(const GccArgs a) {
+    using C = cpx<double>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    C* buf = (C*)smem;
+    const int tid = threadIdx.x, pair = blockIdx.y, r = blockIdx.x;
+    const int L = a.L, M = a.M, M2 = a.M2, R = a.R;
+    const C* Zi = (const C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2) + 2 * (size_t)M + (M + 1);
+    const C* twm = (const C*)a.twm;
+    for (int k = tid; k < M2; k += kGccThreads) {
+        C acc = Zi[k];
+        for (int q = 1; q < R; ++q) {
+            const C wq = cconj(twm[(int)(((long long)((r * q) % R) * M2) % M)]);
+            acc = acc + cmul(wq, Zi[k + q * M2]);
+        }
+        acc = cmul(cconj(twm[(int)(((long long)r * k) % M)]), acc);
+        buf[k] = cconj(acc);
+    }
+    __syncthreads();
+    fft_mixed_forward<double, kGccMaxB>(buf, (const C*)a.tw2, a.plan, tid, kGccThreads);
+    double* out = a.xcorr + (size_t)pair * L;
+    const double inv = 1.0 / (double)M;
+    for (int m = tid; m < M2; m += kGccThreads) {
+        const int t = 2 * (R * m + r);
+        out[t] = buf[m].x * inv;
+        out[t + 1] = -buf[m].y * inv;
+    }
+}
+
+
 // ---- any window length: chirp-z (Bluestein) on a four-step power-of-two transform ----------------------------------
 // The delay-range spin box runs from 0.1 s to 1000 s in steps of 0.1 s (delay_estimator.py:222-226): windows of
 // L = 2400 r samples, r = 1..10000 — most of them neither 5-smooth nor small enough for the one-workgroup kernel above
@@ -639,7 +757,9 @@ extern "C" int frt_gcc_create(frt_gcc** out, int length, int n_pairs) {
         return rc;
     }
     h->lds_bytes = (size_t)h->M2 * 16 + 16 * sizeof(double) + 16 * sizeof(int);
-    if (hipFuncSetAttribute((const void*)gcc_phat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)gcc_phat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gcc_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gcc_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
         set_last_error("frt_gcc_create: cannot reserve %zu bytes of LDS", h->lds_bytes);
         frt_gcc_destroy(h);
         return FRT_ERR_HIP;
@@ -719,7 +839,18 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
     a.M = h->M;
     a.M2 = h->M2;
     a.R = h->R;
-    hipLaunchKernelGGL(gcc_phat_kernel, dim3(h->n_pairs), dim3(kGccThreads), h->lds_bytes, h->stream, a);
+    if ((long long)h->n_pairs * 2 <= device_cu_count() && !getenv("FRT_GCC_ONE_WORKGROUP")) {
+        // a batch that leaves more than half of the CUs idle: the pair's sub-transforms as workgroups of their own
+        if ((rc = h->gmax.reserve((size_t)h->n_pairs * 8))) return rc;
+        unsigned long long* gm = h->gmax.as<unsigned long long>();
+        hipLaunchKernelGGL(gcc_fwd_kernel, dim3(2 * h->R, h->n_pairs), dim3(kGccThreads), h->lds_bytes, h->stream, a, gm);
+        hipLaunchKernelGGL(gcc_cross_kernel, dim3((h->M + 1 + 255) / 256, h->n_pairs), dim3(256), 0, h->stream, a, gm);
+        hipLaunchKernelGGL(gcc_pack_kernel, dim3((h->M + 255) / 256, h->n_pairs), dim3(256), 0, h->stream, a, gm);
+        hipLaunchKernelGGL(gcc_inv_kernel, dim3(h->R, h->n_pairs), dim3(kGccThreads), h->lds_bytes, h->stream, a);
+        hipLaunchKernelGGL(any_argmax_kernel, dim3(h->n_pairs), dim3(kGccThreads), 0, h->stream, a.xcorr, h->L, h->argmax.as<int>());
+    } else {
+        hipLaunchKernelGGL(gcc_phat_kernel, dim3(h->n_pairs), dim3(kGccThreads), h->lds_bytes, h->stream, a);
+    }
     FRT_HIP_CHECK(hipGetLastError());
     }
     if (!dev) FRT_HIP_CHECK(hipMemcpyAsync(xcorr_out, h->out.ptr, bytes, hipMemcpyDeviceToHost, h->stream));

@@ -211,3 +211,18 @@ def test_delay_estimator_stream_equals_host_chain(hip):
             assert abs(a.Xcorr_extremum - b.Xcorr_extremum) <= 1e-12 * max(abs(a.Xcorr_extremum), 1e-30)
             windows += a.delay_ms != 0.
         assert windows > 0 and abs(a.delay_ms - 1e3 * 31 / 12000.0) < 0.1
+
+
+def test_gcc_small_batch_path_equals_one_workgroup_path(hip, monkeypatch):
+    """Batches that would leave most CUs idle run a pair's sub-transforms as workgroups of their own (five launches);
+    the arithmetic is the one-workgroup kernel's: identical bits, for R = 1, 2 and 4."""
+    from friture_amd.signal.correlation import GccPhat
+    for L in (2400, 24000, 49152):
+        rng = np.random.default_rng(L)
+        d0 = 0.25 * rng.standard_normal((3, L))
+        d1 = np.roll(d0, 17, axis=1) + 0.05 * rng.standard_normal((3, L))
+        x_multi, am_multi = GccPhat(L, 3).correlate(d0, d1)
+        monkeypatch.setenv("FRT_GCC_ONE_WORKGROUP", "1")
+        x_one, am_one = GccPhat(L, 3).correlate(d0, d1)
+        monkeypatch.delenv("FRT_GCC_ONE_WORKGROUP")
+        assert np.array_equal(x_multi, x_one) and list(am_multi) == list(am_one) == [17] * 3
