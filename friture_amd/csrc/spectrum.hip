@@ -102,8 +102,16 @@ extern "C" int frt_spectrum_post(const void* psd, int psd_is_f32, int n_frames, 
                     (!ref_smoothed || dev == is_device_pointer(ref_smoothed)),
                 "frt_spectrum_post: buffers must all be host or all be device memory");
     const size_t esz = psd_is_f32 ? 4 : 8;
-    DeviceBuffer b_psd, b_prev, b_w, b_ref, b_sm, b_db, b_k, b_idx;
-    auto release = [&]() { for (DeviceBuffer* b : {&b_psd, &b_prev, &b_w, &b_ref, &b_sm, &b_db, &b_k, &b_idx}) b->release(); };
+    // device scratch of this stateless entry point: grow-only, per calling thread (it used to be allocated and freed on
+    // every call — the spectrum widget calls once per audio chunk)
+    struct Scratch {
+        DeviceBuffer psd, prev, w, ref, sm, db, k, idx;
+        ~Scratch() { for (DeviceBuffer* b : {&psd, &prev, &w, &ref, &sm, &db, &k, &idx}) b->release(); }
+    };
+    static thread_local Scratch scratch;
+    DeviceBuffer &b_psd = scratch.psd, &b_prev = scratch.prev, &b_w = scratch.w, &b_ref = scratch.ref, &b_sm = scratch.sm,
+                 &b_db = scratch.db, &b_k = scratch.k, &b_idx = scratch.idx;
+    auto release = [&]() {};
     const void* d_psd = psd;
     const double *d_prev = previous, *d_w = weight_db, *d_ref = ref_smoothed;
     double *d_sm = smoothed_out, *d_db = db_out;

@@ -104,3 +104,70 @@ class SpectrumAnalyzer:
             None if wp is None else wp.ctypes.data, None if rp is None else rp.ctypes.data, sm.ctypes.data, db.ctypes.data,
             ctypes.byref(peak), ctypes.byref(pitch)))
         return sm, db, peak.value, pitch.value
+
+
+class SpectrumAnalyzerStream(SpectrumAnalyzer):
+    """The same slot with its signals resident in HBM: the ring is a DeviceRingBuffer, the realizable frames go through the
+    float64 STFT in place, and smoothing, dB + weighting, peak and harmonic-product pitch (frt_spectrum_post) read and
+    write device buffers — the smoothed spectra never leave the device; per chunk the new samples go up and the dB
+    spectrum and two indices come down."""
+
+    def __init__(self, *args, **kw):
+        import torch
+        self._torch = torch
+        self._dev = torch.device("cuda", torch.cuda.current_device())
+        super().__init__(*args, **kw)
+        from .ringbuffer import DeviceRingBuffer
+        self.ringbuffer = DeviceRingBuffer()
+
+    def setfftsize(self, fft_size):
+        super().setfftsize(fft_size)
+        torch = self._torch
+        nb = len(self.freq)
+        self._d_disp1 = torch.zeros(nb, dtype=torch.float64, device=self._dev)
+        self._d_disp2 = torch.zeros(nb, dtype=torch.float64, device=self._dev)
+        self._d_next = torch.zeros(nb, dtype=torch.float64, device=self._dev)       # the smoothed spectrum being written
+        self._d_db = torch.empty(nb, dtype=torch.float64, device=self._dev)
+
+    def update_weighting(self):
+        super().update_weighting()
+        self._d_w = self._torch.from_numpy(np.ascontiguousarray(self.w, np.float64)).to(self._dev)
+
+    def handle_new_data(self, floatdata):
+        torch = self._torch
+        self.ringbuffer.push(torch.from_numpy(np.ascontiguousarray(floatdata, np.float64)).to(self._dev), 0.)
+        index = self.ringbuffer.offset
+        available = index - self.old_index
+        if available < 0:
+            available = 0
+            self.old_index = index
+        needed = self.fft_size * (1. - self.overlap)
+        realizable = int(np.floor(available / needed))
+        if realizable <= 0:
+            return None
+        span = self.fft_size + (realizable - 1) * self.hop
+        last = self.old_index + (realizable - 1) * self.hop
+        window = self.ringbuffer.data_indexed(last, span)
+        self.old_index += realizable * self.hop
+        psd1 = self._engine.psd(window[0:1, :])[0]
+        peak, pitch = self._post_dev(psd1, self._d_disp1, self._d_w, None)
+        self._d_disp1, self._d_next = self._d_next, self._d_disp1
+        if self.dual_channels and window.shape[0] > 1:
+            psd2 = self._engine.psd(window[1:2, :].contiguous())[0]
+            peak, _ = self._post_dev(psd2, self._d_disp2, None, self._d_disp1)
+            self._d_disp2, self._d_next = self._d_next, self._d_disp2
+        db = self._d_db.cpu().numpy()
+        self.dB_spectrogram = db
+        self.fmax = self.freq[peak]
+        self.fpitch = max(self.freq[pitch], 1e-20)
+        return self.freq, db, self.fmax, self.fpitch
+
+    def _post_dev(self, psd, disp, weight, ref):
+        nf, nb = psd.shape
+        peak, pitch = ctypes.c_int(0), ctypes.c_int(0)
+        vp = ctypes.c_void_p
+        _lib.check(self._lib.frt_spectrum_post(
+            vp(psd.data_ptr()), 0, nf, nb, nb, self.kernel.ctypes.data, len(self.kernel), float(self.alpha), vp(disp.data_ptr()),
+            None if weight is None else vp(weight.data_ptr()), None if ref is None else vp(ref.data_ptr()), vp(self._d_next.data_ptr()),
+            vp(self._d_db.data_ptr()), ctypes.byref(peak), ctypes.byref(pitch)))
+        return peak.value, pitch.value

@@ -188,3 +188,25 @@ def test_octave_spectrum_stream_equals_host_chain(hip):
             ra, rb = a.handle_new_data(chunk), b.handle_new_data(chunk)
             assert ra[2] == rb[2] and np.array_equal(ra[0], rb[0])
             assert np.max(np.abs(ra[3] - rb[3])) <= 4.4e-5, (bpo, n, float(np.max(np.abs(ra[3] - rb[3]))))
+
+
+@pytest.mark.parametrize("dual", [False, True])
+def test_spectrum_analyzer_stream_equals_host_chain(hip, dual):
+    """SpectrumAnalyzerStream (device ring, smoothed spectra resident in HBM) against SpectrumAnalyzer chunk after chunk:
+    identical dB spectra, peak and pitch, single and dual channel (the dual-channel dB is the ratio to channel 1's
+    smoothed spectrum, spectrum.py:160-175)."""
+    from friture_amd.spectrum import SpectrumAnalyzer, SpectrumAnalyzerStream
+    kw = dict(fft_size=2048, overlap=0.75, weighting=2, response_time=0.05, dual_channels=dual)
+    a, b = SpectrumAnalyzer(**kw), SpectrumAnalyzerStream(**kw)
+    rows = 2 if dual else 1
+    x = np.stack([synth("tone", 30000, 3), synth("noise", 30000, 8)])[:rows].astype(np.float64)
+    pos, got_any = 0, 0
+    for n in [512] * 20 + [100, 3000, 7, 512, 2048] + [512] * 20:
+        chunk = x[:, pos:pos + n]
+        pos += n
+        ra, rb = a.handle_new_data(chunk), b.handle_new_data(chunk)
+        assert (ra is None) == (rb is None)
+        if ra is not None:
+            got_any += 1
+            assert np.array_equal(ra[1], rb[1]) and ra[2] == rb[2] and ra[3] == rb[3]
+    assert got_any > 30

@@ -71,6 +71,31 @@ def main():
 
         time_pushes(oracle_push, chunks[:50])
         res[f"spectrogram_N{n_fft}_numpy_oracle"] = stats(time_pushes(oracle_push, chunks[50:250]))
+    # ---- spectrum widget: N = 8192 (its default), 75 % overlap ------------------------------------------------------------
+    from friture_amd.spectrum import SpectrumAnalyzer, SpectrumAnalyzerStream
+    for name, obj in (("device_resident", SpectrumAnalyzerStream()), ("block_by_block", SpectrumAnalyzer())):
+        time_pushes(obj.handle_new_data, chunks[:50])
+        res[f"spectrum_N8192_{name}"] = stats(time_pushes(obj.handle_new_data, chunks[50:]))
+    sa = SpectrumAnalyzer()
+    ring3, st3 = dsp.MirrorRing(), {"old": 0, "prev": np.zeros(4097)}
+    w8 = dsp.weighting_curves(dsp.frequency_axis(8192))[0]
+    win8, fax8 = dsp.hann_symmetric(8192), dsp.frequency_axis(8192)
+
+    def oracle_spectrum(c):
+        ring3.push(c)
+        realizable = int(np.floor((ring3.offset - st3["old"]) / 2048.0))
+        if realizable <= 0:
+            return None
+        cols = []
+        for _ in range(realizable):
+            cols.append(dsp.psd_frame(ring3.data_indexed(st3["old"], 8192)[0], win8))
+            st3["old"] += 2048
+        r = dsp.spectrum_readout(np.stack(cols, axis=1), sa.kernel, sa.alpha, st3["prev"], w8, fax8)
+        st3["prev"] = r["smoothed"]
+        return r
+
+    time_pushes(oracle_spectrum, chunks[:50])
+    res["spectrum_N8192_numpy_oracle"] = stats(time_pushes(oracle_spectrum, chunks[50:450]))
     # ---- octave spectrum: 1/3 and 1/24 octave -------------------------------------------------------------------
     from friture_amd.octavespectrum import OctaveSpectrum, OctaveSpectrumStream
     xf = [c.astype(np.float32).astype(np.float64) for c in chunks]
