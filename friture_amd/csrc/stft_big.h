@@ -17,6 +17,9 @@
 // Three barriers per frame, 74 KB of LDS for N = 16384 -> two 512-thread workgroups per CU.
 #pragma once
 
+#ifndef FRT_BIG_ZB              // bin pairs whose Z values are requested together in the unpack (2, 4 or 8)
+#define FRT_BIG_ZB 4
+#endif
 #ifndef FRT_BIG_ABLATE          // experiment builds only: 1 no row stores, 2 no sample loads after the first frame, 4 no sub-transforms
 #define FRT_BIG_ABLATE 0
 #endif
@@ -78,25 +81,21 @@ struct BigPlan {
 // T: float (every optimisation below) or double (the transform structure only: no register-resident constants, no
 // prefetch, no staging — the float64 instance serves the drop-in / pitch-tracker path, twice the registers and LDS).
 template <typename T, int LOG2M, bool DMA>
-__global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK, sizeof(T) == 4 ? 2 : 1) stft_big_kernel(const StftArgs a) {
+__device__ __forceinline__ void stft_big_body(const StftArgs& a, cpx<T>* __restrict__ lds, uint32_t* __restrict__ lut_lds,
+                                              cpx<T>* __restrict__ stage, cpx<T>* __restrict__ tws_lds) {
+    // The LDS arrays arrive as __restrict__ parameters of an inlined function: that is what gives every LDS access an
+    // alias scope, and the scopes are what let the compiler's wait-count pass see that the sub-transforms and the unpack
+    // (regions, LUT) do not read what the LDS-DMA of the next frame (stage) writes.  Without them every ds_read behind a
+    // global_load_lds waits for vmcnt(0): the staging of the next frame was awaited right where it was issued.
     using B = BigPlan<LOG2M>;
     using C = cpx<T>;
-    static_assert(!DMA || sizeof(T) == 4, "LDS staging is a float32 feature");
-    constexpr int M = B::M, MS = B::MS, TPFS = B::TPFS, RS = B::RS, BLOCK = B::BLOCK, GPB = B::GPB;
-    static_assert(!DMA || GPB == 1, "the staged variant serves one frame per workgroup");
-
-    __shared__ C lds[GPB * 16 * RS];
-    __shared__ uint32_t lut_lds[256];
-    __shared__ __attribute__((aligned(16))) C stage[DMA ? M : 1];
-    // float64 re-reads its sub-transform twiddles at every use (no registers to hold them): from a copy of the table
-    // in LDS — a global load there is an exposed L2 round trip per pass, and it queues behind the row stores
+    constexpr int M = B::M, MS = B::MS, TPFS = B::TPFS, RS = B::RS, BLOCK = B::BLOCK;
+    static_assert(B::GPB == 1 && BLOCK == MS, "one frame per workgroup");
     constexpr bool TWLDS = sizeof(T) == 8;
-    __shared__ __attribute__((aligned(16))) C tws_lds[TWLDS ? MS : 1];
 
     const int tid = threadIdx.x;
-    const int grp = tid / MS;
-    const int t = tid - grp * MS;
-    C* reg = lds + grp * 16 * RS;
+    const int t = tid;
+    C* reg = lds;
 
     if (a.kind == FRT_STFT_IMAGE) {
         for (int q = tid; q < 256; q += BLOCK) lut_lds[q] = a.lut[q];
@@ -105,15 +104,13 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK, sizeof(T) == 4 ? 2 : 1)
         for (int q = tid; q < MS; q += BLOCK) tws_lds[q] = ((const C*)a.tws)[q];      // visible after the loop's first barrier
     }
 
-    const int gg = blockIdx.x * GPB + grp;
-    const bool group_ok = gg < a.n_groups;
-    const int ggc = group_ok ? gg : 0;
-    const int chan = ggc / a.runs_per_channel;
-    const int run = ggc - chan * a.runs_per_channel;
+    // everything that places the workgroup is uniform: scalar registers, scalar-base addressing for loads and stores
+    const int gg = blockIdx.x;
+    const int chan = gg / a.runs_per_channel;
+    const int run = gg - chan * a.runs_per_channel;
     const long long f0 = a.frame_base + (long long)run * a.run;
-    long long nfr = a.n_frames - f0;
-    if (nfr > a.run) nfr = a.run;
-    if (!group_ok) nfr = 0;
+    int nfr = (int)(a.n_frames - f0 < (long long)a.run ? a.n_frames - f0 : (long long)a.run);
+    if (gg >= a.n_groups || nfr < 0) nfr = 0;
 
     const C* xs = (const C*)((const T*)a.x + chan * a.x_stride);
     const C* win = (const C*)a.window;
@@ -157,38 +154,58 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK, sizeof(T) == 4 ? 2 : 1)
         }
     }
 
+    // z[t + j Ms] of a frame: scalar base (the frame's first sample + j Ms, all uniform) + ONE lane offset, 8 t bytes —
+    // spelled out, because the compiler's own split kept several 64-bit per-lane pointers alive across the frame loop
+    // (`opaque0`: a zero the compiler cannot see through, defined inside the frame loop — it keeps "row start + 8 t" from
+    // being hoisted out of the loop as a 64-bit per-lane pointer again)
+    const uint32_t t_bytes = (uint32_t)t * (uint32_t)sizeof(C);
+    auto sample = [&](long long frame, int j, int opaque0 = 0) -> C {
+        const unsigned long long ub = (unsigned long long)(xs + (frame * a.hop >> 1) + j * MS);
+        // (readfirstlane of a uniform value is free, and pins the base to scalar registers: scalar-base addressing)
+        const unsigned long long sb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ub >> 32)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ub);
+        return *(const C*)((const char*)sb + (t_bytes + (uint32_t)opaque0));
+    };
     // N <= 4096: the 16 samples of the NEXT frame are requested as soon as the current frame's first stage has left
     // its registers (32 more live registers: +15 % at 2048 / 4096; at 8192 the kernel would drop to one wave per SIMD
     // or lose the hoisted weights, at 16384 it spills — measured slower or equal there)
     constexpr bool PREFETCH = HOIST1 && LOG2M <= 11;
     C nx[PREFETCH ? 16 : 1];                     // the samples of the frame about to be transformed
     if constexpr (PREFETCH) {
-        const C* x0 = xs + (f0 * a.hop >> 1) + t;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) nx[j] = nfr > 0 ? x0[j * MS] : C{(T)0, (T)0};
+        for (int j = 0; j < 16; ++j) nx[j] = nfr > 0 ? sample(f0, j) : C{(T)0, (T)0};
 #pragma unroll
         for (int j = 0; j < 16; ++j) nx[j] = C{nx[j].x * winr[j].x, nx[j].y * winr[j].y};      // nx holds WINDOWED samples
     }
-    // one frame = M complex = 8 M bytes = M / 128 wave-instructions of 1 KB, dealt round-robin to the wavefronts
+    // one frame = M complex = 8 M bytes = M / 128 wave-instructions of 1 KB, dealt round-robin to the wavefronts.
+    // Issued from inline assembly (scalar row base + lane offset, LDS address in M0): an LDS-DMA the compiler knows of
+    // makes its wait-count pass guard LDS accesses behind it with vmcnt(0) wherever it cannot prove them disjoint from
+    // the staging buffer — it did so at the first LDS access of the sub-transforms, i.e. the copy of the next frame was
+    // awaited right where it had been issued and overlapped with nothing.  The waits are placed by hand instead: the
+    // vmcnt(16) at the top of the frame loop (vector-memory operations retire in order, and the only ones younger than
+    // the copy are the frame's row stores).
+    const uint32_t stage_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)stage;
     auto stage_frame = [&](long long frame) {
-        const char* src = (const char*)(xs + (frame * a.hop >> 1));
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const char* src = (const char*)(xs + (frame * a.hop >> 1)) + wave * 1024;
+        const uint32_t dst = stage_lds + wave * 1024;
+        const uint32_t lane16 = (tid & 63) * 16;
 #pragma unroll
         for (int j = 0; j < M / 128 / (BLOCK / 64); ++j) {
-            const int chunk = j * (BLOCK / 64) + wave;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + chunk * 1024 + lane * 16),
-                                             (void __attribute__((address_space(3)))*)((char*)stage + chunk * 1024), 16, 0, 0);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :
+                         : "v"(lane16), "s"(src + j * (BLOCK / 64) * 1024), "s"(dst + j * (BLOCK / 64) * 1024)
+                         : "memory", "m0");
         }
     };
     if constexpr (DMA) {
         if (nfr > 0) stage_frame(f0);
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): nothing younger is in flight yet that the loop's vmcnt(16) could count on
     }
-    for (int g = 0; g < a.run; ++g) {
-        const bool valid = g < nfr;
+    for (int g = 0; g < nfr; ++g) {                           // nfr is uniform over the workgroup
         // the staged frame has landed once at most the 16 row stores of the previous frame are still outstanding
         if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x4F70);           // vmcnt(16), other counters untouched
-        if (!__syncthreads_or(valid)) break;                 // also fences the previous frame's LDS reads
+        __syncthreads();                                      // fences the previous frame's LDS reads
         int zero = 0;
         asm volatile("s_mov_b32 %0, 0" : "=s"(zero));        // keeps table loads inside the loop
 
@@ -210,7 +227,7 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK, sizeof(T) == 4 ? 2 : 1)
             for (int m = 0; m < 4; ++m) {
                 C d[4];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) d[p] = valid ? stage[t + (m + 4 * p) * MS] : C{(T)0, (T)0};
+                for (int p = 0; p < 4; ++p) d[p] = stage[t + (m + 4 * p) * MS];
                 C b0 = {d[0].x * winr[m].x, d[0].y * winr[m].y};
                 C b1 = {d[1].x * winr[m + 4].x, d[1].y * winr[m + 4].y};
                 C b2 = {d[2].x * winr[m + 8].x, d[2].y * winr[m + 8].y};
@@ -219,12 +236,11 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK, sizeof(T) == 4 ? 2 : 1)
                 v[m] = b0; v[m + 4] = b1; v[m + 8] = b2; v[m + 12] = b3;
             }
         } else {
-            const C* xf = xs + ((f0 + (valid ? g : 0)) * a.hop >> 1) + t;
             const C* wf = win + t + zero;
             C d[4], w[4], dn[4], wn[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                d[p] = valid ? xf[(4 * p) * MS] : C{(T)0, (T)0};
+                d[p] = sample(f0 + g, 4 * p, zero);
                 if constexpr (HOIST1) w[p] = winr[4 * p];
                 else w[p] = wf[(4 * p) * MS];
             }
@@ -233,7 +249,7 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK, sizeof(T) == 4 ? 2 : 1)
                 if (m < 3) {
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
-                        dn[p] = valid ? xf[(m + 1 + 4 * p) * MS] : C{(T)0, (T)0};
+                        dn[p] = sample(f0 + g, m + 1 + 4 * p, zero);
                         if constexpr (HOIST1) wn[p] = winr[m + 1 + 4 * p];
                         else wn[p] = wf[(m + 1 + 4 * p) * MS];
                     }
@@ -262,9 +278,8 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK, sizeof(T) == 4 ? 2 : 1)
             if ((FRT_BIG_ABLATE & 2) && a.n_frames > 0) {
                 // keep the first frame's samples
             } else if (g + 1 < nfr) {
-                const C* xn = xs + ((f0 + g + 1) * a.hop >> 1) + t;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) nx[j] = xn[j * MS];
+                for (int j = 0; j < 16; ++j) nx[j] = sample(f0 + g + 1, j, zero);
             } else {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) nx[j] = C{(T)0, (T)0};
@@ -298,6 +313,24 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK, sizeof(T) == 4 ? 2 : 1)
             k &= M - 1;
             return reg[(k & 15) * RS + lds_pad(k >> 4)];
         };
+        // The Z values of ZB of the thread's eight pairs are requested before the first is used (the registers of the
+        // first stage are free here): 8 / ZB exposed LDS round trips per frame instead of eight — with two waves per
+        // SIMD there is little else to cover them.  (All eight at once spill where the prefetched samples are live too.)
+        constexpr int ZB = (PREFETCH && LOG2M == 11) ? 2 : FRT_BIG_ZB;      // N = 4096 has no registers left
+        C za[8], zb[8];
+        auto request_z = [&](int q0) {
+#pragma unroll
+            for (int q = q0; q < q0 + ZB; ++q) {
+                za[q] = zat(t + q * MS);
+                zb[q] = zat(M - t - q * MS);
+            }
+        };
+        request_z(0);
+        // (without the scheduling barrier the batches are merged again, and the kernel spills)
+        auto next_z = [&](int q0) {
+            __builtin_amdgcn_sched_barrier(0);
+            request_z(q0);
+        };
         if constexpr (PREFETCH) {
             // The next frame's samples are windowed HERE, before this frame's row stores are issued.  The vector-memory
             // counter retires in order: a first use after the stores (the top of the next iteration) can only be
@@ -311,15 +344,20 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK, sizeof(T) == 4 ? 2 : 1)
                 asm volatile("" : "+v"(nx[j2].x), "+v"(nx[j2].y));      // the products exist here: not sunk to their use
             }
         }
-        if (valid) {
+        {
             T* row = (T*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
             // colour words are 4 bytes whatever the arithmetic type
             uint32_t* prow = (uint32_t*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
-            auto finish_store = [&](int k, T p, T w) {
-                if ((FRT_BIG_ABLATE & 1) && p != (T)-1) return;      // never true for a power: the arithmetic stays
-                if (a.kind == FRT_STFT_PSD) {
-                    row[k] = p;
-                } else if (a.kind == FRT_STFT_IMAGE) {
+            constexpr bool NOSTORE = (FRT_BIG_ABLATE & 1) != 0;
+            // Row stores: scalar base (row + the pair's offset) + one of two lane offsets, 4 tz for the bins t + q Ms and
+            // 4 (Ms - tz) for the bins M - t - q Ms.  tz = t + an opaque 0: otherwise the sixteen lane offsets are
+            // hoisted out of the frame loop into sixteen registers the kernel does not have.
+            const uint32_t tz = (uint32_t)(t + zero), tzh = (uint32_t)(MS - t - zero);
+            auto lo_at = [&](auto* base, int q) { return base + q * MS + tz; };                    // bin t + q Ms
+            auto hi_at = [&](auto* base, int q) { return base + (M - MS - q * MS) + tzh; };        // bin M - t - q Ms
+            auto finish_store = [&](T* dst, int k, T p, T w) {           // the dB kinds (and the float64 colour index)
+                if (NOSTORE && p != (T)-1) return;                // never true for a power: the arithmetic stays
+                if (a.kind == FRT_STFT_IMAGE) {
                     const T vv = clamp_index(image_gain * log2_t(p + (T)1e-30) + w);
                     int idx = (int)vv;
                     if constexpr (sizeof(T) == 4) {
@@ -327,33 +365,26 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK, sizeof(T) == 4 ? 2 : 1)
                         const bool near_edge = __builtin_amdgcn_fractf(vv) < a.edge2;
                         if (__any(near_edge)) idx = exact_colour_index(near_edge, p, k, idx, a);
                     }
-                    prow[k] = lut_lds[idx];
+                    *(uint32_t*)dst = lut_lds[idx];
                 } else {
                     T vv = db10<T>(p) + w;
                     if (a.kind == FRT_STFT_NORM) vv = (vv + norm_off) * norm_scale;
-                    row[k] = vv;
+                    *dst = vv;
                 }
             };
             auto weight_at = [&](int k) -> T { return wgt ? wgt[k + zero] : (T)0; };
             auto pair_powers = [&](int q, C wk, T& plo, T& phi) {
-                const int k = t + q * MS;                    // k < M/2
-                const C A = zat(k), Bc = cconj(zat(M - k));
+                const C A = za[q], Bc = cconj(zb[q]);
                 const C S = A + Bc, D = A - Bc;
                 const C tt = cmul(wk, D);
                 const T ar = S.x + tt.y, ai = S.y - tt.x, br = S.x - tt.y, bi = S.y + tt.x;
                 plo = ar * ar + ai * ai;
                 phi = br * br + bi * bi;
             };
-            auto pair = [&](int q, C wk, T wlo, T whi) {
-                T plo, phi;
-                pair_powers(q, wk, plo, phi);
-                finish_store(t + q * MS, plo, wlo);
-                finish_store(M - t - q * MS, phi, whi);
-            };
             // IMAGE kind, float32: four bins at a time — index values, LUT reads (issued with the float32 index), ONE
             // near-edge test for the four, stores.  A test per bin put a branch, and behind it an exposed LUT read,
             // between every two of the thread's 17 stores (+8 % on the kernel).
-            auto image4 = [&](const int (&k)[4], const T (&pw)[4], const T (&w)[4]) {
+            auto image4 = [&](int q, const int (&k)[4], const T (&pw)[4], const T (&w)[4]) {
                 T vv[4];
                 uint32_t c[4];
 #pragma unroll
@@ -373,56 +404,92 @@ __global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK, sizeof(T) == 4 ? 2 : 1)
                         }
                     }
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) prow[k[e]] = c[e];
+                *lo_at(prow, q) = c[0];
+                *hi_at(prow, q) = c[1];
+                *lo_at(prow, q + 1) = c[2];
+                *hi_at(prow, q + 1) = c[3];
             };
-            if constexpr (HOIST1) {
-                if (sizeof(T) == 4 && HOISTW && a.kind == FRT_STFT_IMAGE && !(FRT_BIG_ABLATE & 1)) {
+            // unpack factors and weights: registers (float32), or requested here — ALL of them before the first row
+            // store: a table load issued between the stores of two bin pairs is only complete, for the in-order
+            // vector-memory counter, once those stores are acknowledged (float64)
+            C twl[8];
+            T wl[16];
 #pragma unroll
-                    for (int q = 0; q < 8; q += 2) {
-                        T pw[4];
-                        pair_powers(q, twur[q], pw[0], pw[1]);
-                        pair_powers(q + 1, twur[q + 1], pw[2], pw[3]);
-                        const int k[4] = {t + q * MS, M - t - q * MS, t + (q + 1) * MS, M - t - (q + 1) * MS};
-                        const T w[4] = {wgr[q], wgr[8 + q], wgr[q + 1], wgr[8 + q + 1]};
-                        image4(k, pw, w);
-                    }
-                } else {
+            for (int q = 0; q < 8; ++q) {
+                if constexpr (HOIST1) twl[q] = twur[q];
+                else twl[q] = twn[t + q * MS + zero];
+            }
+            if (a.kind != FRT_STFT_PSD) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        if constexpr (HOISTW) pair(q, twur[q], wgr[q], wgr[8 + q]);
-                        else pair(q, twur[q], a.kind == FRT_STFT_PSD ? (T)0 : weight_at(t + q * MS),
-                                  a.kind == FRT_STFT_PSD ? (T)0 : weight_at(M - t - q * MS));
+                for (int q = 0; q < 8; ++q) {
+                    if constexpr (HOISTW) {
+                        wl[q] = wgr[q];
+                        wl[8 + q] = wgr[8 + q];
+                    } else {
+                        wl[q] = weight_at(t + q * MS);
+                        wl[8 + q] = weight_at(M - t - q * MS);
                     }
+                }
+            }
+            // the output kind is uniform: one branch per frame, not one per bin
+            if (a.kind == FRT_STFT_PSD) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    T plo, phi;
+                    if (q > 0 && q % ZB == 0) next_z(q);
+                    pair_powers(q, twl[q], plo, phi);
+                    if (!NOSTORE || plo == (T)-1) {
+                        *lo_at(row, q) = plo;
+                        *hi_at(row, q) = phi;
+                    }
+                }
+            } else if (sizeof(T) == 4 && a.kind == FRT_STFT_IMAGE && !NOSTORE) {
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    T pw[4];
+                    if (q > 0 && q % ZB == 0) next_z(q);
+                    pair_powers(q, twl[q], pw[0], pw[1]);
+                    pair_powers(q + 1, twl[q + 1], pw[2], pw[3]);
+                    const int k[4] = {t + q * MS, M - t - q * MS, t + (q + 1) * MS, M - t - (q + 1) * MS};
+                    const T w[4] = {wl[q], wl[8 + q], wl[q + 1], wl[8 + q + 1]};
+                    image4(q, k, pw, w);
                 }
             } else {
-                // float64: the eight unpack factors (and the weights of the dB kinds) are ALL requested before the
-                // first row store — a table load issued between the stores of two bin pairs is only complete, for
-                // the in-order vector-memory counter, once those stores are acknowledged
-                C twl[8];
-                T wl[16];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) twl[q] = twn[t + q * MS + zero];
-                if (a.kind != FRT_STFT_PSD && wgt) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        wl[q] = wgt[t + q * MS + zero];
-                        wl[8 + q] = wgt[M - t - q * MS + zero];
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) wl[q] = (T)0;
+                for (int q = 0; q < 8; ++q) {
+                    T plo, phi;
+                    if (q > 0 && q % ZB == 0) next_z(q);
+                    pair_powers(q, twl[q], plo, phi);
+                    finish_store(lo_at(row, q), t + q * MS, plo, wl[q]);
+                    finish_store(hi_at(row, q), M - t - q * MS, phi, wl[8 + q]);
                 }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) pair(q, twl[q], wl[q], wl[8 + q]);
             }
             if (t == 0) {
                 const C zm = zat(M / 2);
-                const T wn = wg_nyq;                           // (a load here, after the row stores, would put vmcnt(0) at the loop top)
-                finish_store(M / 2, (zm.x * zm.x + zm.y * zm.y) * (T)4, wn);
+                const T pm = (zm.x * zm.x + zm.y * zm.y) * (T)4;
+                // (a weight load here, after the row stores, would put vmcnt(0) at the loop top: wg_nyq is a register)
+                if (a.kind == FRT_STFT_PSD) {
+                    if (!NOSTORE) row[M / 2] = pm;
+                } else {
+                    finish_store(row + M / 2, M / 2, pm, wg_nyq);
+                }
             }
         }
     }
+}
+
+template <typename T, int LOG2M, bool DMA>
+__global__ void __launch_bounds__(BigPlan<LOG2M>::BLOCK, sizeof(T) == 4 ? 2 : 1) stft_big_kernel(const StftArgs a) {
+    using B = BigPlan<LOG2M>;
+    using C = cpx<T>;
+    static_assert(!DMA || sizeof(T) == 4, "LDS staging is a float32 feature");
+    __shared__ C lds[16 * B::RS];
+    __shared__ uint32_t lut_lds[256];
+    __shared__ __attribute__((aligned(16))) C stage[DMA ? B::M : 1];
+    // float64 re-reads its sub-transform twiddles at every use (no registers to hold them): from a copy of the table
+    // in LDS — a global load there is an exposed L2 round trip per pass, and it queues behind the row stores
+    __shared__ __attribute__((aligned(16))) C tws_lds[sizeof(T) == 8 ? B::MS : 1];
+    stft_big_body<T, LOG2M, DMA>(a, lds, lut_lds, stage, tws_lds);
 }
 
 }  // namespace frt

@@ -1,0 +1,7 @@
+#!/bin/bash
+# large-frame restructure: correctness first, then A/B against the previous build
+timeout 900 python -m pytest tests/test_stft_gpu.py -x -q -m gpu 2>&1 | tail -3
+timeout 300 python -m pytest tests/test_pitch_gpu.py -x -q -m gpu 2>&1 | tail -2
+for rep in 1 2; do
+bash tools/exp/ab_variants.sh "prev base" "16384 8192 32 20 0 0 40" "16384 8192 32 20 3 0 40" "8192 4096 32 21 0 0 40" "8192 4096 32 21 3 0 40" "4096 2048 16 22 0 0 40" "4096 1024 16 22 3 0 40" "2048 1024 8 24 0 0 40" "2048 512 8 24 3 0 40"
+done
