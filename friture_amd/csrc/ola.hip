@@ -283,22 +283,87 @@ struct OlaBatchArgs {
     int band_index[kMaxFilters];
     const double* ewt;         // smoothing weights alpha (1 - alpha)^(elen - 1 - i), per band at ewt_off
     long long ewt_off[kMaxFilters];
+    double ewr[kMaxFilters];   // (1 - alpha)^w of the band, w = lanes per energy block (see the kernel)
 };
 
-__global__ void __launch_bounds__(kObThreads) ola_batch_kernel(const OlaBatchArgs a) {
+#ifndef FRT_OB_ABLATE           // experiment builds only (wrong results): 1 twiddle gathers -> one address, 2 H loads -> one address,
+#define FRT_OB_ABLATE 0         // 4 no band outputs / energies / tails, 8 no workgroup barriers inside the transforms
+#endif
+struct ObTwOneAddress {         // FRT_OB_ABLATE & 1
+    const cpx<double>* tw;
+    __device__ __forceinline__ cpx<double> get(int n, int /*idx*/) const { return tw[n]; }
+};
+// fft_pow2_forward asks for its factors in order: pass 1 q = 1..7, pass 2 q = 1..7, radix-4 pass c = 0: q = 1..3, c = 1: q = 1..3
+struct ObTwPowers {
+    cpx<double> w1[4];
+    mutable cpx<double> cur;
+    __device__ __forceinline__ void load(const cpx<double>* tw, int i) {
+        w1[0] = tw[((i & 7) * (kObM / 64)) & (kObM - 1)];
+        w1[1] = tw[((i & 63) * (kObM / 512)) & (kObM - 1)];
+        w1[2] = tw[i & 511];
+        w1[3] = tw[(i + kObThreads) & 511];
+    }
+    __device__ __forceinline__ cpx<double> get(int n, int /*idx*/) const {
+        const int row = n < 7 ? 0 : n < 14 ? 1 : n < 17 ? 2 : 3;
+        const int q = n < 7 ? n : n < 14 ? n - 7 : n < 17 ? n - 14 : n - 17;      // 0 = first power
+        cur = q == 0 ? w1[row] : cmul(cur, w1[row]);
+        return cur;
+    }
+};
+// Sum over the w = 2^n <= 64 lanes of a group, every lane of the group receiving it: the first four steps (partners inside a row
+// of 16 lanes) are DPP moves — quad permutes, then the half-row and row mirrors, which pair a lane with one that already
+// holds the other half's sum — and only the steps across rows go through ds_bpermute.  (Six bpermute round trips per block
+// and band were a visible part of the bank's time.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double group_sum(double acc, int w) {
+    if (w >= 2) acc += dpp_f64<0xB1>(acc);         // quad_perm [1,0,3,2]
+    if (w >= 4) acc += dpp_f64<0x4E>(acc);         // quad_perm [2,3,0,1]
+    if (w >= 8) acc += dpp_f64<0x141>(acc);        // row_half_mirror
+    if (w >= 16) acc += dpp_f64<0x140>(acc);       // row_mirror
+    if (w >= 32) acc += __shfl_xor(acc, 16, 64);
+    if (w >= 64) acc += __shfl_xor(acc, 32, 64);
+    return acc;
+}
+#ifndef FRT_OB_EABL     // experiment builds (wrong energies): 1 no stores, 2 no lane reduction, 4 no LDS reads, 8 no weight recurrence
+#define FRT_OB_EABL 0
+#endif
+#ifndef FRT_OB_MIN_WAVES        // waves per SIMD the register budget is capped for (2: 256 VGPRs; occupancy is not what binds this kernel)
+#define FRT_OB_MIN_WAVES 2
+#endif
+__global__ void __launch_bounds__(kObThreads, FRT_OB_MIN_WAVES) ola_batch_kernel(const OlaBatchArgs a) {
     using C = cpx<double>;
     constexpr int M = kObM, F = kObF, LOG2M = 11;
     using P = Pow2Plan<LOG2M>;
     static_assert(P::M == M && P::TPF == kObThreads, "one thread per eight points of the 2048-point complex transform");
-    __shared__ C buf[lds_padded_size(M)];         // exchange buffer of the radix-8 passes; afterwards Z, then the finished window
-    __shared__ C spec[M + 1];                     // X[0..M]
+    // ONE LDS array: exchange buffer of the radix-8 passes, hand-over of Z / of the packed products between threads, and
+    // the finished window.  The spectrum X of the window lives in registers — thread tid keeps the four bin pairs
+    // (k, M - k), k = tid + 256 j (thread 0 also bin M/2) — so that a workgroup needs 37 KB of LDS instead of 70 and
+    // three fit a CU; a pair also shares its sum / difference / twiddle product between the two bins, in both directions.
+    __shared__ C buf[lds_padded_size(M)];         // >= M + 1 elements
+    __shared__ C xmid_lds;                        // X[M/2] (self-paired; thread 0 packs it)
     const int tid = threadIdx.x;
     const int blk = blockIdx.x, grp = blockIdx.y, c = blockIdx.z;
     const long long o0 = (long long)blk * kObL;                  // first output sample of this workgroup
     const int Lb = (int)((a.n - o0) < kObL ? (a.n - o0) : kObL); // its outputs
     const bool first = blk == 0, last = o0 + Lb == a.n;
     const C* twl = (const C*)a.twl;
-    const TwTable<double, LOG2M> twt{(const C*)a.tw, 0};
+#if FRT_OB_ABLATE & 1
+    const ObTwOneAddress twt{(const C*)a.tw};
+#else
+    // The transform's twiddle factors: per pass the thread keeps ONE factor in registers (exp(-2 pi i k step / M) of its
+    // k: four complex numbers for the three twiddled passes, the radix-4 pass has two butterflies) and raises it to the
+    // powers q = 2..7 (2, 3) as the pass consumes them.  Re-read from the table at every use the 20 factors were gathers
+    // with a stride of q k step entries (up to 64 cache lines per wave-instruction), each pass waiting for its own L2
+    // round trip: 30 % of the whole bank's time; all 20 in registers (80 VGPRs) spill.
+    ObTwPowers twt;
+    twt.load((const C*)a.tw, tid);
+#endif
 
     // window position p <-> stage sample o0 - 511 + p; z[q] = w[2q] + i w[2q+1]; thread tid holds q = tid + 256 j
     C v[8];
@@ -316,19 +381,29 @@ __global__ void __launch_bounds__(kObThreads) ola_batch_kernel(const OlaBatchArg
             v[j] = {sample(s0 + 2 * q), sample(s0 + 2 * q + 1)};
         }
     }
-    fft_pow2_forward<double, LOG2M, false>(v, buf, tid, twt);    // v[j] = Z[tid + 256 j]
+    fft_pow2_forward<double, LOG2M, (FRT_OB_ABLATE & 8) != 0>(v, buf, tid, twt);    // v[j] = Z[tid + 256 j]
     __syncthreads();                                             // the last pass's gathers are done: buf is free
 #pragma unroll
     for (int j = 0; j < 8; ++j) buf[tid + j * kObThreads] = v[j];
     __syncthreads();
-    for (int k = tid; k <= M; k += kObThreads) {                 // X[k], k = 0..M
-        const C A = buf[k == M ? 0 : k];
-        const C B = cconj(buf[k == 0 ? 0 : M - k]);
+    // X[k] = (S - i t) / 2 and X[M - k] = (conj S - i conj t) / 2 with S = Z[k] + conj Z[M-k], t = w^k (Z[k] - conj Z[M-k]),
+    // w = exp(-2 pi i / F); k = 0 pairs X[0] with the Nyquist bin X[M]
+    C xa[4], xb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = tid + j * kObThreads;                      // 0 .. M/2 - 1
+        const C A = buf[k];
+        const C B = cconj(buf[(M - k) & (M - 1)]);
         const C S = A + B, D = A - B;
         const C t = cmul(twl[k], D);
-        spec[k] = {0.5 * (S.x + t.y), 0.5 * (S.y - t.x)};
+        xa[j] = {0.5 * (S.x + t.y), 0.5 * (S.y - t.x)};
+        xb[j] = {0.5 * (S.x - t.y), -0.5 * (S.y + t.x)};
     }
-    __syncthreads();
+    if (tid == 0) {
+        const C A = buf[M / 2];                                  // self-paired: B = conj A, w^(M/2) = -i
+        xmid_lds = {A.x, -A.y};                                    // (S - i (-i)(D)) / 2 with S = (2 A.x, 0), D = (0, 2 A.y)
+    }
+    __syncthreads();                                             // buf is free again
 
     double* out = (double*)buf;                                  // the finished window, plain doubles, after each inverse
     const double inv = 1.0 / (double)M;
@@ -336,19 +411,42 @@ __global__ void __launch_bounds__(kObThreads) ola_batch_kernel(const OlaBatchArg
         const int f = grp * a.gsize + fi;
         if (f >= a.nfilt) break;
         const C* H = (const C*)a.H + (size_t)f * (M + 1);
-        // Y = X H packed for the inverse: Z[k] = ((A + B) + i conj(w^k) (A - B)) / 2 with A = Y[k], B = conj Y[M-k], conjugated
+        // Block energies (below) weight sample i of a block of m by alpha (1 - alpha)^(m-1-i); lane li of a block's group of w
+        // lanes takes the samples li + u w.  It reads ONE weight from the table — that of its last sample, requested here, a
+        // whole transform ahead of its use — and steps down from it with (1 - alpha)^w (from the largest weight down, so
+        // that an underflow happens where the table's own entries underflow).
+        const bool band_energy = a.eblock && f != a.dec_filter && !(FRT_OB_ABLATE & 4);
+        const int em = a.elen, ew = (em < 64 && (em & (em - 1)) == 0) ? em : 64;
+        int e_opaque0 = 0;                               // keeps the term offsets from being hoisted out of the filter loop
+        asm volatile("s_mov_b32 %0, 0" : "=s"(e_opaque0));
+        const int e_lw = 31 - __builtin_clz(ew);         // ew is a power of two: shifts, not divisions
+        const int e_lane = (tid & 63) + e_opaque0, e_sub = e_lane >> e_lw, e_li = e_lane - (e_sub << e_lw);
+        const double* ewt_f = a.ewt + a.ewt_off[f];
+        double w_last0 = 0.0;
+        if (band_energy && e_li < em) w_last0 = ewt_f[e_li + ((((em - 1 - e_li) >> e_lw) < 15 ? ((em - 1 - e_li) >> e_lw) : 15) << e_lw)];
+        // Y = X H packed for the inverse: with A = Y[k], B = conj Y[M-k], S = A + B, t = conj(w^k) (A - B) the inputs are
+        // conj((S + i t) / 2) at k and conj((conj S + i conj t) / 2) at M - k; they go to their owners through LDS
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
             const int k = tid + j * kObThreads;
-            C A = cmul(spec[k], H[k]);
-            C Bm = cmul(spec[M - k], H[M - k]);
+            C A = cmul(xa[j], H[(FRT_OB_ABLATE & 2) ? j : k]);
+            C Bm = cmul(xb[j], H[(FRT_OB_ABLATE & 2) ? j + 4 : M - k]);
             if (k == 0) { A.y = 0.0; Bm.y = 0.0; }              // irfft ignores the imaginary part of the edge bins
             const C B = cconj(Bm);
             const C S = A + B, D = A - B;
             const C t = cmul(cconj(twl[k]), D);
-            v[j] = {0.5 * (S.x - t.y), -0.5 * (S.y + t.x)};
+            buf[k] = {0.5 * (S.x - t.y), -0.5 * (S.y + t.x)};
+            if (k != 0) buf[M - k] = {0.5 * (S.x + t.y), 0.5 * (S.y - t.x)};
         }
-        fft_pow2_forward<double, LOG2M, false>(v, buf, tid, twt);               // conj(FFT(conj Z)) = M ifft(Z)
+        if (tid == 0) {
+            const C A = cmul(xmid_lds, H[M / 2]);                    // k = M/2: B = conj A, conj(w^k) = i: t = i (0, 2 A.y)
+            buf[M / 2] = {A.x, A.y};                             // conj((S + i t)/2) = conj((A.x, -A.y)) ... = (A.x, A.y)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = buf[tid + j * kObThreads];
+        __syncthreads();                                         // gathered: the first pass may scatter into buf
+        fft_pow2_forward<double, LOG2M, (FRT_OB_ABLATE & 8) != 0>(v, buf, tid, twt);               // conj(FFT(conj Z)) = M ifft(Z)
         __syncthreads();
         const double* pin = a.pend_in + ((size_t)c * a.nfilt + f) * kTail;
         // finish the window: scale / sign, carried tails on the first 511 outputs of the batch; plain doubles in LDS
@@ -371,7 +469,7 @@ __global__ void __launch_bounds__(kObThreads) ola_batch_kernel(const OlaBatchArg
                 double* xn = a.xnext + (long long)c * a.xnext_stride + o0 / 2;      // o0 is even
                 for (int m = tid; 2 * m < Lb; m += kObThreads) xn[m] = res[2 * m];
             }
-        } else {
+        } else if (!(FRT_OB_ABLATE & 4)) {
             if (a.y) {
                 double* y = a.y + (long long)c * a.y_cstride + a.y_off[f] + o0;
                 for (int t = tid; t < Lb; t += kObThreads) y[t] = res[t];
@@ -380,21 +478,42 @@ __global__ void __launch_bounds__(kObThreads) ola_batch_kernel(const OlaBatchArg
                 // zero-state block energies alpha sum_i (1-alpha)^(m-1-i) y_i^2 (exp_smoothing.py:40-56): groups of
                 // w = min(m, 64) lanes per energy block, fixed summation order
                 // (a power of two below 64: that many lanes per block and several blocks per wave; anything else: a whole wave)
-                const int m = a.elen, w = (m < 64 && (m & (m - 1)) == 0) ? m : 64, per_wave = 64 / w;
-                const int lane = tid & 63, wave = tid >> 6, sub = lane / w, li = lane - sub * w;
-                const double* wt = a.ewt + a.ewt_off[f];
+                const int m = em, w = ew, per_wave = 64 / w;
+                const int wave = tid >> 6, sub = e_sub, li = e_li;
+                const double rinv = a.ewr[f];
                 const int ne = Lb / m;
                 double* eo = a.eblock + ((size_t)c * a.nblocks + (size_t)(o0 / m)) * a.nbands + a.band_index[f];
-                for (int e0 = wave * per_wave; e0 < ne; e0 += (kObThreads / 64) * per_wave) {
-                    const int le = e0 + sub;
-                    double acc = 0.0;
-                    if (le < ne)
-                        for (int i2 = li; i2 < m; i2 += w) {
-                            const double val = res[le * m + i2];
-                            acc += wt[i2] * (val * val);
+                for (int b0 = 0; b0 < m; b0 += 16 * w) {                     // one trip unless m > 1024 (whole-chunk blocks)
+                    // the lane's weights of this trip: terms u = 0..umax, from the last one down
+                    const int umax = li + b0 < m ? (((m - 1 - li - b0) >> e_lw) < 15 ? ((m - 1 - li - b0) >> e_lw) : 15) : -1;
+                    double wv[16];
+                    double wcur = b0 == 0 ? w_last0 : (umax >= 0 ? ewt_f[b0 + li + (umax << e_lw)] : 0.0);
+#pragma unroll
+                    for (int u = 15; u >= 0; --u) {
+                        wv[u] = u > umax ? 0.0 : wcur;
+                        if (u <= umax && !(FRT_OB_EABL & 8)) wcur *= rinv;
+                    }
+                    for (int e0 = wave * per_wave; e0 < ne; e0 += (kObThreads / 64) * per_wave) {
+                        const int le = e0 + sub;
+                        // branch-free: a term past the block's end has weight 0 and reads a clamped (valid) address
+                        double acc = 0.0;
+#pragma unroll
+                        for (int h = 0; h < 16; h += 8) {                    // eight reads in flight
+                            double val[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const int at = le * m + b0 + li + ((h + u) << e_lw);
+                                val[u] = (FRT_OB_EABL & 4) ? (double)at : res[at < F - kTail ? at : F - kTail - 1];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) acc += wv[h + u] * (val[u] * val[u]);
                         }
-                    for (int d = w >> 1; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-                    if (le < ne && li == 0) eo[(size_t)le * a.nbands] = acc;
+                        if (!(FRT_OB_EABL & 2)) acc = group_sum(acc, w);
+                        if (le < ne && li == 0 && (!(FRT_OB_EABL & 1) || acc == -1.0)) {
+                            if (b0 == 0) eo[(size_t)le * a.nbands] = acc;
+                            else eo[(size_t)le * a.nbands] += acc;           // (m > 1024: same thread, same order every run)
+                        }
+                    }
                 }
             }
         }
@@ -505,6 +624,10 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
             a.y_off[i] = band_off[band];
             a.band_index[i] = band;
             a.ewt_off[i] = d_eblock ? o->ewt_off[band] : 0;
+            if (d_eblock) {
+                const int ew = (a.elen < 64 && (a.elen & (a.elen - 1)) == 0) ? a.elen : 64;      // lanes per energy block
+                a.ewr[i] = std::pow(1.0 - o->ewt_alpha[band], (double)ew);
+            }
         }
         a.xnext = j + 1 < kNOctave ? h->xbuf[j + 1].as<double>() : nullptr;
         a.xnext_stride = j + 1 < kNOctave ? len[j + 1] : 0;

@@ -495,7 +495,7 @@ template <typename T, int LOG2M>
 static int launch_big_one(const StftArgs& a, hipStream_t stream) {
     using B = BigPlan<LOG2M>;
     const int blocks = (a.n_groups + B::GPB - 1) / B::GPB;
-    if constexpr (sizeof(T) == 4 && LOG2M >= 12) {
+    if constexpr (sizeof(T) == 4 && LOG2M >= FRT_BIG_DMA_MIN_LOG2M) {
         // rows on 16-byte boundaries (the library's own staging buffers and torch tensors are): the LDS-DMA variant
         const bool aligned16 = ((uintptr_t)a.x % 16 == 0) && (a.x_stride % 4 == 0) && (a.hop % 4 == 0);
         if (aligned16 && !getenv("FRT_STFT_NO_DMA")) {

@@ -17,6 +17,9 @@
 // Three barriers per frame, 74 KB of LDS for N = 16384 -> two 512-thread workgroups per CU.
 #pragma once
 
+#ifndef FRT_BIG_DMA_MIN_LOG2M    // smallest log2(N/2) whose aligned launches take the LDS-staged instance
+#define FRT_BIG_DMA_MIN_LOG2M 11
+#endif
 #ifndef FRT_BIG_ZB              // bin pairs whose Z values are requested together in the unpack (2, 4 or 8)
 #define FRT_BIG_ZB 4
 #endif
@@ -74,7 +77,7 @@ struct BigPlan {
     static constexpr int GPB = 1;                           // frames in flight per workgroup
 };
 
-// DMA (one frame per workgroup, N >= 8192, 16-byte aligned rows): the samples of the NEXT frame are copied from HBM
+// DMA (N >= 4096, 16-byte aligned rows): the samples of the NEXT frame are copied from HBM
 // straight into LDS (global_load_lds_dwordx4, no registers involved) while the current frame's sub-transforms and
 // unpack run; the first stage then reads its 16 samples from LDS.  These sizes cannot afford the 32 live registers a
 // register prefetch costs (they hold ~90 hoisted constants), and have the LDS to spare.
@@ -83,10 +86,9 @@ struct BigPlan {
 template <typename T, int LOG2M, bool DMA>
 __device__ __forceinline__ void stft_big_body(const StftArgs& a, cpx<T>* __restrict__ lds, uint32_t* __restrict__ lut_lds,
                                               cpx<T>* __restrict__ stage, cpx<T>* __restrict__ tws_lds) {
-    // The LDS arrays arrive as __restrict__ parameters of an inlined function: that is what gives every LDS access an
-    // alias scope, and the scopes are what let the compiler's wait-count pass see that the sub-transforms and the unpack
-    // (regions, LUT) do not read what the LDS-DMA of the next frame (stage) writes.  Without them every ds_read behind a
-    // global_load_lds waits for vmcnt(0): the staging of the next frame was awaited right where it was issued.
+    // (The LDS arrays arrive as __restrict__ parameters of an inlined function so that every LDS access carries an alias
+    // scope.  That alone did not keep the compiler's wait-count pass from guarding LDS accesses behind an LDS-DMA with
+    // vmcnt(0) — paired ds_write2 lose their scopes — which is why the copy is issued from inline assembly, below.)
     using B = BigPlan<LOG2M>;
     using C = cpx<T>;
     constexpr int M = B::M, MS = B::MS, TPFS = B::TPFS, RS = B::RS, BLOCK = B::BLOCK;
@@ -169,7 +171,7 @@ __device__ __forceinline__ void stft_big_body(const StftArgs& a, cpx<T>* __restr
     // N <= 4096: the 16 samples of the NEXT frame are requested as soon as the current frame's first stage has left
     // its registers (32 more live registers: +15 % at 2048 / 4096; at 8192 the kernel would drop to one wave per SIMD
     // or lose the hoisted weights, at 16384 it spills — measured slower or equal there)
-    constexpr bool PREFETCH = HOIST1 && LOG2M <= 11;
+    constexpr bool PREFETCH = HOIST1 && !DMA && LOG2M <= 11;
     C nx[PREFETCH ? 16 : 1];                     // the samples of the frame about to be transformed
     if constexpr (PREFETCH) {
 #pragma unroll
@@ -316,7 +318,7 @@ __device__ __forceinline__ void stft_big_body(const StftArgs& a, cpx<T>* __restr
         // The Z values of ZB of the thread's eight pairs are requested before the first is used (the registers of the
         // first stage are free here): 8 / ZB exposed LDS round trips per frame instead of eight — with two waves per
         // SIMD there is little else to cover them.  (All eight at once spill where the prefetched samples are live too.)
-        constexpr int ZB = (PREFETCH && LOG2M == 11) ? 2 : FRT_BIG_ZB;      // N = 4096 has no registers left
+        constexpr int ZB = (PREFETCH && LOG2M == 11) ? 2 : FRT_BIG_ZB;      // (the unaligned-row fallback at N = 4096 has no registers left)
         C za[8], zb[8];
         auto request_z = [&](int q0) {
 #pragma unroll

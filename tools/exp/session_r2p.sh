@@ -1,0 +1,3 @@
+#!/bin/bash
+timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+python tools/bench_firbank.py

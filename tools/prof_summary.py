@@ -39,7 +39,7 @@ def pmc(root, needle):
             if needle in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in sorted(acc.items()):
-            print(f"{os.path.basename(os.path.dirname(d)):8s} {k:28s} dispatches={len(v):3d} mean={sum(v)/len(v):.6g}")
+            print(f"{os.path.basename(os.path.dirname(d)):8s} {k:28s} dispatches={len(v):3d} mean={sum(v)/len(v):.6g} sum={sum(v):.6g} max={max(v):.6g}")
 
 
 if __name__ == "__main__":
