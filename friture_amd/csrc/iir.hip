@@ -320,7 +320,21 @@ static int launch_iir_stage(IirStageArgs a, const int* orders, int n_channels, h
 // (channel, chunk) column and walks its samples, the table row g[k][0..rows) is wave-uniform (scalar loads,
 // the FMAs take it from SGPRs), 32 states per lane are accumulated at a time.  blockIdx.y splits the chunk
 // into K-slices whose partial sums the scan kernel adds; blockIdx.z tiles the rows.
-constexpr int kZsRows = 32;
+constexpr int kZsRows = 32;             // the table's rows are padded to a multiple of this
+#ifndef FRT_ZS_ROWS
+#define FRT_ZS_ROWS 16
+#endif
+#ifndef FRT_ZS_COLS
+#define FRT_ZS_COLS 2
+#endif
+constexpr int kZsRowsPerPass = FRT_ZS_ROWS, kZsCols = FRT_ZS_COLS;      // states x columns per lane (see iir_zero_state_kernel)
+static_assert(kZsRows % kZsRowsPerPass == 0, "row groups tile the padded table");
+#ifndef FRT_ZS_ABLATE           // experiment builds (wrong results): 1 one table row for every sample, 2 no sample loads
+#define FRT_ZS_ABLATE 0
+#endif
+#ifndef FRT_ZS_BATCH            // samples per lane and batch of the zero-state kernel (8, 16 or 32)
+#define FRT_ZS_BATCH 8
+#endif
 constexpr int kMaxSlices = 8;
 
 struct ZeroStateArgs {
@@ -331,72 +345,186 @@ struct ZeroStateArgs {
     int slice;                 // samples per K-slice (multiple of 8)
     int vec;                   // rows 16-byte aligned: vector loads allowed
     const double* table;       // [chunk][rows_padded]: g[k][r]
+    const double* table_m;     // the same values in the MFMA kernel's operand order (zs_mfma_index)
     int rows, rows_padded;
     const int* rowmap;         // [rows_padded]: f * kStates + s of each row, -1 for padding
     double* partial;           // [n_slices][C][nfilt][nchunks][kStates]
     long long partial_stride;
 };
 
+// ROWS states x COLS (channel, chunk) columns per lane.  The table row g[k][.] reaches the FMAs through scalar registers,
+// 8 bytes of scalar-cache traffic per FMA instruction when a lane owns one column — and that stream, not the arithmetic,
+// was what bound the kernel (a build reading one table row for every k ran 3x faster).  Every g[k][r] now feeds COLS FMAs.
+template <int ROWS, int COLS>
 __global__ void __launch_bounds__(64) iir_zero_state_kernel(const ZeroStateArgs a) {
     const int lane = threadIdx.x;
-    const long long col = (long long)blockIdx.x * 64 + lane;
     const long long ncols = (long long)a.n_channels * a.nchunks;
+    const int r0 = blockIdx.z * ROWS;
+    const int k0 = blockIdx.y * a.slice;
+    bool valid[COLS];
+    int ch[COLS], cq[COLS];
+    long long first[COLS], xrow[COLS];
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) {
+        const long long col = ((long long)blockIdx.x * 64 + lane) * COLS + j;
+        valid[j] = col < ncols;
+        const long long cc = valid[j] ? col : 0;
+        ch[j] = (int)(cc / a.nchunks);
+        cq[j] = (int)(cc % a.nchunks);
+        first[j] = (long long)cq[j] * a.chunk + k0;                    // stage sample index of the column's first sample
+        xrow[j] = (long long)ch[j] * a.x_stride;
+    }
+    const double* __restrict__ g = a.table + (size_t)k0 * a.rows_padded + r0;
+    double acc[COLS][ROWS];
+#pragma unroll
+    for (int j = 0; j < COLS; ++j)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) acc[j][r] = 0.0;
+    // KB samples of each of the lane's streams per batch, their loads in flight together; 16-byte loads when the rows are
+    // aligned (a.vec) — a quarter / half of the load instructions, each of which touches 64 different cache lines
+    constexpr int KB = FRT_ZS_BATCH;
+    for (int k = 0; k < a.slice; k += KB) {
+        double xv[COLS][KB];
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) {
+            const long long i0 = first[j] + k;
+            if (FRT_ZS_ABLATE & 2) {
+#pragma unroll
+                for (int u = 0; u < KB; ++u) xv[j][u] = (double)(k + u);
+            } else if (a.vec && valid[j] && i0 + KB <= a.n && k + KB <= a.slice) {
+                if (a.in_f32) {
+                    const float4* p = (const float4*)((const float*)a.x + xrow[j] + i0);
+                    float4 raw[KB / 4];
+#pragma unroll
+                    for (int u = 0; u < KB / 4; ++u) raw[u] = p[u];
+#pragma unroll
+                    for (int u = 0; u < KB / 4; ++u) {
+                        xv[j][4 * u] = raw[u].x; xv[j][4 * u + 1] = raw[u].y; xv[j][4 * u + 2] = raw[u].z; xv[j][4 * u + 3] = raw[u].w;
+                    }
+                } else {
+                    const double2* p = (const double2*)((const double*)a.x + xrow[j] + i0);
+#pragma unroll
+                    for (int u = 0; u < KB / 2; ++u) {
+                        const double2 v = p[u];
+                        xv[j][2 * u] = v.x;
+                        xv[j][2 * u + 1] = v.y;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < KB; ++u) {
+                    const long long i = i0 + u;
+                    const bool ok = valid[j] && i < a.n && k + u < a.slice;
+                    const long long ii = ok ? xrow[j] + i : 0;
+                    const double v = a.in_f32 ? (double)((const float*)a.x)[ii] : ((const double*)a.x)[ii];
+                    xv[j][u] = ok ? v : 0.0;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            if (k + u < a.slice) {                                   // uniform; a.slice is a multiple of 8
+                const double* __restrict__ gk = g + (size_t)((FRT_ZS_ABLATE & 1) ? 0 : k + u) * a.rows_padded;
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const double gv = gk[r];
+#pragma unroll
+                    for (int j = 0; j < COLS; ++j) acc[j][r] = __builtin_fma(gv, xv[j][u], acc[j][r]);
+                }
+            }
+        }
+    }
+    double* out = a.partial + (size_t)blockIdx.y * a.partial_stride;
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) {
+        if (!valid[j]) continue;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int m = a.rowmap[r0 + r];                               // uniform
+            if (m >= 0) out[(((size_t)ch[j] * a.nfilt + (m >> 4)) * a.nchunks + cq[j]) * kStates + (m & 15)] = acc[j][r];
+        }
+    }
+}
+
+// The same product on the matrix cores.  It IS a dense contraction — end[row][col] = sum_k g[k][row] x[col][k], 24-108 rows,
+// 64-16384 samples deep, C x chunks columns — and on the vector ALUs it was bound by operand delivery, not arithmetic: one
+// table value per FMA through the scalar cache (above).  v_mfma_f64_16x16x4_f64 takes A = g^T (16 rows x 4 samples) and
+// B = x (4 samples x 16 columns) from vector registers, one value per lane each, and reuses them 16-fold inside the array.
+//   lane l = (j = l % 16, g = l / 16).  A block of 16 samples is four MFMA steps t = 0..3; in step t slot g stands for sample
+//   16 kb + 4 g + t (the sum over k does not care which slot a sample sits in, as long as A and B agree).  So a lane needs
+//   four CONSECUTIVE samples of column j per block — one 16-byte load, the four lanes of a column covering 64 contiguous
+//   bytes — and, per row tile, the four table values g[16 kb + 4 g + t][16 rt + j], stored contiguously for exactly this
+//   (zs_mfma_index): 32 bytes per lane, 2 KB contiguous per wavefront.
+//   D: lane (j, g) holds rows 16 rt + 4 v + g (v = 0..3) of column j (tools/exp/mfma_f64_layout.cpp prints the layout).
+typedef double zs_double4 __attribute__((ext_vector_type(4)));
+__host__ __device__ inline size_t zs_mfma_index(int k, int row, int row_tiles) {
+    return (((((size_t)(k >> 4) * row_tiles + (row >> 4)) * 4 + ((k >> 2) & 3)) * 16 + (row & 15)) * 4) + (k & 3);
+}
+constexpr int kZsTiles = kZsRows / 16;          // row tiles per workgroup
+
+__global__ void __launch_bounds__(64) iir_zero_state_mfma_kernel(const ZeroStateArgs a) {
+    const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+    const long long ncols = (long long)a.n_channels * a.nchunks;
+    const long long col = (long long)blockIdx.x * 16 + j;
     const bool valid = col < ncols;
     const long long cc = valid ? col : 0;
     const int c = (int)(cc / a.nchunks), q = (int)(cc % a.nchunks);
-    const int r0 = blockIdx.z * kZsRows;
-    const int k0 = blockIdx.y * a.slice;
-    const long long first = (long long)q * a.chunk + k0;              // stage sample index of this lane's first sample
+    const int k0 = blockIdx.y * a.slice;                                  // a multiple of 16
+    const int rt0 = blockIdx.z * kZsTiles, row_tiles = a.rows_padded / 16;
+    const long long first = (long long)q * a.chunk + k0 + 4 * g;          // the lane's first sample
     const long long xrow = (long long)c * a.x_stride;
-    const double* __restrict__ g = a.table + (size_t)k0 * a.rows_padded + r0;
-    double acc[kZsRows];
+    zs_double4 acc[kZsTiles];
 #pragma unroll
-    for (int r = 0; r < kZsRows; ++r) acc[r] = 0.0;
-    // eight samples of the lane's own stream per batch (one 64-byte line), their loads in flight together;
-    // 16-byte loads when the rows are aligned (a.vec) — a quarter / half of the load instructions, each of
-    // which touches 64 different cache lines
-    for (int k = 0; k < a.slice; k += 8) {
-        double xv[8];
-        const long long i0 = first + k;
-        if (a.vec && valid && i0 + 8 <= a.n) {
-            if (a.in_f32) {
-                const float4* p = (const float4*)((const float*)a.x + xrow + i0);
-                const float4 lo = p[0], hi = p[1];
-                xv[0] = lo.x; xv[1] = lo.y; xv[2] = lo.z; xv[3] = lo.w;
-                xv[4] = hi.x; xv[5] = hi.y; xv[6] = hi.z; xv[7] = hi.w;
+    for (int rt = 0; rt < kZsTiles; ++rt) acc[rt] = zs_double4{0.0, 0.0, 0.0, 0.0};
+    const zs_double4* __restrict__ tm = (const zs_double4*)a.table_m;
+    constexpr int UN = 2;                                                 // blocks of 16 samples whose loads are in flight together
+    for (int kb = 0; kb < a.slice / 16; kb += UN) {
+        double xs[UN][4];
+        zs_double4 av[UN][kZsTiles];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const bool in_slice = kb + u < a.slice / 16;
+            const long long i0 = first + 16 * (kb + u);
+            if (in_slice && a.vec && valid && i0 + 4 <= a.n) {
+                if (a.in_f32) {
+                    const float4 v = *(const float4*)((const float*)a.x + xrow + i0);
+                    xs[u][0] = v.x; xs[u][1] = v.y; xs[u][2] = v.z; xs[u][3] = v.w;
+                } else {
+                    const double2* p = (const double2*)((const double*)a.x + xrow + i0);
+                    const double2 lo = p[0], hi = p[1];
+                    xs[u][0] = lo.x; xs[u][1] = lo.y; xs[u][2] = hi.x; xs[u][3] = hi.y;
+                }
             } else {
-                const double2* p = (const double2*)((const double*)a.x + xrow + i0);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double2 v = p[u];
-                    xv[2 * u] = v.x;
-                    xv[2 * u + 1] = v.y;
+                for (int t = 0; t < 4; ++t) {
+                    const long long i = i0 + t;
+                    const bool ok = in_slice && valid && i < a.n;
+                    const long long ii = ok ? xrow + i : 0;
+                    const double v = a.in_f32 ? (double)((const float*)a.x)[ii] : ((const double*)a.x)[ii];
+                    xs[u][t] = ok ? v : 0.0;
                 }
             }
-        } else {
+            const size_t kblock = (size_t)(k0 >> 4) + (in_slice ? kb + u : 0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const long long i = i0 + u;
-                const bool ok = valid && i < a.n;
-                const long long ii = ok ? xrow + i : 0;
-                const double v = a.in_f32 ? (double)((const float*)a.x)[ii] : ((const double*)a.x)[ii];
-                xv[u] = ok ? v : 0.0;
-            }
+            for (int rt = 0; rt < kZsTiles; ++rt) av[u][rt] = tm[((kblock * row_tiles + rt0 + rt) * 4 + g) * 16 + j];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const double* __restrict__ gk = g + (size_t)(k + u) * a.rows_padded;
+        for (int u = 0; u < UN; ++u)
 #pragma unroll
-            for (int r = 0; r < kZsRows; ++r) acc[r] = __builtin_fma(gk[r], xv[u], acc[r]);
-        }
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rt = 0; rt < kZsTiles; ++rt)
+                    acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][rt][t], xs[u][t], acc[rt], 0, 0, 0);
     }
     if (!valid) return;
     double* out = a.partial + (size_t)blockIdx.y * a.partial_stride;
 #pragma unroll
-    for (int r = 0; r < kZsRows; ++r) {
-        const int m = a.rowmap[r0 + r];                               // uniform
-        if (m >= 0) out[(((size_t)c * a.nfilt + (m >> 4)) * a.nchunks + q) * kStates + (m & 15)] = acc[r];
-    }
+    for (int rt = 0; rt < kZsTiles; ++rt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int m = a.rowmap[(rt0 + rt) * 16 + 4 * v + g];
+            if (m >= 0) out[(((size_t)c * a.nfilt + (m >> 4)) * a.nchunks + q) * kStates + (m & 15)] = acc[rt][v];
+        }
 }
 
 // partial[0][i] += partial[1..n_slices)[i]: the K-slices of pass 1 summed in slice order
@@ -696,7 +824,7 @@ extern "C" void frt_octbank_destroy(frt_octbank* h) {
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     frt_ola_destroy(h);
-    DeviceBuffer* bufs[] = {&h->coef, &h->order, &h->state, &h->xin, &h->ypacked, &h->chunk_end, &h->chunk_init, &h->power, &h->zs_table, &h->zs_rowmap,
+    DeviceBuffer* bufs[] = {&h->coef, &h->order, &h->state, &h->xin, &h->ypacked, &h->chunk_end, &h->chunk_init, &h->power, &h->zs_table, &h->zs_table_m, &h->zs_rowmap,
                             &h->eblock, &h->alpha, &h->decay_n, &h->smooth, &h->weight, &h->eout};
     for (auto* b : bufs) b->release();
     for (auto& b : h->xbuf) b.release();
@@ -813,7 +941,7 @@ static int ensure_powers(frt_octbank* h, int n) {
         h->zs_offset[j] = total;
         total += (size_t)stage_chunk(h->chunk0, j) * h->zs_rows_padded;
     }
-    std::vector<double> tab(total, 0.0);
+    std::vector<double> tab(total, 0.0), tab_m(total, 0.0);      // tab_m: the same values in the MFMA kernel's operand order
     for (int j = 0; j < kNOctave; ++j) {
         const int L = stage_chunk(h->chunk0, j);
         int row = 0;
@@ -824,7 +952,10 @@ static int ensure_powers(frt_octbank* h, int n) {
             std::vector<long double> v(ord), w(ord);
             for (int t = 0; t < ord; ++t) v[t] = (long double)bc[t + 1] - (long double)ac[t + 1] * (long double)bc[0];
             for (int k = L - 1; k >= 0; --k) {
-                for (int t = 0; t < ord; ++t) tab[h->zs_offset[j] + (size_t)k * h->zs_rows_padded + row + t] = (double)v[t];
+                for (int t = 0; t < ord; ++t) {
+                    tab[h->zs_offset[j] + (size_t)k * h->zs_rows_padded + row + t] = (double)v[t];
+                    tab_m[h->zs_offset[j] + zs_mfma_index(k, row + t, h->zs_rows_padded / 16)] = (double)v[t];
+                }
                 // v <- A v:  (A v)[t] = v[t+1] - a[t+1] v[0]
                 for (int t = 0; t < ord; ++t) w[t] = (t + 1 < ord ? v[t + 1] : 0.0L) - (long double)ac[t + 1] * v[0];
                 v.swap(w);
@@ -832,7 +963,7 @@ static int ensure_powers(frt_octbank* h, int n) {
             row += ord;
         }
     }
-    if ((rc = upload(h->zs_table, tab)) || (rc = upload(h->zs_rowmap, rowmap))) return rc;
+    if ((rc = upload(h->zs_table, tab)) || (rc = upload(h->zs_table_m, tab_m)) || (rc = upload(h->zs_rowmap, rowmap))) return rc;
     h->power_chunk0 = h->chunk0;
     h->power_n = n;
     return FRT_OK;
@@ -913,20 +1044,28 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
                 if ((rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream))) return rc;
             } else {
                 // K-slices: enough wavefronts to fill the chip when the columns alone do not
-                const long long colwaves = ((long long)h->n_channels * a.nchunks + 63) / 64;
-                while (n_slices < kMaxSlices && colwaves * n_slices < 2048 && a.chunk / (2 * n_slices) >= 8) n_slices *= 2;
+                static const bool use_vector_alu = getenv("FRT_ZS_VECTOR") != nullptr;      // A/B runs: the vector-ALU kernel
+                const int cols_per_wave = use_vector_alu ? 64 * kZsCols : 16;
+                const int slice_min = use_vector_alu ? 8 : 16;
+                const long long colwaves = ((long long)h->n_channels * a.nchunks + cols_per_wave - 1) / cols_per_wave;
+                while (n_slices < kMaxSlices && colwaves * n_slices < 2048 && a.chunk % (2 * n_slices * slice_min) == 0) n_slices *= 2;      // whole K-blocks per slice
                 ZeroStateArgs z{};
                 z.x = a.x; z.x_stride = a.x_stride; z.n = a.n; z.in_f32 = a.in_f32;
                 z.chunk = a.chunk; z.nchunks = a.nchunks; z.n_channels = h->n_channels; z.nfilt = h->nfilt;
                 z.slice = a.chunk / n_slices;
                 z.vec = ((uintptr_t)a.x % 16 == 0) && (a.x_stride % (a.in_f32 ? 4 : 2) == 0);
                 z.table = h->zs_table.as<double>() + h->zs_offset[j];
+                z.table_m = h->zs_table_m.as<double>() + h->zs_offset[j];
                 z.rows = h->zs_rows; z.rows_padded = h->zs_rows_padded;
                 z.rowmap = h->zs_rowmap.as<int>();
                 z.partial = h->chunk_end.as<double>();
                 z.partial_stride = slice_stride;
-                hipLaunchKernelGGL(iir_zero_state_kernel, dim3((unsigned)colwaves, n_slices, h->zs_rows_padded / kZsRows), dim3(64), 0,
-                                   h->stream, z);
+                if (use_vector_alu)
+                    hipLaunchKernelGGL((iir_zero_state_kernel<kZsRowsPerPass, kZsCols>),
+                                       dim3((unsigned)colwaves, n_slices, h->zs_rows_padded / kZsRowsPerPass), dim3(64), 0, h->stream, z);
+                else
+                    hipLaunchKernelGGL(iir_zero_state_mfma_kernel, dim3((unsigned)colwaves, n_slices, h->zs_rows_padded / kZsRows), dim3(64),
+                                       0, h->stream, z);
                 if (n_slices > 1)
                     hipLaunchKernelGGL(iir_slice_sum_kernel, dim3((unsigned)((slice_stride + 255) / 256)), dim3(256), 0, h->stream,
                                        h->chunk_end.as<double>(), slice_stride, n_slices, slice_stride);

@@ -43,7 +43,7 @@ struct frt_octbank {
     std::vector<int> h_order;
     frt::DeviceBuffer coef, order, state;        // state: [9][C][nfilt][16]
     frt::DeviceBuffer xin, ypacked, xbuf[frt::kNOctave], chunk_end, chunk_init, power;
-    frt::DeviceBuffer zs_table, zs_rowmap;   // zero-state response tables of the time-parallel mode (iir.hip)
+    frt::DeviceBuffer zs_table, zs_table_m, zs_rowmap;   // zero-state response tables of the time-parallel mode (iir.hip)
     std::vector<size_t> zs_offset;           // per stage, in doubles
     int zs_rows = 0, zs_rows_padded = 0;
     bool zero_state_by_recurrence = false;   // A/B and tests: pass 1 as a second run of the recurrence

@@ -330,6 +330,42 @@ __device__ __forceinline__ double group_sum(double acc, int w) {
     if (w >= 64) acc += __shfl_xor(acc, 32, 64);
     return acc;
 }
+// The 2048-point forward transform of fft_core.h (radix 8, 8, 8, 4; v[j] = z[i + 256 j] in, Z[i + 256 j] out) with its three
+// exchanges alternating between two LDS buffers, first -> second -> first: the barrier that would keep a pass's scatter from
+// overtaking the previous pass's gathers is not needed when the scatter goes to the other buffer (whose last readers all
+// passed the barrier in between).  `first` must have no readers left at entry, `second` none by the first barrier inside.
+template <typename TW>
+__device__ __forceinline__ void fft2048_two_buffers(cpx<double> (&v)[8], cpx<double>* first, cpx<double>* second, int i, const TW& tw) {
+    using P = Pow2Plan<11>;
+    constexpr int TPF = P::TPF, M = P::M;
+    static_assert(P::NP8 == 3 && P::RLAST == 4, "8 x 8 x 8 x 4");
+    int n = 0, p = 1;
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        const int k = i & (p - 1);
+        if (pass > 0) {
+            const int step = M / (8 * p);
+#pragma unroll
+            for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], tw.get(n++, (q * k * step) & (M - 1)));
+        }
+        dft8(v);
+        cpx<double>* buf = (pass & 1) ? second : first;
+        const int base = (i - k) * 8 + k;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) buf[lds_pad(base + q * p)] = v[q];
+        if (!(FRT_OB_ABLATE & 8)) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = buf[lds_pad(i + j * TPF)];
+        p *= 8;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {                                // two radix-4 butterflies on slots c + 2q
+        const int k = (i + c * TPF) & (p - 1);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) v[c + 2 * q] = cmul(v[c + 2 * q], tw.get(n++, (q * k * (M / (4 * p))) & (M - 1)));
+        dft4(v[c], v[c + 2], v[c + 4], v[c + 6]);
+    }
+}
 #ifndef FRT_OB_EABL     // experiment builds (wrong energies): 1 no stores, 2 no lane reduction, 4 no LDS reads, 8 no weight recurrence
 #define FRT_OB_EABL 0
 #endif
@@ -341,11 +377,14 @@ __global__ void __launch_bounds__(kObThreads, FRT_OB_MIN_WAVES) ola_batch_kernel
     constexpr int M = kObM, F = kObF, LOG2M = 11;
     using P = Pow2Plan<LOG2M>;
     static_assert(P::M == M && P::TPF == kObThreads, "one thread per eight points of the 2048-point complex transform");
-    // ONE LDS array: exchange buffer of the radix-8 passes, hand-over of Z / of the packed products between threads, and
-    // the finished window.  The spectrum X of the window lives in registers — thread tid keeps the four bin pairs
-    // (k, M - k), k = tid + 256 j (thread 0 also bin M/2) — so that a workgroup needs 37 KB of LDS instead of 70 and
-    // three fit a CU; a pair also shares its sum / difference / twiddle product between the two bins, in both directions.
-    __shared__ C buf[lds_padded_size(M)];         // >= M + 1 elements
+    // TWO LDS arrays taking turns as exchange buffer of the radix-8 passes, hand-over of Z / of the packed products between
+    // threads, and finished window: writing to the array nobody can still be reading saves the five barriers per transform
+    // that only guarded the re-use of a single one (the register budget allows two workgroups per CU; two arrays of 37 KB
+    // each still fit twice).  The spectrum X of the window lives in registers — thread tid keeps the four bin pairs
+    // (k, M - k), k = tid + 256 j (thread 0 also bin M/2); a pair shares its sum / difference / twiddle product between the
+    // two bins, in both directions.
+    __shared__ C buf_a[lds_padded_size(M)];       // >= M + 1 elements each
+    __shared__ C buf_b[lds_padded_size(M)];
     __shared__ C xmid_lds;                        // X[M/2] (self-paired; thread 0 packs it)
     const int tid = threadIdx.x;
     const int blk = blockIdx.x, grp = blockIdx.y, c = blockIdx.z;
@@ -381,11 +420,12 @@ __global__ void __launch_bounds__(kObThreads, FRT_OB_MIN_WAVES) ola_batch_kernel
             v[j] = {sample(s0 + 2 * q), sample(s0 + 2 * q + 1)};
         }
     }
-    fft_pow2_forward<double, LOG2M, (FRT_OB_ABLATE & 8) != 0>(v, buf, tid, twt);    // v[j] = Z[tid + 256 j]
-    __syncthreads();                                             // the last pass's gathers are done: buf is free
+    fft2048_two_buffers(v, buf_a, buf_b, tid, twt);              // v[j] = Z[tid + 256 j]; exchanges in a, b, a
 #pragma unroll
-    for (int j = 0; j < 8; ++j) buf[tid + j * kObThreads] = v[j];
+    for (int j = 0; j < 8; ++j) buf_b[tid + j * kObThreads] = v[j];
     __syncthreads();
+    C* buf = buf_b;                                              // the array just written; `other`: free of readers
+    C* other = buf_a;
     // X[k] = (S - i t) / 2 and X[M - k] = (conj S - i conj t) / 2 with S = Z[k] + conj Z[M-k], t = w^k (Z[k] - conj Z[M-k]),
     // w = exp(-2 pi i / F); k = 0 pairs X[0] with the Nyquist bin X[M]
     C xa[4], xb[4];
@@ -403,9 +443,8 @@ __global__ void __launch_bounds__(kObThreads, FRT_OB_MIN_WAVES) ola_batch_kernel
         const C A = buf[M / 2];                                  // self-paired: B = conj A, w^(M/2) = -i
         xmid_lds = {A.x, -A.y};                                    // (S - i (-i)(D)) / 2 with S = (2 A.x, 0), D = (0, 2 A.y)
     }
-    __syncthreads();                                             // buf is free again
+    // (no barrier: the first filter packs into `other`; `buf` is written again only behind the barrier after the packing)
 
-    double* out = (double*)buf;                                  // the finished window, plain doubles, after each inverse
     const double inv = 1.0 / (double)M;
     for (int fi = 0; fi < a.gsize; ++fi) {
         const int f = grp * a.gsize + fi;
@@ -435,19 +474,21 @@ __global__ void __launch_bounds__(kObThreads, FRT_OB_MIN_WAVES) ola_batch_kernel
             const C B = cconj(Bm);
             const C S = A + B, D = A - B;
             const C t = cmul(cconj(twl[k]), D);
-            buf[k] = {0.5 * (S.x - t.y), -0.5 * (S.y + t.x)};
-            if (k != 0) buf[M - k] = {0.5 * (S.x + t.y), 0.5 * (S.y - t.x)};
+            other[k] = {0.5 * (S.x - t.y), -0.5 * (S.y + t.x)};
+            if (k != 0) other[M - k] = {0.5 * (S.x + t.y), 0.5 * (S.y - t.x)};
         }
         if (tid == 0) {
             const C A = cmul(xmid_lds, H[M / 2]);                    // k = M/2: B = conj A, conj(w^k) = i: t = i (0, 2 A.y)
-            buf[M / 2] = {A.x, A.y};                             // conj((S + i t)/2) = conj((A.x, -A.y)) ... = (A.x, A.y)
+            other[M / 2] = {A.x, A.y};                             // conj((S + i t)/2) = conj((A.x, -A.y)) ... = (A.x, A.y)
         }
-        __syncthreads();
+        __syncthreads();                                         // xmid_lds (first filter) and the packed inputs are visible
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = buf[tid + j * kObThreads];
-        __syncthreads();                                         // gathered: the first pass may scatter into buf
-        fft_pow2_forward<double, LOG2M, (FRT_OB_ABLATE & 8) != 0>(v, buf, tid, twt);               // conj(FFT(conj Z)) = M ifft(Z)
-        __syncthreads();
+        for (int j = 0; j < 8; ++j) v[j] = other[tid + j * kObThreads];
+        // exchanges in buf, other, buf: every thread is past the barrier above, so nobody reads `buf` (the previous filter's
+        // window, or Z) any more; conj(FFT(conj Z)) = M ifft(Z)
+        fft2048_two_buffers(v, buf, other, tid, twt);
+        double* out = (double*)other;                            // the finished window, plain doubles (its readers: the gathers
+                                                                 // of the second exchange, two barriers back)
         const double* pin = a.pend_in + ((size_t)c * a.nfilt + f) * kTail;
         // finish the window: scale / sign, carried tails on the first 511 outputs of the batch; plain doubles in LDS
 #pragma unroll
@@ -525,7 +566,11 @@ __global__ void __launch_bounds__(kObThreads, FRT_OB_MIN_WAVES) ola_batch_kernel
                 po[t] = val;
             }
         }
-        __syncthreads();
+        // no barrier: the next filter packs into `buf` (its last readers, the third exchange's gathers, are behind the barrier
+        // above), and the array holding this window is written again only behind the next filter's first barrier
+        C* const tmp = buf;
+        buf = other;
+        other = tmp;
     }
 }
 

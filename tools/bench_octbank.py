@@ -28,6 +28,9 @@ def main():
     import torch
     from friture_amd import _lib, filter_design
     from friture_amd.filter import IirBank
+    import os
+    if os.environ.get('FRT_LIB_VARIANT'):      # A/B runs: a variant library built by tools/exp/build_variant.sh
+        _lib.LIB_PATH = Path(__file__).resolve().parent / 'variants' / os.environ['FRT_LIB_VARIANT'] / 'libfriture_hip.so'
     _lib.init(0)
     t = filter_design.load_tables()
     bank = IirBank(t["bdec"], t["adec"], list(t[f"boct_{args.bpo}"]), list(t[f"aoct_{args.bpo}"]), args.channels)
