@@ -37,6 +37,8 @@
 namespace frt {
 
 
+constexpr int kScanRowsDecl = 32;   // = kScanRows (iir_scan_kernel, below)
+
 struct IirStageArgs {
     const void* x;             // [C][x_stride] stage input
     long long x_stride;
@@ -51,7 +53,10 @@ struct IirStageArgs {
     int nchunks;
     int pass;                  // 0 sequential, 1 zero-state scan pass, 2 output pass from chunk_init
     double* chunk_end;         // [C][nfilt][nchunks][kStates] pass 1 result
-    const double* chunk_init;  // [C][nfilt][nchunks][kStates] pass 2 initial states
+    const double* chunk_init;  // [C][nfilt][nchunks][kStates] pass 2: a chunk's state had its scan row started from zero ...
+    const double* group_start; // [C][nfilt][kScanRows][kStates] ... the rows' true initial states ...
+    const double* group_pow;   // [nfilt][scan_group][kStates][kStates] ... and (A^L)^i, i = the chunk's index in its row
+    int scan_group;            // chunks per scan row
     double* y;                 // band outputs (packed per channel) or null
     long long y_cstride;
     long long y_off[kMaxFilters];   // offset of each filter's band inside a channel's packed row
@@ -184,7 +189,15 @@ __device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long 
     double z = 0.0;
     if (live) {
         if (a.pass == 0) z = a.state[sidx];
-        else if (a.pass == 2) z = a.chunk_init[cidx];
+        else if (a.pass == 2) {
+            // true initial state = zero-start prefix + (A^L)^i x the scan row's initial state (iir_scan_kernel)
+            const int srow = q / a.scan_group, i = q - srow * a.scan_group;
+            const double* pw = a.group_pow + (((size_t)f * a.scan_group + i) * kStates + s) * kStates;
+            const double* gs = a.group_start + (((size_t)c * a.nfilt + f) * kScanRowsDecl + srow) * kStates;
+            double acc = a.chunk_init[cidx];
+            for (int t = 0; t < ord; ++t) acc += pw[t] * gs[t];
+            z = acc;
+        }
     }
 
     const int band = a.band_index[f];
@@ -558,13 +571,14 @@ __device__ __forceinline__ double row_matvec(const double (&m)[kStates], double 
 // of nchunks.  power_l / power_g: [nfilt][16][16] row-major A^L and A^(L group).  The end states of eight chunks
 // are fetched at a time, so that no serial step waits for memory.
 constexpr int kScanRows = 32;
+static_assert(kScanRows == kScanRowsDecl, "one constant");
 constexpr int kScanBatch = 8;
 
 template <int NT>
 __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l, const double* __restrict__ power_g,
                                               const double* __restrict__ state, const double* __restrict__ chunk_end,
-                                              double* __restrict__ chunk_init, int gid, int f, bool live, int nchunks, int group,
-                                              double (*gend)[kStates], double (*gstart)[kStates]) {
+                                              double* __restrict__ chunk_init, double* __restrict__ group_start, int gid, int f, bool live,
+                                              int nchunks, int group, double (*gend)[kStates]) {
     const int row = threadIdx.x >> 4, s = threadIdx.x & 15;
     double m[kStates];
 #pragma unroll
@@ -579,28 +593,8 @@ __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l
         for (int j = 0; j < kScanBatch; ++j) e[j] = (live && q + j < q1) ? ce[(size_t)(q + j) * kStates] : 0.0;
     };
 
+    // (1) the row's chunks from a zero state: chunk_init[q] = the state chunk q would start from, had its row started at 0
     double z = 0.0;
-    for (int q = q0; q < q1; q += kScanBatch) {
-        double e[kScanBatch];
-        end_states(q, e);
-#pragma unroll
-        for (int j = 0; j < kScanBatch; ++j)
-            if (q + j < q1) z = e[j] + row_matvec<NT>(m, z);
-    }
-    gend[row][s] = z;
-    __syncthreads();
-    if (row == 0) {
-        double mg[kStates];
-#pragma unroll
-        for (int t = 0; t < kStates; ++t) mg[t] = power_g[((size_t)f * kStates + s) * kStates + t];
-        double zz = live ? state[(size_t)gid * kStates + s] : 0.0;
-        for (int r = 0; r < kScanRows; ++r) {
-            gstart[r][s] = zz;
-            zz = gend[r][s] + row_matvec<NT>(mg, zz);
-        }
-    }
-    __syncthreads();
-    z = gstart[row][s];
     for (int q = q0; q < q1; q += kScanBatch) {
         double e[kScanBatch];
         end_states(q, e);
@@ -612,6 +606,21 @@ __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l
             }
         }
     }
+    gend[row][s] = z;
+    __syncthreads();
+    // (2) row 0 chains the rows with A^(L group): group_start[row] = the true state at the row's first chunk.  The output
+    // pass adds (A^L)^(q - q0) group_start[row] to chunk_init[q] itself (iir_stage_body) — replaying every row from its
+    // true start here, as this kernel used to, was 64 more of the 160 serial steps that are all its time.
+    if (row == 0) {
+        double mg[kStates];
+#pragma unroll
+        for (int t = 0; t < kStates; ++t) mg[t] = power_g[((size_t)f * kStates + s) * kStates + t];
+        double zz = live ? state[(size_t)gid * kStates + s] : 0.0;
+        for (int r = 0; r < kScanRows; ++r) {
+            group_start[((size_t)gid * kScanRows + r) * kStates + s] = zz;
+            zz = gend[r][s] + row_matvec<NT>(mg, zz);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* __restrict__ power_l,
@@ -619,15 +628,16 @@ __global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* 
                                                                   const double* __restrict__ state,
                                                                   const double* __restrict__ chunk_end,
                                                                   const int* __restrict__ order,
-                                                                  double* __restrict__ chunk_init, int nfilt, int nchunks, int group) {
-    __shared__ double gend[kScanRows][kStates], gstart[kScanRows][kStates];
+                                                                  double* __restrict__ chunk_init, double* __restrict__ group_start, int nfilt,
+                                                                  int nchunks, int group) {
+    __shared__ double gend[kScanRows][kStates];
     const int gid = blockIdx.x;                               // (channel, filter) pair
     const int f = gid % nfilt;
     const int ord = order[f];                                 // uniform in the workgroup
     const bool live = (int)(threadIdx.x & 15) < ord;
-    if (ord <= 4) iir_scan_body<4>(power_l, power_g, state, chunk_end, chunk_init, gid, f, live, nchunks, group, gend, gstart);
-    else if (ord <= 12) iir_scan_body<12>(power_l, power_g, state, chunk_end, chunk_init, gid, f, live, nchunks, group, gend, gstart);
-    else iir_scan_body<16>(power_l, power_g, state, chunk_end, chunk_init, gid, f, live, nchunks, group, gend, gstart);
+    if (ord <= 4) iir_scan_body<4>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, f, live, nchunks, group, gend);
+    else if (ord <= 12) iir_scan_body<12>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, f, live, nchunks, group, gend);
+    else iir_scan_body<16>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, f, live, nchunks, group, gend);
 }
 
 // sp_blk = E_blk + sp_{blk-1} * (1-alpha)^n  (exp_smoothing.py:52-54), optional dB + weighting.
@@ -715,6 +725,85 @@ __global__ void __launch_bounds__(kEnergyThreads) energy_scan_kernel(const doubl
         __syncthreads();
     }
     if (tid < nbands) smooth[(size_t)c * nbands + tid] = prev;
+}
+
+// The same recurrence for long batches, split along time: the single-workgroup-per-channel kernel above walks a batch of
+// 4096 blocks in 55 tiles of four barriers each — 143 us of an 1.8 ms bank, with 8 of 256 CUs busy.  Here a workgroup owns
+// kEnergySplit consecutive blocks of one channel, a thread one band: (1) energy_local_kernel runs the recurrence from a
+// zero carry inside every split (in place) and records the split's last value; (2) energy_finish_kernel chains the splits
+// before its own (sp = end_g + carry d^len, a few dozen steps), folds the carry in (local_b + carry d^(b - b0 + 1)),
+// converts and writes.
+constexpr int kEnergySplit = 64;
+
+__global__ void energy_local_kernel(double* __restrict__ eblock, const double* __restrict__ decay_n, double* __restrict__ seg_end,
+                                    int nblocks, int nbands) {
+    const int band = threadIdx.x, sp = blockIdx.x, c = blockIdx.y, nsplit = gridDim.x;
+    if (band >= nbands) return;
+    const int b0 = sp * kEnergySplit, b1 = (b0 + kEnergySplit) < nblocks ? (b0 + kEnergySplit) : nblocks;
+    const double d = decay_n[band];
+    double* p = eblock + ((size_t)c * nblocks + b0) * nbands + band;
+    double local = 0.0;
+    for (int b = b0; b < b1; b += 8) {
+        double e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = b + j < b1 ? p[(size_t)(b - b0 + j) * nbands] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (b + j < b1) {
+                local = e[j] + local * d;
+                p[(size_t)(b - b0 + j) * nbands] = local;
+            }
+        }
+    }
+    seg_end[((size_t)c * nsplit + sp) * nbands + band] = local;
+}
+
+__global__ void energy_finish_kernel(const double* __restrict__ local, const double* __restrict__ decay_n,
+                                     double* seg_end, const double* __restrict__ smooth, void* __restrict__ out,
+                                     int out_f32, int nblocks, int nbands, const double* __restrict__ weight_db, int as_db) {
+    const int band = threadIdx.x, sp = blockIdx.x, c = blockIdx.y, nsplit = gridDim.x;
+    if (band >= nbands) return;
+    const int b0 = sp * kEnergySplit, b1 = (b0 + kEnergySplit) < nblocks ? (b0 + kEnergySplit) : nblocks;
+    const double d = decay_n[band];
+    double dlen = 1.0;                                           // d^kEnergySplit (every split before this one is full)
+    for (int i = 0; i < kEnergySplit; ++i) dlen *= d;
+    double carry = smooth[(size_t)c * nbands + band];           // read by every split of the channel; written by the last one
+    const double* se = seg_end + (size_t)c * nsplit * nbands + band;
+    for (int g = 0; g < sp; g += 8) {
+        double e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = g + j < sp ? se[(size_t)(g + j) * nbands] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (g + j < sp) carry = e[j] + carry * dlen;
+    }
+    const double w = (as_db && weight_db) ? weight_db[band] : 0.0;
+    const size_t base = ((size_t)c * nblocks + b0) * nbands + band;
+    double pw = d, last = carry;
+    for (int b = b0; b < b1; b += 8) {
+        double e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = b + j < b1 ? local[base + (size_t)(b - b0 + j) * nbands] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (b + j < b1) {
+                last = e[j] + carry * pw;
+                pw *= d;
+                double v = last;
+                if (as_db) v = 10.0 * log10(v + 1e-30) + w;
+                const size_t o = base + (size_t)(b - b0 + j) * nbands;
+                if (out_f32) ((float*)out)[o] = (float)v;
+                else ((double*)out)[o] = v;
+            }
+        }
+    }
+    // the channel's other splits read `smooth` too: it is replaced by a third launch-ordered step, below (energy_carry_kernel)
+    if (sp == nsplit - 1) seg_end[((size_t)c * nsplit + sp) * nbands + band] = last;      // parked in its own slot (nobody reads it here)
+}
+
+__global__ void energy_carry_kernel(const double* __restrict__ seg_end, double* __restrict__ smooth, int nsplit, int nbands) {
+    const int band = threadIdx.x, c = blockIdx.x;
+    if (band < nbands) smooth[(size_t)c * nbands + band] = seg_end[((size_t)c * nsplit + nsplit - 1) * nbands + band];
 }
 
 // ---- host side -----------------------------------------------------------------------------------
@@ -824,7 +913,7 @@ extern "C" void frt_octbank_destroy(frt_octbank* h) {
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     frt_ola_destroy(h);
-    DeviceBuffer* bufs[] = {&h->coef, &h->order, &h->state, &h->xin, &h->ypacked, &h->chunk_end, &h->chunk_init, &h->power, &h->zs_table, &h->zs_table_m, &h->zs_rowmap,
+    DeviceBuffer* bufs[] = {&h->coef, &h->order, &h->state, &h->xin, &h->ypacked, &h->chunk_end, &h->chunk_init, &h->power, &h->zs_table, &h->zs_table_m, &h->zs_rowmap, &h->eseg, &h->gpow, &h->gstart,
                             &h->eblock, &h->alpha, &h->decay_n, &h->smooth, &h->weight, &h->eout};
     for (auto* b : bufs) b->release();
     for (auto& b : h->xbuf) b.release();
@@ -928,6 +1017,42 @@ static int ensure_powers(frt_octbank* h, int n) {
     }
     int rc = upload(h->power, p);
     if (rc) return rc;
+    // (A^L)^i for i < group: a chunk's true initial state is its zero-start prefix + (A^L)^i x its scan row's initial state
+    // (iir_scan_kernel, iir_stage_body); successive products in long double
+    {
+        h->gpow_offset.assign(kNOctave, 0);
+        size_t total = 0;
+        for (int j = 0; j < kNOctave; ++j) {
+            const int cj = stage_chunk(h->chunk0, j);
+            h->gpow_offset[j] = total;
+            total += (size_t)h->nfilt * scan_group((len[j] + cj - 1) / cj) * kStates * kStates;
+        }
+        std::vector<double> gp(total, 0.0);
+        const int d = kStates;
+        std::vector<long double> A(d * d), R(d * d), T(d * d);
+        for (int j = 0; j < kNOctave; ++j) {
+            const int cj = stage_chunk(h->chunk0, j);
+            const int group = scan_group((len[j] + cj - 1) / cj);
+            for (int f = 0; f < h->nfilt; ++f) {
+                const double* AL = &p[((size_t)j * h->nfilt + f) * kStates * kStates];        // A^L, rounded to double: the matrix the scan applies
+                for (int i = 0; i < d * d; ++i) A[i] = (long double)AL[i];
+                std::fill(R.begin(), R.end(), 0.0L);
+                for (int i = 0; i < d; ++i) R[i * d + i] = 1.0L;
+                for (int i = 0; i < group; ++i) {
+                    double* dst = &gp[h->gpow_offset[j] + ((size_t)f * group + i) * kStates * kStates];
+                    for (int e = 0; e < d * d; ++e) dst[e] = (double)R[e];
+                    for (int r = 0; r < d; ++r)
+                        for (int c2 = 0; c2 < d; ++c2) {
+                            long double acc = 0;
+                            for (int k = 0; k < d; ++k) acc += A[r * d + k] * R[k * d + c2];
+                            T[r * d + c2] = acc;
+                        }
+                    R = T;
+                }
+            }
+        }
+        if ((rc = upload(h->gpow, gp))) return rc;
+    }
     // zero-state response tables g[k][row] = (A^(L-1-k) B)[s], rows = the live states of every filter
     std::vector<int> rowmap;
     for (int f = 0; f < h->nfilt; ++f)
@@ -986,7 +1111,9 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
         int rc = ensure_powers(h, n);
         if (rc) return rc;
         const size_t ws = (size_t)h->n_channels * h->nfilt * nchunks * kStates * sizeof(double);
-        if ((rc = h->chunk_end.reserve(ws * kMaxSlices)) || (rc = h->chunk_init.reserve(ws))) return rc;
+        if ((rc = h->chunk_end.reserve(ws * kMaxSlices)) || (rc = h->chunk_init.reserve(ws)) ||
+            (rc = h->gstart.reserve((size_t)h->n_channels * h->nfilt * kScanRows * kStates * sizeof(double))))
+            return rc;
     }
     for (int j = 1; j < kNOctave; ++j) {
         int rc = h->xbuf[j].reserve((size_t)h->n_channels * len[j] * sizeof(double));
@@ -1012,6 +1139,9 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
         a.nchunks = parallel ? (len[j] + a.chunk - 1) / a.chunk : 1;
         a.chunk_end = h->chunk_end.as<double>();
         a.chunk_init = h->chunk_init.as<double>();
+        a.group_start = h->gstart.as<double>();
+        a.group_pow = parallel ? h->gpow.as<double>() + h->gpow_offset[j] : nullptr;
+        a.scan_group = parallel ? scan_group(a.nchunks) : 1;
         a.y = d_y;
         a.y_cstride = y_cstride;
         for (int i = 0; i < h->bpo; ++i) {
@@ -1073,7 +1203,8 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
             const size_t per = (size_t)kNOctave * h->nfilt * kStates * kStates, off = (size_t)j * h->nfilt * kStates * kStates;
             hipLaunchKernelGGL(iir_scan_kernel, dim3(h->n_channels * h->nfilt), dim3(kScanRows * 16), 0, h->stream,
                                h->power.as<double>() + off, h->power.as<double>() + per + off, a.state, h->chunk_end.as<double>(),
-                               h->order.as<int>(), h->chunk_init.as<double>(), h->nfilt, a.nchunks, scan_group(a.nchunks));
+                               h->order.as<int>(), h->chunk_init.as<double>(), h->gstart.as<double>(), h->nfilt, a.nchunks,
+                               scan_group(a.nchunks));
             a.pass = 2;
             if ((rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream))) return rc;
         }
@@ -1246,9 +1377,21 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
     if (h->mode == 1) rc = frt_ola_filter_batch(h, d_x, 1, n, nullptr, 0, h->eblock.as<double>(), block, nblocks, alphas);
     else rc = run_stages(h, d_x, 1, n, (int)n, nullptr, 0, h->eblock.as<double>(), block, nblocks);
     if (rc) return rc;
-    hipLaunchKernelGGL(energy_scan_kernel, dim3(h->n_channels), dim3(kEnergyThreads), 0, h->stream, h->eblock.as<double>(),
-                       h->decay_n.as<double>(), h->smooth.as<double>(), (void*)d_out, 1, nblocks, h->nbands,
-                       weight_db ? h->weight.as<double>() : nullptr, as_db);
+    if (nblocks >= 4 * kEnergySplit) {
+        const int nsplit = (nblocks + kEnergySplit - 1) / kEnergySplit, threads = (h->nbands + 63) / 64 * 64;
+        if ((rc = h->eseg.reserve((size_t)h->n_channels * nsplit * h->nbands * sizeof(double)))) return rc;
+        hipLaunchKernelGGL(energy_local_kernel, dim3(nsplit, h->n_channels), dim3(threads), 0, h->stream, h->eblock.as<double>(),
+                           h->decay_n.as<double>(), h->eseg.as<double>(), nblocks, h->nbands);
+        hipLaunchKernelGGL(energy_finish_kernel, dim3(nsplit, h->n_channels), dim3(threads), 0, h->stream, h->eblock.as<double>(),
+                           h->decay_n.as<double>(), h->eseg.as<double>(), h->smooth.as<double>(), (void*)d_out, 1, nblocks, h->nbands,
+                           weight_db ? h->weight.as<double>() : nullptr, as_db);
+        hipLaunchKernelGGL(energy_carry_kernel, dim3(h->n_channels), dim3(threads), 0, h->stream, h->eseg.as<double>(),
+                           h->smooth.as<double>(), nsplit, h->nbands);
+    } else {
+        hipLaunchKernelGGL(energy_scan_kernel, dim3(h->n_channels), dim3(kEnergyThreads), 0, h->stream, h->eblock.as<double>(),
+                           h->decay_n.as<double>(), h->smooth.as<double>(), (void*)d_out, 1, nblocks, h->nbands,
+                           weight_db ? h->weight.as<double>() : nullptr, as_db);
+    }
     FRT_HIP_CHECK(hipGetLastError());
     if (!dx) {
         FRT_HIP_CHECK(hipMemcpyAsync(energy_out, d_out, ecount * sizeof(float), hipMemcpyDeviceToHost, h->stream));
