@@ -76,6 +76,8 @@ struct IirStageArgs {
     int dec_lanes;             // lanes per slot of the decimator's mode (16 or 4), 0 without a decimator
     int row_filter[kMaxFilters];
     int quad_filter[kMaxFilters];
+    int row_energy, quad_energy;    // does any filter of the class feed a band energy?  (the decimator does not: its wavefronts,
+                                    // more than half of a 1/3-octave stage, skip the two energy instructions per sample)
 };
 
 __device__ __forceinline__ double dpp_row_bcast0(double v) {
@@ -201,7 +203,7 @@ __device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long 
     }
 
     const int band = a.band_index[f];
-    const bool energy = a.eblock != nullptr && a.pass != 1;           // uniform
+    const bool energy = a.eblock != nullptr && a.pass != 1 && (LPS == 16 ? a.row_energy : a.quad_energy) != 0;      // uniform
     const bool my_energy = energy && band >= 0 && leader;
     const double alpha = (energy && band >= 0) ? a.alpha[band] : 0.0;
     const double decay = 1.0 - alpha;
@@ -312,9 +314,15 @@ static int launch_iir_stage(IirStageArgs a, const int* orders, int n_channels, h
     a.n_channels = n_channels;
     a.n_row = a.n_quad = 0;
     a.dec_lanes = 0;
+    a.row_energy = a.quad_energy = 0;
     for (int f = 0; f < a.nfilt; ++f) {
-        if (orders[f] > 4) a.row_filter[a.n_row++] = f;
-        else a.quad_filter[a.n_quad++] = f;
+        if (orders[f] > 4) {
+            a.row_filter[a.n_row++] = f;
+            a.row_energy |= a.band_index[f] >= 0;
+        } else {
+            a.quad_filter[a.n_quad++] = f;
+            a.quad_energy |= a.band_index[f] >= 0;
+        }
         if (f == a.dec_filter) a.dec_lanes = orders[f] > 4 ? 16 : 4;
     }
     const long long per = (long long)n_channels * a.nchunks;
@@ -474,6 +482,9 @@ __host__ __device__ inline size_t zs_mfma_index(int k, int row, int row_tiles) {
     return (((((size_t)(k >> 4) * row_tiles + (row >> 4)) * 4 + ((k >> 2) & 3)) * 16 + (row & 15)) * 4) + (k & 3);
 }
 constexpr int kZsTiles = kZsRows / 16;          // row tiles per workgroup
+#ifndef FRT_ZS_UNROLL
+#define FRT_ZS_UNROLL 2
+#endif
 
 __global__ void __launch_bounds__(64) iir_zero_state_mfma_kernel(const ZeroStateArgs a) {
     const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
@@ -490,7 +501,7 @@ __global__ void __launch_bounds__(64) iir_zero_state_mfma_kernel(const ZeroState
 #pragma unroll
     for (int rt = 0; rt < kZsTiles; ++rt) acc[rt] = zs_double4{0.0, 0.0, 0.0, 0.0};
     const zs_double4* __restrict__ tm = (const zs_double4*)a.table_m;
-    constexpr int UN = 2;                                                 // blocks of 16 samples whose loads are in flight together
+    constexpr int UN = FRT_ZS_UNROLL;                                                 // blocks of 16 samples whose loads are in flight together
     for (int kb = 0; kb < a.slice / 16; kb += UN) {
         double xs[UN][4];
         zs_double4 av[UN][kZsTiles];

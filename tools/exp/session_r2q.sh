@@ -1,3 +1,4 @@
 #!/bin/bash
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-python tools/bench_firbank.py | cut -c1-330
+timeout 900 python -m pytest tests/test_iir_gpu.py tests/test_widgets_gpu.py tests/test_sharding_gpu.py tests/test_gcc_gpu.py -x -q -m gpu 2>&1 | tail -3
+python tools/bench_octbank.py --iters 10 | cut -c1-80
+python tools/bench_octbank.py --iters 5 --chunk 4096 --bpo 24 --log2-samples 20 | cut -c1-80
