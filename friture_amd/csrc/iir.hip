@@ -1189,7 +1189,9 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
                 const int cols_per_wave = use_vector_alu ? 64 * kZsCols : 16;
                 const int slice_min = use_vector_alu ? 8 : 16;
                 const long long colwaves = ((long long)h->n_channels * a.nchunks + cols_per_wave - 1) / cols_per_wave;
-                while (n_slices < kMaxSlices && colwaves * n_slices < 2048 && a.chunk % (2 * n_slices * slice_min) == 0) n_slices *= 2;      // whole K-blocks per slice
+                static const int max_slices = getenv("FRT_ZS_MAX_SLICES") ? atoi(getenv("FRT_ZS_MAX_SLICES")) : kMaxSlices;      // A/B runs
+                static const int wave_goal = getenv("FRT_ZS_WAVE_GOAL") ? atoi(getenv("FRT_ZS_WAVE_GOAL")) : 2048;
+                while (n_slices < max_slices && colwaves * n_slices < wave_goal && a.chunk % (2 * n_slices * slice_min) == 0) n_slices *= 2;      // whole K-blocks per slice
                 ZeroStateArgs z{};
                 z.x = a.x; z.x_stride = a.x_stride; z.n = a.n; z.in_f32 = a.in_f32;
                 z.chunk = a.chunk; z.nchunks = a.nchunks; z.n_channels = h->n_channels; z.nfilt = h->nfilt;

@@ -1,4 +1,2 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_iir_gpu.py tests/test_widgets_gpu.py tests/test_sharding_gpu.py tests/test_gcc_gpu.py -x -q -m gpu 2>&1 | tail -3
-python tools/bench_octbank.py --iters 10 | cut -c1-80
-python tools/bench_octbank.py --iters 5 --chunk 4096 --bpo 24 --log2-samples 20 | cut -c1-80
+for ms in 8 1 2 4; do for wg in 1024 2048 4096; do echo -n "max_slices $ms goal $wg: "; FRT_ZS_MAX_SLICES=$ms FRT_ZS_WAVE_GOAL=$wg python tools/bench_octbank.py --iters 10 | cut -c1-80; done; done
