@@ -157,6 +157,40 @@ def test_band_energies(tabs, bpo, chunk):
     assert np.max(np.abs(db - (10 * np.log10(got.astype(np.float64) + 1e-30) + A))) < 1e-3
 
 
+def test_energy_recurrence_split_along_time_equals_tiled(tabs):
+    """Long batches run the block-energy recurrence split along time (energy_local / energy_finish kernels, >= 256 blocks),
+    short calls the one-workgroup-per-channel tile kernel: a 600-block batch (ten splits, the last one ragged) must carry
+    the same smoothed energies as the same samples fed in calls of 100 blocks — linear and dB read-out."""
+    from friture_amd.filter import IirBank
+    bpo, C, nblocks = 3, 3, 600
+    boct, aoct = list(tabs[f"boct_{bpo}"]), list(tabs[f"aoct_{bpo}"])
+    n = 1024 * nblocks
+    x32 = np.stack([synth("noise", n, 21), synth("chirp", n, 22), synth("tone", n, 23)])
+    alphas, _ = dsp.band_smoothing_setup(bpo, 0.125)
+    fi, _, _ = dsp.octave_frequencies(9 * bpo, bpo)
+    A = dsp.band_weighting(fi)[0]
+    for as_db in (False, True):
+        long_bank = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, C)
+        short_bank = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, C)
+        for b in (long_bank, short_bank):
+            b.set_chunk(0)            # sequential filters: bit-identical band signals whatever the call boundaries
+        kw = dict(weight_db=A, as_db=True) if as_db else {}
+        whole = long_bank.energies(x32, 1024, alphas, **kw)
+        parts = [short_bank.energies(x32[:, i * 102400:(i + 1) * 102400], 1024, alphas, **kw) for i in range(6)]
+        pieces = np.concatenate(parts, axis=1)
+        assert whole.shape == pieces.shape == (C, nblocks, 9 * bpo)
+        if as_db:
+            assert np.max(np.abs(whole - pieces)) < 1e-4            # float32 dB values
+        else:
+            assert np.max(np.abs(whole / pieces - 1)) < 1e-6         # float32 output of float64 sums
+        # a second long call continues from the carried energies of the first
+        again_long = long_bank.energies(x32[:, :1024 * 300], 1024, alphas, **kw)
+        again_short = np.concatenate([short_bank.energies(x32[:, i * 102400:(i + 1) * 102400], 1024, alphas, **kw) for i in range(3)], axis=1)
+        tol = 1e-4 if as_db else 1e-6
+        err = np.max(np.abs(again_long - again_short)) if as_db else np.max(np.abs(again_long / again_short - 1))
+        assert err < tol
+
+
 def test_full_size_bank_properties(tabs):
     """BASELINE configs[2] size (8 ch x 2^22 samples, 1/3 octave, device resident) through size-independent
     properties: exact linearity in amplitude, streaming == batch (state and smoothed energies carried
