@@ -20,6 +20,9 @@
 #ifndef FRT_BIG_DMA_MIN_LOG2M    // smallest log2(N/2) whose aligned launches take the LDS-staged instance
 #define FRT_BIG_DMA_MIN_LOG2M 11
 #endif
+#ifndef FRT_BIG_UNROLL_ROUNDS    // 1: both rounds of sub-transforms as straight-line code (LDS addresses of the second round as immediate offsets: +1-2 %)
+#define FRT_BIG_UNROLL_ROUNDS 1
+#endif
 #ifndef FRT_BIG_ZB              // bin pairs whose Z values are requested together in the unpack (2, 4 or 8)
 #define FRT_BIG_ZB 4
 #endif
@@ -293,7 +296,11 @@ __device__ __forceinline__ void stft_big_body(const StftArgs& a, cpx<T>* __restr
             if (g + 1 < nfr && !((FRT_BIG_ABLATE & 2) && a.n_frames > 0)) stage_frame(f0 + g + 1);
         }
         // ---- 3. sixteen wave-local transforms of length Ms over t, two rounds of eight ----------------------
+#if FRT_BIG_UNROLL_ROUNDS
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
         for (int r = 0; r < ((FRT_BIG_ABLATE & 4) ? (a.n_frames < 0 ? 2 : 0) : 2); ++r) {
             C* buf = reg + (8 * r + sg) * RS;
             C u[8];
