@@ -364,7 +364,7 @@ __device__ __forceinline__ void stft_big_body(const StftArgs& a, cpx<T>* __restr
             const uint32_t tz = (uint32_t)(t + zero), tzh = (uint32_t)(MS - t - zero);
             auto lo_at = [&](auto* base, int q) { return base + q * MS + tz; };                    // bin t + q Ms
             auto hi_at = [&](auto* base, int q) { return base + (M - MS - q * MS) + tzh; };        // bin M - t - q Ms
-            auto finish_store = [&](T* dst, int k, T p, T w) {           // the dB kinds (and the float64 colour index)
+            auto finish_store = [&](T* dst, uint32_t* pdst, int k, T p, T w) {      // the dB kinds (and the float64 colour index)
                 if (NOSTORE && p != (T)-1) return;                // never true for a power: the arithmetic stays
                 if (a.kind == FRT_STFT_IMAGE) {
                     const T vv = clamp_index(image_gain * log2_t(p + (T)1e-30) + w);
@@ -374,7 +374,7 @@ __device__ __forceinline__ void stft_big_body(const StftArgs& a, cpx<T>* __restr
                         const bool near_edge = __builtin_amdgcn_fractf(vv) < a.edge2;
                         if (__any(near_edge)) idx = exact_colour_index(near_edge, p, k, idx, a);
                     }
-                    *(uint32_t*)dst = lut_lds[idx];
+                    *pdst = lut_lds[idx];                            // colour words are 4 bytes whatever T is
                 } else {
                     T vv = db10<T>(p) + w;
                     if (a.kind == FRT_STFT_NORM) vv = (vv + norm_off) * norm_scale;
@@ -469,8 +469,8 @@ __device__ __forceinline__ void stft_big_body(const StftArgs& a, cpx<T>* __restr
                     T plo, phi;
                     if (q > 0 && q % ZB == 0) next_z(q);
                     pair_powers(q, twl[q], plo, phi);
-                    finish_store(lo_at(row, q), t + q * MS, plo, wl[q]);
-                    finish_store(hi_at(row, q), M - t - q * MS, phi, wl[8 + q]);
+                    finish_store(lo_at(row, q), lo_at(prow, q), t + q * MS, plo, wl[q]);
+                    finish_store(hi_at(row, q), hi_at(prow, q), M - t - q * MS, phi, wl[8 + q]);
                 }
             }
             if (t == 0) {
@@ -480,7 +480,7 @@ __device__ __forceinline__ void stft_big_body(const StftArgs& a, cpx<T>* __restr
                 if (a.kind == FRT_STFT_PSD) {
                     if (!NOSTORE) row[M / 2] = pm;
                 } else {
-                    finish_store(row + M / 2, M / 2, pm, wg_nyq);
+                    finish_store(row + M / 2, prow + M / 2, M / 2, pm, wg_nyq);
                 }
             }
         }

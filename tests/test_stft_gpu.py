@@ -133,6 +133,36 @@ def test_large_frame_instances(golden, engine_cls, n_fft):
         assert np.mean(im != images[0]) < 2e-4       # different summation orders move the float32 PSD by an ulp
 
 
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (4096, 1024), (8192, 2048), (16384, 4096), (4096, 2048), (16384, 8192)])
+def test_large_frame_float64_all_kinds(golden, engine_cls, n_fft, hop):
+    """The float64 large-frame instance (drop-in / pitch-tracker path) through every output kind: PSD, dB, normalised and
+    the colour image (4-byte pixels from an 8-byte transform: its own row pitch) against the oracle's float64 chain."""
+    from friture_amd import tables
+    g = golden("image")
+    lut, smin, smax = g["lut"], -140.0, 0.0
+    frames = 7
+    T = n_fft + hop * (frames - 1) + 5
+    x = np.stack([synth("noise", T, 31), synth("chirp", T, 32)]).astype(np.float64)
+    A = tables.weighting_db(tables.rfft_frequencies(n_fft), 1e-50)[0]
+    e = engine_cls(n_fft, hop, 2, 64)
+    e.set_epilogue(A, smin, smax, lut)
+    psd, db, norm, img = e.psd(x), e.db(x), e.norm(x), e.image(x)
+    for c in range(2):
+        ref = dsp.stft_psd(x[c], n_fft, hop)
+        assert psd[c].shape == ref.shape == (frames, n_fft // 2 + 1)
+        assert per_frame_err(psd[c], ref) <= TOL64
+        ref_db = 10.0 * np.log10(ref + 1e-30) + A
+        # bins 60 dB and more below the frame maximum carry the transform's absolute error (1e-16 of the maximum) as a
+        # large relative one: dB and colour of those are ill-conditioned in any arithmetic
+        strong = ref > 1e-6 * ref.max(axis=1, keepdims=True)
+        assert np.max(np.abs(db[c] - ref_db)[strong]) < 1e-8
+        assert np.max(np.abs(norm[c] - (ref_db - smin) / (smax - smin))[strong]) < 1e-10
+        idx, frac = dsp.colour_index(ref, A, smin, smax)
+        differs = img[c] != lut[idx]
+        assert np.mean(differs[strong]) < 1e-4, (c, np.mean(differs[strong]))      # only pixels at an index edge may differ
+        assert np.mean(differs) < 2e-2, (c, np.mean(differs))
+
+
 def test_db_norm_image_against_golden(golden, engine_cls):
     g = golden("image")
     x, A, lut = g["x"], g["weight"], g["lut"]
