@@ -99,12 +99,14 @@ def test_iir_bank_ragged_blocks_and_channels(tabs):
         bank.filter(np.zeros((3, 0)))
 
 
-@pytest.mark.parametrize("chunk", [16384, 4096, 1024, 3072, -2048])
-def test_time_parallel_mode_matches_sequential(tabs, chunk):
+@pytest.mark.parametrize("chunk,extra", [(16384, 0), (4096, 0), (1024, 0), (3072, 0), (-2048, 0), (2048, 3), (1024, 1021)])
+def test_time_parallel_mode_matches_sequential(tabs, chunk, extra):
+    """`extra`: a ragged length — rows of the staged input off the 16-byte grid (the scalar-load branch of the zero-state
+    kernel), a last chunk that is not whole, odd stage lengths down the decimation chain."""
     from friture_amd.filter import IirBank
     bpo = 3
     boct, aoct = list(tabs[f"boct_{bpo}"]), list(tabs[f"aoct_{bpo}"])
-    n = 5 * 16384 + 4096
+    n = 5 * 16384 + 4096 + extra
     x = np.stack([synth("noise", n, 5), synth("tone", n, 6)]).astype(np.float64)
     seq = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, 2)
     par = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, 2)

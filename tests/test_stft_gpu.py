@@ -107,14 +107,17 @@ def test_run_length_invariance(engine_cls):
         assert np.array_equal(o, outs[0])
 
 
+@pytest.mark.parametrize("tail", [3, 8])
 @pytest.mark.parametrize("n_fft", [2048, 4096, 8192, 16384])
-def test_large_frame_instances(golden, engine_cls, n_fft):
+def test_large_frame_instances(golden, engine_cls, n_fft, tail):
     """N >= 2048 has two instances of K1: the radix-16 + wave-local one (stft_big.h, the default) and the
     generic workgroup Stockham walk (selected by a negative run length).  Both must sit inside the
     tolerance of the oracle whatever the run length, and colour the same pixels up to LUT bin edges."""
     hop = n_fft // 2
     frames = 23
-    T = n_fft + hop * (frames - 1) + 3
+    # tail 3: channel rows off the 16-byte grid (register-prefetch / direct-load instances); tail 8: rows on it (the
+    # instances that stage the next frame in LDS, N >= 4096)
+    T = n_fft + hop * (frames - 1) + tail
     x = np.stack([synth("noise", T, 5), synth("chirp", T, 6)])
     ref = [dsp.stft_psd(x[c].astype(np.float64), n_fft, hop) for c in range(2)]
     g = golden("image")
@@ -128,9 +131,14 @@ def test_large_frame_instances(golden, engine_cls, n_fft):
         got = e.psd(x)
         for c in range(2):
             assert per_frame_err(got[c], ref[c]) <= TOL32, (run, c)
-        images.append(e.image(x))
+        img = e.image(x)
+        for c in range(2):
+            # the instance's pixels are exactly what the reference's float64 epilogue assigns to the instance's own PSD
+            rep = dsp.image_parity(img[c], got[c], None, A, -140.0, 0.0, g["lut"])
+            assert rep["epilogue_mismatch_outside_edge"] == 0 and rep["epilogue_mismatched"] <= 3, (run, c, rep)
+        images.append(img)
     for im in images[1:]:
-        assert np.mean(im != images[0]) < 2e-4       # different summation orders move the float32 PSD by an ulp
+        assert np.mean(im != images[0]) < 1e-3       # different summation orders move the float32 PSD by an ulp
 
 
 @pytest.mark.parametrize("n_fft,hop", [(2048, 512), (4096, 1024), (8192, 2048), (16384, 4096), (4096, 2048), (16384, 8192)])
