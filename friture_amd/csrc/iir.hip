@@ -1049,15 +1049,18 @@ static int ensure_powers(frt_octbank* h, int n) {
                 for (int i = 0; i < d * d; ++i) A[i] = (long double)AL[i];
                 std::fill(R.begin(), R.end(), 0.0L);
                 for (int i = 0; i < d; ++i) R[i * d + i] = 1.0L;
+                const int ord = h->h_order[f];                       // everything outside the leading ord x ord block is zero
                 for (int i = 0; i < group; ++i) {
                     double* dst = &gp[h->gpow_offset[j] + ((size_t)f * group + i) * kStates * kStates];
                     for (int e = 0; e < d * d; ++e) dst[e] = (double)R[e];
-                    for (int r = 0; r < d; ++r)
-                        for (int c2 = 0; c2 < d; ++c2) {
+                    std::fill(T.begin(), T.end(), 0.0L);
+                    for (int r = 0; r < ord; ++r)
+                        for (int c2 = 0; c2 < ord; ++c2) {
                             long double acc = 0;
-                            for (int k = 0; k < d; ++k) acc += A[r * d + k] * R[k * d + c2];
+                            for (int k = 0; k < ord; ++k) acc += A[r * d + k] * R[k * d + c2];
                             T[r * d + c2] = acc;
                         }
+                    for (int r = ord; r < d; ++r) T[r * d + r] = 0.0L;
                     R = T;
                 }
             }
