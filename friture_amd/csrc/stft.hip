@@ -123,11 +123,26 @@ __device__ __forceinline__ void stream_store(T* p, T v) {
 #ifndef FRT_WAVE_MIN_WAVES
 #define FRT_WAVE_MIN_WAVES 3
 #endif
+// SHIFT = -1: the RING instance (float32, hop = N/2, one wavefront per frame, 16-byte aligned rows).  The frame's samples
+// do not live in a register window: each wavefront owns a ring of two half-frames in LDS, the half-frame that the frame
+// after next needs is copied there from HBM by an LDS-DMA issued from inline assembly (stft_big.h explains why) as soon as
+// the window multiply has read the half it replaces, and the window multiply reads its eight slots with ds_read_b64.
+// Measured: +4 % (PSD) / +2.5 % (image) at three waves per SIMD (139 VGPRs); at four waves (128 VGPRs, 20-36 bytes of spills,
+// whose scratch traffic also counts against the hand-placed vmcnt) 4 % slower than the register-window instance.
+#ifndef FRT_RING_MIN_WAVES
+#define FRT_RING_MIN_WAVES 3
+#endif
+#ifndef FRT_RING_HALVES          // half-frames in a wavefront's ring: 2 (the copy has one frame to land) or 3 (two frames)
+#define FRT_RING_HALVES 2
+#endif
+#ifndef FRT_RING_WEIGHTS_IN_LDS
+#define FRT_RING_WEIGHTS_IN_LDS 0
+#endif
 template <typename TIN, typename T, int LOG2M, int SHIFT>
 __global__ void
 #if defined(FRT_WAVE_MIN_WAVES)
 __launch_bounds__((Pow2Plan<LOG2M>::TPF < 256 ? 256 : Pow2Plan<LOG2M>::TPF),
-                  (Pow2Plan<LOG2M>::TPF <= 64 ? FRT_WAVE_MIN_WAVES : 1))
+                  (Pow2Plan<LOG2M>::TPF <= 64 ? (SHIFT < 0 ? FRT_RING_MIN_WAVES : FRT_WAVE_MIN_WAVES) : 1))
 #else
 __launch_bounds__((Pow2Plan<LOG2M>::TPF < 256 ? 256 : Pow2Plan<LOG2M>::TPF))
 #endif
@@ -140,8 +155,14 @@ stft_kernel(const StftArgs a) {
     using C = cpx<T>;
     using CIN = cpx<TIN>;
 
+    constexpr bool RING = SHIFT < 0;
+    static_assert(!RING || (TPF == 64 && sizeof(T) == 4 && sizeof(TIN) == 4), "ring instance: one wavefront per float32 frame");
     __shared__ C lds[GPB * lds_padded_size(M)];
     __shared__ uint32_t lut_lds[256];                // colour words: gathered per bin, keep them on-chip
+    constexpr int NH = FRT_RING_HALVES;
+    __shared__ __attribute__((aligned(16))) C ring_lds[RING ? GPB * NH * (M / 2) : 1];      // per lane group: NH half-frames of M/2 complex
+    constexpr bool WLDS = RING && FRT_RING_WEIGHTS_IN_LDS;                       // dB / colour-index offsets read from LDS per frame
+    __shared__ T wgt_lds[WLDS ? M + 1 : 1];                                      // instead of nine registers held for the run
 
     const int tid = threadIdx.x;
     const int grp = tid / TPF;
@@ -160,6 +181,11 @@ stft_kernel(const StftArgs a) {
 
     if (a.kind == FRT_STFT_IMAGE) {
         for (int t = threadIdx.x; t < 256; t += BLOCK) lut_lds[t] = a.lut[t];
+        __syncthreads();
+    }
+    if constexpr (WLDS) {
+        const T* wsrc = (const T*)(a.kind == FRT_STFT_IMAGE ? a.wimage : a.weight);
+        for (int t = threadIdx.x; t <= M; t += BLOCK) wgt_lds[t] = wsrc ? wsrc[t] : (T)0;
         __syncthreads();
     }
 
@@ -191,12 +217,16 @@ stft_kernel(const StftArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                 // bins i + j TPF and M - i - j TPF (see the unpack)
             twu[j] = twn[i + j * TPF];
-            wdb[j] = wgt ? wgt[i + j * TPF] : (T)0;
-            wdb[4 + j] = wgt ? wgt[M - i - j * TPF] : (T)0;
+            if constexpr (!WLDS) {
+                wdb[j] = wgt ? wgt[i + j * TPF] : (T)0;
+                wdb[4 + j] = wgt ? wgt[M - i - j * TPF] : (T)0;
+            }
         }
         twr.load((const C*)a.tw, i);
     }
-    if (wgt) wdb_mid = wgt[M / 2];
+    if constexpr (!WLDS) {
+        if (wgt) wdb_mid = wgt[M / 2];
+    }
 
     const T norm_off = (T)a.norm_off, norm_scale = (T)a.norm_scale;
 
@@ -220,14 +250,42 @@ stft_kernel(const StftArgs a) {
     // frame loop is unrolled NSETS times with the roles as compile-time constants, the set holding the oldest block is
     // refilled as soon as the window multiply has read it, and no register is ever copied (the copies were 16 of the
     // ~600 instructions a frame issues).
-    constexpr int NEW = SHIFT == 0 ? 8 : SHIFT;       // slots fetched per frame
-    constexpr int NSETS = 8 / NEW;
-    C raw[8];
+    constexpr int NEW = RING ? 4 : SHIFT == 0 ? 8 : SHIFT;       // slots fetched per frame
+    constexpr int NSETS = RING ? NH : 8 / NEW;
+    C raw[RING ? 1 : 8];
+    C* ring = ring_lds + (RING ? grp * NH * (M / 2) : 0);         // half-frame h of the run in slot h mod NH
+    // half-frame h of the run (samples [h hop, (h + 1) hop) from the run's first frame) -> ring slot h mod NH: two wave-wide
+    // 16-byte copies of 1 KB each
+    auto ring_fetch = [&](long long h) {
+        if constexpr (RING) {
+            const char* src = (const char*)(xc + (f0 + h) * a.hop);
+            const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(ring + (int)(h % NH) * (M / 2));
+            const uint32_t lane16 = (uint32_t)i * 16;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) raw[j] = {(T)0, (T)0};
-    if (nfr > 0) {
+            for (int part = 0; part < (int)(M * sizeof(T)) / 1024; ++part) {
+                const unsigned long long ub = (unsigned long long)(src + part * 1024);
+                const unsigned long long sb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ub >> 32)) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ub);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :
+                             : "v"(lane16), "s"(sb), "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)(dst + part * 1024)))
+                             : "memory", "m0");
+            }
+        }
+    };
+    if constexpr (RING) {
+        if (nfr > 0) {
+            ring_fetch(0);
+            ring_fetch(1);
+            if (NH > 2 && nfr > 1) ring_fetch(2);
+        }
+    } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) raw[j] = load_slot(f0, j);
+        for (int j = 0; j < 8; ++j) raw[j] = {(T)0, (T)0};
+        if (nfr > 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) raw[j] = load_slot(f0, j);
+        }
     }
 
     // Drain the one-off loads (tables, first frame) here.  Without this the compiler's s_waitcnt
@@ -249,6 +307,19 @@ stft_kernel(const StftArgs a) {
 
         int zero = 0;
         if constexpr (!HOIST) asm volatile("s_mov_b32 %0, 0" : "=s"(zero));   // opaque per iteration
+        // RING: the copy this frame's second half arrives by was issued a frame ago, in front of that frame's nine row
+        // stores — the only younger vector-memory operations (the counter retires in order): at most nine outstanding
+        // means the copy has landed.  (The first frame's two copies are drained before the loop.)
+        if constexpr (RING) {
+            if constexpr (NH == 2) {
+                __builtin_amdgcn_s_waitcnt(0x0F79);          // vmcnt(9), other counters untouched
+            } else {
+                // three halves: the copy was issued two frames ago; younger are two frames' stores and, if the previous
+                // frame issued one, its copy (2 instructions)
+                if (g + 1 < nfr) __builtin_amdgcn_s_waitcnt(0x4F74);      // vmcnt(20)
+                else __builtin_amdgcn_s_waitcnt(0x4F72);                  // vmcnt(18)
+            }
+        }
 
         C v[8];
 #pragma unroll
@@ -259,9 +330,18 @@ stft_kernel(const StftArgs a) {
             } else {
                 wj = ((const C*)wtab)[i + j * TPF + zero];
             }
-            const C r = raw[((j / NEW + PH) % NSETS) * NEW + j % NEW];      // logical slot j of this frame
+            C r;
+            if constexpr (RING) r = ring[((j / 4 + PH) % NH) * (M / 2) + i + (j & 3) * TPF];     // first half: slot PH, second: the next
+            else r = raw[((j / NEW + PH) % NSETS) * NEW + j % NEW];      // logical slot j of this frame
             v[j] = {r.x * wj.x, r.y * wj.y};
         }
+        if constexpr (RING) {
+            // the products exist (the eight LDS reads have returned): the first half's slot is free for half-frame g + 2,
+            // which frame g + 1 reads a whole transform from now
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v[j].x), "+v"(v[j].y));
+            if (g + NH - 1 < nfr) ring_fetch((long long)g + NH);
+        } else {
         // The set that held the oldest block has been read: request the next frame's new slots into it now, a whole
         // transform ahead of their use.
         // (Unconditional, with the frame index clamped to the run's last frame: a conditional refill makes every slot a
@@ -279,6 +359,7 @@ stft_kernel(const StftArgs a) {
         } else if (g + 1 < nfr) {       // a hop that reloads the whole frame: the redundant request would be a whole frame
 #pragma unroll
             for (int t = 0; t < 8; ++t) raw[t] = load_slot(f0 + g + 1, t);
+        }
         }
 
 #ifdef FRT_ABLATE
@@ -345,8 +426,10 @@ stft_kernel(const StftArgs a) {
         // The prefetched slots are waited for HERE, in front of this frame's stores: the vector-memory counter retires in
         // order, so a first use behind the stores (the next frame's window multiply) could only be guarded by vmcnt(0) —
         // the acknowledgement of every row store.  The empty asm makes the loaded values a use at this point.
+        if constexpr (!RING) {
 #pragma unroll
-        for (int t = 0; t < NEW; ++t) asm volatile("" : "+v"(raw[PH * NEW + t].x), "+v"(raw[PH * NEW + t].y));
+            for (int t = 0; t < NEW; ++t) asm volatile("" : "+v"(raw[PH * NEW + t].x), "+v"(raw[PH * NEW + t].y));
+        }
 
 #ifdef FRT_ABLATE
         if (a.ablate & 1) {
@@ -374,7 +457,10 @@ stft_kernel(const StftArgs a) {
                 T wl[4], wh[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if constexpr (HOIST) {
+                    if constexpr (WLDS) {
+                        wl[j] = wgt_lds[klo + j * TPF];
+                        wh[j] = wgt_lds[khi - j * TPF];
+                    } else if constexpr (HOIST) {
                         wl[j] = wdb[j];
                         wh[j] = wdb[4 + j];
                     } else {
@@ -382,6 +468,7 @@ stft_kernel(const StftArgs a) {
                         wh[j] = wgt ? wgt[khi - j * TPF + zero] : (T)0;
                     }
                 }
+                if constexpr (WLDS) wdb_mid = wgt_lds[M / 2];
                 if (a.kind == FRT_STFT_IMAGE) {
                     // colour words are 4 bytes whatever the arithmetic type
                     uint32_t* prow = (uint32_t*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
@@ -478,7 +565,9 @@ stft_kernel(const StftArgs a) {
         }
         if constexpr (NSETS > 2) {
             if (!frame(std::integral_constant<int, 2>{}, g + 2)) break;
-            if (!frame(std::integral_constant<int, 3>{}, g + 3)) break;
+            if constexpr (NSETS > 3) {
+                if (!frame(std::integral_constant<int, 3>{}, g + 3)) break;
+            }
         }
     }
 }
@@ -533,6 +622,10 @@ static int launch_one(const StftArgs& a, int blocks, hipStream_t stream) {
 
 template <typename TIN, typename T, int LOG2M>
 static int launch_shift(const StftArgs& a, int shift, int blocks, hipStream_t stream) {
+    if constexpr (sizeof(T) == 4 && LOG2M == 9) {
+        if (shift == -1) return launch_one<TIN, T, LOG2M, -1>(a, blocks, stream);
+    }
+    if (shift < 0) shift = 4;
     if constexpr (sizeof(T) == 4) {
         if (shift == 2) return launch_one<TIN, T, LOG2M, 2>(a, blocks, stream);
         if (shift == 4) return launch_one<TIN, T, LOG2M, 4>(a, blocks, stream);
@@ -773,6 +866,14 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
         const int s = h->hop * 8 / N;
         if (s == 2 || s == 4) shift = s;
     }
+    // N = 1024, hop 512, rows on 16-byte boundaries: the ring instance (samples through a per-wavefront LDS ring filled by LDS-DMA)
+    static const bool no_ring = getenv("FRT_STFT_NO_RING") != nullptr;       // A/B runs: the register-window instance
+    // (PSD / dB kinds: +4 % over the register window, 60-61 % of HBM peak; the colour kind, whose epilogue adds its own LDS
+    // gathers, measures equal or 0.5 % behind and keeps the register window unless FRT_STFT_RING_IMAGE is set)
+    static const bool ring_image = getenv("FRT_STFT_RING_IMAGE") != nullptr;
+    if (shift == 4 && h->log2m == 9 && h->precision == 32 && ((uintptr_t)d_x % 16 == 0) && (x_stride % 4 == 0) && !no_ring &&
+        (kind != FRT_STFT_IMAGE || ring_image))
+        shift = -1;
     const int tpf = M / 8;
     const int gpb = tpf < 256 ? 256 / tpf : 1;
     // run length: enough lane groups to fill the chip several times over, long enough to amortise
