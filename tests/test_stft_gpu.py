@@ -107,6 +107,33 @@ def test_run_length_invariance(engine_cls):
         assert np.array_equal(o, outs[0])
 
 
+@pytest.mark.parametrize("frames", [1, 2, 3, 17, 64])
+def test_ring_instance_of_the_headline_size(engine_cls, frames):
+    """N = 1024, hop 512, channel rows on 16-byte boundaries: the PSD / dB kinds take their samples through a per-wavefront
+    LDS ring filled by LDS-DMA (stft.hip, SHIFT = -1).  Every run length — a run's first two half-frames are fetched up
+    front, the rest one frame ahead, the last frame fetches nothing — must give the oracle's spectra, and the same bits as
+    each other (the arithmetic does not depend on where a run starts)."""
+    n_fft, hop = 1024, 512
+    T = n_fft + hop * (frames - 1) + 4                       # a multiple of 4: rows stay aligned for every channel
+    x = np.stack([synth("noise", T, 41), synth("chirp", T, 42), synth("tone", T, 43)])
+    ref = [dsp.stft_psd(x[c].astype(np.float64), n_fft, hop) for c in range(3)]
+    first = None
+    for run in (0, 1, 2, 3, 8, 64):
+        e = engine_cls(n_fft, hop, 3, 32)
+        e.set_run_length(run)
+        got = e.psd(x)
+        assert got.shape == (3, frames, n_fft // 2 + 1)
+        for c in range(3):
+            assert per_frame_err(got[c], ref[c]) <= TOL32, (run, c)
+        if first is None:
+            first = got
+        else:
+            assert np.array_equal(got, first), run
+        db = e.db(x)
+        strong = np.stack(ref) > 1e-6 * np.stack(ref).max(axis=2, keepdims=True)
+        assert np.max(np.abs(db - 10.0 * np.log10(np.stack(ref) + 1e-30))[strong]) < 1e-3
+
+
 @pytest.mark.parametrize("tail", [3, 8])
 @pytest.mark.parametrize("n_fft", [2048, 4096, 8192, 16384])
 def test_large_frame_instances(golden, engine_cls, n_fft, tail):
