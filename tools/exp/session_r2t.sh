@@ -1,12 +1,11 @@
 #!/bin/bash
 export FRT_BENCH_SETS=4
 B=tools/bin/stft_selftest
-LD_LIBRARY_PATH=$PWD/tools/variants/ringh3:$LD_LIBRARY_PATH timeout 300 $B check 2>&1 | grep -v "^ok" | tail -3
+for rep in 1 2 3 4 5 6; do
+  echo -n "window img: "; FRT_STFT_NO_RING=1 $B bench 1024 512 1 26 3 0 100 | tail -1 | cut -c60-100
+  echo -n "ring   img: "; FRT_STFT_RING_IMAGE=1 $B bench 1024 512 1 26 3 0 100 | tail -1 | cut -c60-100
+done
 for rep in 1 2 3; do
-  echo -n "ring2 psd: "; $B bench 1024 512 1 26 0 0 50 | tail -1 | cut -c60-130
-  echo -n "ring2 img: "; $B bench 1024 512 1 26 3 0 50 | tail -1 | cut -c60-130
-  echo -n "ring3h psd: "; LD_LIBRARY_PATH=$PWD/tools/variants/ringh3:$LD_LIBRARY_PATH $B bench 1024 512 1 26 0 0 50 | tail -1 | cut -c60-130
-  echo -n "ring3h img: "; LD_LIBRARY_PATH=$PWD/tools/variants/ringh3:$LD_LIBRARY_PATH $B bench 1024 512 1 26 3 0 50 | tail -1 | cut -c60-130
-  echo -n "window psd: "; FRT_STFT_NO_RING=1 $B bench 1024 512 1 26 0 0 50 | tail -1 | cut -c60-130
-  echo -n "window img: "; FRT_STFT_NO_RING=1 $B bench 1024 512 1 26 3 0 50 | tail -1 | cut -c60-130
+FRT_STFT_NO_RING=1 python bench.py --steps 50 --warmup 5 --cpu-budget 0 --no-legs 2>/dev/null | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('bench window', r['roofline']['kernel_ms_repeats'])"
+FRT_STFT_RING_IMAGE=1 python bench.py --steps 50 --warmup 5 --cpu-budget 0 --no-legs 2>/dev/null | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('bench ring  ', r['roofline']['kernel_ms_repeats'])"
 done
