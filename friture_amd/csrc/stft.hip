@@ -331,15 +331,20 @@ stft_kernel(const StftArgs a) {
                 wj = ((const C*)wtab)[i + j * TPF + zero];
             }
             C r;
-            if constexpr (RING) r = ring[((j / 4 + PH) % NH) * (M / 2) + i + (j & 3) * TPF];     // first half: slot PH, second: the next
-            else r = raw[((j / NEW + PH) % NSETS) * NEW + j % NEW];      // logical slot j of this frame
+            if constexpr (RING) {
+                r = ring[((j / 4 + PH) % NH) * (M / 2) + i + (j & 3) * TPF];     // first half: slot PH, second: the next
+                // the sample itself is pinned, not the product: the multiply stays free to fuse into the first butterfly
+                // exactly as in the register-window instance (the two instances give bit-identical spectra)
+                asm volatile("" : "+v"(r.x), "+v"(r.y));
+            } else {
+                r = raw[((j / NEW + PH) % NSETS) * NEW + j % NEW];      // logical slot j of this frame
+            }
             v[j] = {r.x * wj.x, r.y * wj.y};
         }
         if constexpr (RING) {
-            // the products exist (the eight LDS reads have returned): the first half's slot is free for half-frame g + 2,
-            // which frame g + 1 reads a whole transform from now
-#pragma unroll
-            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v[j].x), "+v"(v[j].y));
+            // the eight LDS reads have returned (their values are pinned above): the first half's slot is free for
+            // half-frame g + NH, which a later frame reads at least a whole transform from now
+            asm volatile("" ::: "memory");
             if (g + NH - 1 < nfr) ring_fetch((long long)g + NH);
         } else {
         // The set that held the oldest block has been read: request the next frame's new slots into it now, a whole

@@ -134,6 +134,28 @@ def test_ring_instance_of_the_headline_size(engine_cls, frames):
         assert np.max(np.abs(db - 10.0 * np.log10(np.stack(ref) + 1e-30))[strong]) < 1e-3
 
 
+def test_ring_and_register_window_instances_give_the_same_bits(engine_cls):
+    """The colour kind keeps the register-window instance while the PSD kinds take the LDS ring: `bench.py` checks the
+    image against the reference epilogue applied to the PSD of the same batch, so the two instances must agree bit for
+    bit.  The window instance is reached with a device row that starts off the 16-byte grid."""
+    import torch
+    n_fft, hop, frames = 1024, 512, 41
+    T = n_fft + hop * (frames - 1)
+    host = synth("noise", T + 4, 51) + 0.3 * synth("chirp", T + 4, 52)
+    buf = torch.from_numpy(host.astype(np.float32)).cuda()
+    e = engine_cls(n_fft, hop, 1, 32)
+    aligned = buf[:T].reshape(1, T).contiguous()                   # ring instance
+    shifted = buf[1:T + 1].reshape(1, T)                           # starts 4 bytes off: register-window instance
+    assert shifted.data_ptr() % 16 != 0 and aligned.data_ptr() % 16 == 0
+    same = shifted.clone().contiguous()                            # the shifted samples on the grid: ring instance again
+    assert same.data_ptr() % 16 == 0
+    p_window = e.psd(shifted).cpu().numpy()
+    p_ring = e.psd(same).cpu().numpy()
+    assert np.array_equal(p_window, p_ring)
+    assert np.array_equal(e.db(shifted).cpu().numpy(), e.db(same).cpu().numpy())
+    assert e.psd(aligned).shape == (1, frames, n_fft // 2 + 1)
+
+
 @pytest.mark.parametrize("tail", [3, 8])
 @pytest.mark.parametrize("n_fft", [2048, 4096, 8192, 16384])
 def test_large_frame_instances(golden, engine_cls, n_fft, tail):
