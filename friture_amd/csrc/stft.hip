@@ -127,8 +127,9 @@ __device__ __forceinline__ void stream_store(T* p, T v) {
 // do not live in a register window: each wavefront owns a ring of two half-frames in LDS, the half-frame that the frame
 // after next needs is copied there from HBM by an LDS-DMA issued from inline assembly (stft_big.h explains why) as soon as
 // the window multiply has read the half it replaces, and the window multiply reads its eight slots with ds_read_b64.
-// Measured: +4 % (PSD) / +2.5 % (image) at three waves per SIMD (139 VGPRs); at four waves (128 VGPRs, 20-36 bytes of spills,
-// whose scratch traffic also counts against the hand-placed vmcnt) 4 % slower than the register-window instance.
+// Measured at three waves per SIMD (139 VGPRs): PSD kind +1.5 ... +4 % depending on the session, colour kind equal to 0.7 %
+// behind (its VALU pipe is 97 % busy either way; it keeps the register window).  At four waves (128 VGPRs, 20-36 bytes of
+// spills, whose scratch traffic also counts against the hand-placed vmcnt) 4 % slower than the register-window instance.
 #ifndef FRT_RING_MIN_WAVES
 #define FRT_RING_MIN_WAVES 3
 #endif
