@@ -58,10 +58,15 @@ def synth_channel(channel: int, n: int) -> np.ndarray:
 
 
 def kernel_source_digest() -> str:
-    """Digest of the K1 kernel sources: a PMC traffic figure is only quoted for the sources it was measured on."""
+    """Digest of the K1 kernel sources — their code, i.e. with comments and blank lines removed: a PMC traffic figure is
+    only quoted for the code it was measured on (rewording a comment does not un-measure it)."""
+    import re
     h = hashlib.sha256()
     for name in ("stft.hip", "stft_big.h", "fft_core.h"):
-        h.update((ROOT / "friture_amd" / "csrc" / name).read_bytes())
+        text = (ROOT / "friture_amd" / "csrc" / name).read_text()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        lines = [re.sub(r"//[^\n]*", "", ln).rstrip() for ln in text.splitlines()]
+        h.update("\n".join(ln for ln in lines if ln.strip()).encode())
     return h.hexdigest()[:16]
 
 
