@@ -479,7 +479,7 @@ def main():
         if psd_ms is not None:
             result["psd_output"] = {"kernel_ms": psd_ms, "spectra_per_s": spectra_per_step / (psd_ms * 1e-3),
                                     "frac_of_hbm_peak": bytes_per_launch / (psd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "note": "same launches writing the float PSD instead of colour pixels (same byte counts)"}
+                                    "note": "same batches, float PSD written instead of colour pixels (same byte counts); on aligned rows this kind runs the LDS-ring instance of the kernel, the colour kind the register-window instance — bit-identical spectra"}
         if same_batch_ms is not None:
             result["same_batch"] = {"kernel_ms": same_batch_ms, "spectra_per_s": spectra_per_step / (same_batch_ms * 1e-3) / 1.0,
                                     "note": "the same batch every step (what a naive loop measures); not the headline"}
