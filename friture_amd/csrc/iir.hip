@@ -37,6 +37,9 @@
 namespace frt {
 
 
+#ifndef FRT_IIR_VEC_OUT             // 16-byte stores of the decimated output (measured: no gain over the per-sample stores)
+#define FRT_IIR_VEC_OUT 0
+#endif
 constexpr int kScanRowsDecl = 32;   // = kScanRows (iir_scan_kernel, below)
 
 struct IirStageArgs {
@@ -76,6 +79,8 @@ struct IirStageArgs {
     int dec_lanes;             // lanes per slot of the decimator's mode (16 or 4), 0 without a decimator
     int row_filter[kMaxFilters];
     int quad_filter[kMaxFilters];
+    int vec_x;                      // stage input rows on 16-byte boundaries: vector loads of whole sample groups
+    int vec_xnext;                  // likewise the decimated output rows
     int row_energy, quad_energy;    // does any filter of the class feed a band energy?  (the decimator does not: its wavefronts,
                                     // more than half of a 1/3-octave stage, skip the two energy instructions per sample)
 };
@@ -228,13 +233,35 @@ __device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long 
         const long long base = start + g0;
         const long long left = stop - base;
         const int cnt = left >= 64 ? 64 : (left > 0 ? (int)left : 0);
-        // the LPS lanes of a slot fetch its 64 samples
+        // the LPS lanes of a slot fetch its 64 samples: 16-byte loads for a whole group on aligned rows (a quarter / half of
+        // the load, convert and LDS-write instructions — the pass runs at its VALU issue rate, and this prologue was 4 of
+        // its 15.6 instructions per sample), one sample at a time for the ragged end of a channel
+        if (a.vec_x && cnt == 64) {
+            if (a.in_f32) {
+                const float* xp = (const float*)a.x + xrow + base;
 #pragma unroll
-        for (int j = 0; j < SPW; ++j) {
-            const int k = s + LPS * j;
-            double v = 0.0;
-            if (k < cnt) v = a.in_f32 ? (double)((const float*)a.x)[xrow + base + k] : ((const double*)a.x)[xrow + base + k];
-            xy[k] = v;
+                for (int j = 0; j < SPW / 4; ++j) {
+                    const int k = 4 * (s + LPS * j);
+                    const float4 v = *(const float4*)(xp + k);
+                    *(double2*)(xy + k) = double2{(double)v.x, (double)v.y};
+                    *(double2*)(xy + k + 2) = double2{(double)v.z, (double)v.w};
+                }
+            } else {
+                const double* xp = (const double*)a.x + xrow + base;
+#pragma unroll
+                for (int j = 0; j < SPW / 2; ++j) {
+                    const int k = 2 * (s + LPS * j);
+                    *(double2*)(xy + k) = *(const double2*)(xp + k);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SPW; ++j) {
+                const int k = s + LPS * j;
+                double v = 0.0;
+                if (k < cnt) v = a.in_f32 ? (double)((const float*)a.x)[xrow + base + k] : ((const double*)a.x)[xrow + base + k];
+                xy[k] = v;
+            }
         }
         wave_lds_sync();
         if (__all(cnt == 64)) {
@@ -278,10 +305,20 @@ __device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long 
             wave_lds_sync();
             if (is_dec) {
                 if (write_dec) {
+                    double* xn = a.xnext + (long long)c * a.xnext_stride + (base >> 1);       // base is a multiple of 64
+                    if (FRT_IIR_VEC_OUT && a.vec_xnext && cnt == 64) {
+                        // a whole group: the 32 even samples as 16-byte stores of two, dealt to the slot's lanes
 #pragma unroll
-                    for (int j = 0; j < SPW; ++j) {
-                        const int k = s + LPS * j;
-                        if (!(k & 1) && k < cnt) a.xnext[(long long)c * a.xnext_stride + ((base + k) >> 1)] = xy[k];
+                        for (int j = 0; j < (SPW + 3) / 4; ++j) {
+                            const int m = 2 * (s + LPS * j);                                      // decimated index of the pair
+                            if (m < 32) *(double2*)(xn + m) = double2{xy[2 * m], xy[2 * m + 2]};
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < SPW; ++j) {
+                            const int k = s + LPS * j;
+                            if (!(k & 1) && k < cnt) xn[k >> 1] = xy[k];
+                        }
                     }
                 }
             } else if (write_y) {
@@ -304,7 +341,7 @@ __device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long 
 
 // grid.x = waves of 16-lane-row slots (filters of order > 4: the decimator) followed by waves of quad slots.
 __global__ void __launch_bounds__(64) iir_stage_kernel(const IirStageArgs a) {
-    __shared__ double lds[16 * 64];
+    __shared__ __attribute__((aligned(16))) double lds[16 * 64];
     if ((int)blockIdx.x < a.waves_row) iir_stage_body<16>(a, blockIdx.x, lds);
     else iir_stage_body<4>(a, (long long)blockIdx.x - a.waves_row, lds);
 }
@@ -314,6 +351,8 @@ static int launch_iir_stage(IirStageArgs a, const int* orders, int n_channels, h
     a.n_channels = n_channels;
     a.n_row = a.n_quad = 0;
     a.dec_lanes = 0;
+    a.vec_x = ((uintptr_t)a.x % 16 == 0) && (a.x_stride % (a.in_f32 ? 4 : 2) == 0);
+    a.vec_xnext = a.xnext && ((uintptr_t)a.xnext % 16 == 0) && (a.xnext_stride % 2 == 0);
     a.row_energy = a.quad_energy = 0;
     for (int f = 0; f < a.nfilt; ++f) {
         if (orders[f] > 4) {
