@@ -154,7 +154,8 @@ __device__ __forceinline__ void iir_samples(int k0, int count, double* xy, doubl
 #pragma unroll 4
     for (int k = k0; k < k0 + count; ++k) {
         const double y = iir_step<LPS>(xy[k], b0, bn, an, keep, z);
-        if (ENERGY) acc = acc * decay + y * y;     // zero-state block energy, Horner form (exp_smoothing.py:40-56)
+        if (ENERGY) acc = __builtin_fma(acc, decay, y * y);     // zero-state block energy, Horner form (exp_smoothing.py:40-56); fused: the
+                                                                // energies are held to 1e-5, and the pass is instruction-issue bound
         if (KEEP) xy[k] = y;                       // every lane of the group writes the same value to the same slot
     }
 }
@@ -293,7 +294,7 @@ __device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long 
                 z = on ? zt : z;
                 if (energy) {
                     if (((g0 + k) & (elen - 1)) == 0) acc = 0.0;
-                    const double at = acc * decay + y * y;
+                    const double at = __builtin_fma(acc, decay, y * y);
                     acc = on ? at : acc;
                     if (my_energy && on && ((g0 + k + 1) & (elen - 1)) == 0)
                         eout[(size_t)((base + k) >> a.eblock_shift) * a.nbands] = alpha * acc;
