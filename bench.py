@@ -186,10 +186,11 @@ def octave_legs(dev, world, rank, ch, bpo, log2n, tag, with_sequential):
     units = world * ch * (n // 1024) * 9 * bpo
     alg_bytes = ch * (n // 1024) * (4096 + 4 * 9 * bpo)
     # recurrence steps of the exact bank: per stage j every channel runs bpo band filters and one decimator over n / 2^j
-    # samples; a wavefront steps 16 band filters (quad slots) or 4 decimators (row slots) with 15 float64 VALU
-    # instructions of 4 issue cycles per sample
-    wave_steps = sum((n >> j) * (-(-ch * bpo // 16) + -(-ch // 4)) for j in range(9))
-    issue_bound_s = wave_steps * 15 * 4 / (SIMDS * MAX_CLOCK_HZ)
+    # samples; a wavefront steps 16 band filters (quad slots: 4 arithmetic + 4 DPP + 2 energy instructions per sample in
+    # the contracted form the energy-only call uses) or 4 decimators (row slots: 3 + 4), 4 issue cycles each
+    quad_waves, row_waves = -(-ch * bpo // 16), -(-ch // 4)
+    wave_instr = sum((n >> j) * (quad_waves * 10 + row_waves * 7) for j in range(9))
+    issue_bound_s = wave_instr * 4 / (SIMDS * MAX_CLOCK_HZ)
     legs = {}
 
     def record(name, bank, steps, mode, extra):
@@ -204,11 +205,13 @@ def octave_legs(dev, world, rank, ch, bpo, log2n, tag, with_sequential):
     chunk = 2048 if bpo <= 3 else 4096
     iir.set_chunk(chunk)
     record("iir_time_parallel", iir, 5,
-           f"exact IIR bank, time-parallel chunks of {chunk} samples: the same recurrences re-associated, 1e-10 of the "
-           f"input scale from the sequential (bit-exact) mode, band energies within 1e-12 (bar 1e-5)",
+           f"exact IIR bank, time-parallel chunks of {chunk} samples: the same recurrences re-associated, the output pass of "
+           f"this energy-only call with contracted multiply-adds; band energies equal to the bit-exact sequential mode's "
+           f"at float32 output precision (1.2e-7; bar 1e-5)",
            lambda dt: {"bound": "f64_valu_issue", "unit": "s", "achieved": dt, "peak": issue_bound_s, "frac": issue_bound_s / dt,
-                       "model": "sum over stages of samples x wavefront slots (16 band filters or 4 decimators per wavefront) x 15 "
-                                "float64 VALU instructions x 4 issue cycles / (1024 SIMDs x 2.4 GHz): the output pass alone; the "
+                       "model": "sum over stages of samples x (quad wavefronts x 10 + row wavefronts x 7 float64 VALU / DPP "
+                                "instructions: 16 band filters or 4 decimators per wavefront) x 4 issue cycles / (1024 SIMDs x "
+                                "2.4 GHz): the arithmetic of the output pass alone, no group fetch, no loop overhead; the "
                                 "time-parallel mode adds the zero-state products and chunk scans on top"})
     if with_sequential:
         seq = IirBank(t["bdec"], t["adec"], list(t[f"boct_{bpo}"]), list(t[f"aoct_{bpo}"]), ch)
