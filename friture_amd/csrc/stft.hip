@@ -59,6 +59,7 @@ struct StftArgs {
 #endif
 };
 
+
 template <typename T> __device__ __forceinline__ T db10(T p);
 template <> __device__ __forceinline__ float db10<float>(float p) {
     // 10*log10(v) = (10/log2(10)) * log2(v); v >= 1e-30 is a normal float, v_log_f32 is exact enough
@@ -112,6 +113,10 @@ template <typename T>
 __device__ __forceinline__ void stream_store(T* p, T v) {
 #ifdef FRT_NT_STORES
     __builtin_nontemporal_store(v, p);
+#elif defined(FRT_STORE_POLICY)          // cache-policy experiments: the bits as assembler text, e.g. -DFRT_STORE_POLICY='"sc1"'
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "");
+    if constexpr (sizeof(T) == 4) asm volatile("global_store_dword %0, %1, off " FRT_STORE_POLICY :: "v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, off " FRT_STORE_POLICY :: "v"(p), "v"(v) : "memory");
 #else
     *p = v;
 #endif
@@ -166,7 +171,10 @@ stft_kernel(const StftArgs a) {
     __shared__ T wgt_lds[WLDS ? M + 1 : 1];                                      // instead of nine registers held for the run
 
     const int tid = threadIdx.x;
-    const int grp = tid / TPF;
+    // a lane group that is a whole wavefront: its index — and with it channel, run, frame range, row and sample bases — is
+    // wave-uniform; said out loud, the compiler keeps that arithmetic (64-bit, ~22 instructions per frame) on the scalar unit
+    // instead of the vector ALUs this kernel is bound by
+    const int grp = TPF == 64 ? __builtin_amdgcn_readfirstlane(tid / TPF) : tid / TPF;
     const int i = tid - grp * TPF;
     C* buf = lds + grp * lds_padded_size(M);
 
@@ -176,8 +184,8 @@ stft_kernel(const StftArgs a) {
     const int chan = ggc / a.runs_per_channel;
     const int run = ggc - chan * a.runs_per_channel;
     const long long f0 = a.frame_base + (long long)run * a.run;
-    long long nfr = a.n_frames - f0;
-    if (nfr > a.run) nfr = a.run;
+    const long long left = a.n_frames - f0;
+    int nfr = left > a.run ? a.run : (int)left;            // frames of this run (32-bit: the loop's compares stay scalar)
     if (!group_ok) nfr = 0;
 
     if (a.kind == FRT_STFT_IMAGE) {
@@ -192,6 +200,8 @@ stft_kernel(const StftArgs a) {
 
     const TIN* xc = (const TIN*)a.x + chan * a.x_stride;
     T* outc = (T*)a.out + chan * a.out_cstride;
+    // complex point of the frame that register slot j of this thread holds before the transform
+    auto point = [&](int j) -> int { return i + j * TPF; };
 
     // ---- per-thread constants ----------------------------------------------------------------
     // One-wave frames (N <= 1024) keep window, twiddles and weights in registers for the whole
@@ -212,7 +222,7 @@ stft_kernel(const StftArgs a) {
     if constexpr (HOIST) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int n = i + j * TPF;
+            const int n = point(j);
             win[j] = {wtab[2 * n], wtab[2 * n + 1]};
         }
 #pragma unroll
@@ -231,18 +241,23 @@ stft_kernel(const StftArgs a) {
 
     const T norm_off = (T)a.norm_off, norm_scale = (T)a.norm_scale;
 
-    auto load_slot = [&](long long f, int j) -> C {
-        const long long s = f * a.hop + 2 * (i + j * TPF);
-        if (a.vec2) {
+    typedef T tv2 __attribute__((ext_vector_type(2)));     // a slot stays ONE 64-bit register pair from the load to the window multiply
+    auto load_slot = [&](long long f, int j) -> tv2 {
+        // frame base (wave-uniform for one-wavefront frames: a scalar pointer) + one 32-bit lane offset + the slot as an
+        // immediate: the load's address costs no vector instruction
+        const TIN* fb = xc + f * a.hop;
+        const unsigned lane_off = 2u * (unsigned)point(0);
+        const int slot_off = 2 * (point(j) - point(0));
+        if (SHIFT != 0 || a.vec2) {         // the shifting instances are only launched on aligned 2-sample loads
 #ifdef FRT_NT_LOADS
             typedef TIN vin2 __attribute__((ext_vector_type(2)));
-            vin2 v = __builtin_nontemporal_load((const vin2*)(xc + s));
+            vin2 v = __builtin_nontemporal_load((const vin2*)(fb + lane_off + slot_off));
 #else
-            CIN v = *(const CIN*)(xc + s);
+            CIN v = *(const CIN*)(fb + lane_off + slot_off);
 #endif
-            return {(T)v.x, (T)v.y};
+            return tv2{(T)v.x, (T)v.y};
         }
-        return {(T)xc[s], (T)xc[s + 1]};
+        return tv2{(T)fb[lane_off + slot_off], (T)fb[lane_off + slot_off + 1]};
     };
 
     // The register window.  A hop advances the frame by NEW of its 8 slots; the other 8 - NEW were loaded for earlier
@@ -253,7 +268,7 @@ stft_kernel(const StftArgs a) {
     // ~600 instructions a frame issues).
     constexpr int NEW = RING ? 4 : SHIFT == 0 ? 8 : SHIFT;       // slots fetched per frame
     constexpr int NSETS = RING ? NH : 8 / NEW;
-    C raw[RING ? 1 : 8];
+    tv2 raw[RING ? 1 : 8];
     C* ring = ring_lds + (RING ? grp * NH * (M / 2) : 0);         // half-frame h of the run in slot h mod NH
     // half-frame h of the run (samples [h hop, (h + 1) hop) from the run's first frame) -> ring slot h mod NH: two wave-wide
     // 16-byte copies of 1 KB each
@@ -282,7 +297,7 @@ stft_kernel(const StftArgs a) {
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) raw[j] = {(T)0, (T)0};
+        for (int j = 0; j < 8; ++j) raw[j] = tv2{(T)0, (T)0};
         if (nfr > 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) raw[j] = load_slot(f0, j);
@@ -333,12 +348,13 @@ stft_kernel(const StftArgs a) {
             }
             C r;
             if constexpr (RING) {
-                r = ring[((j / 4 + PH) % NH) * (M / 2) + i + (j & 3) * TPF];     // first half: slot PH, second: the next
+                r = ring[((j / 4 + PH) % NH) * (M / 2) + point(j & 3)];          // first half: slot PH, second: the next
                 // the sample itself is pinned, not the product: the multiply stays free to fuse into the first butterfly
                 // exactly as in the register-window instance (the two instances give bit-identical spectra)
                 asm volatile("" : "+v"(r.x), "+v"(r.y));
             } else {
-                r = raw[((j / NEW + PH) % NSETS) * NEW + j % NEW];      // logical slot j of this frame
+                const tv2 rr = raw[((j / NEW + PH) % NSETS) * NEW + j % NEW];      // logical slot j of this frame
+                r = {rr[0], rr[1]};
             }
             v[j] = {r.x * wj.x, r.y * wj.y};
         }
@@ -355,7 +371,7 @@ stft_kernel(const StftArgs a) {
         // back-edge — the very moves this scheme removes.  The one redundant request per run re-reads slots this wave
         // fetched a frame ago.)
         if constexpr (NSETS > 1) {
-            long long gn = g + 1 < nfr ? g + 1 : nfr - 1;
+            int gn = g + 1 < nfr ? g + 1 : nfr - 1;
             if (gn < 0) gn = 0;
 #ifdef FRT_ABLATE
             if (a.ablate & 2) gn = 0;
@@ -434,7 +450,7 @@ stft_kernel(const StftArgs a) {
         // the acknowledgement of every row store.  The empty asm makes the loaded values a use at this point.
         if constexpr (!RING) {
 #pragma unroll
-            for (int t = 0; t < NEW; ++t) asm volatile("" : "+v"(raw[PH * NEW + t].x), "+v"(raw[PH * NEW + t].y));
+            for (int t = 0; t < NEW; ++t) asm volatile("" : "+v"(raw[PH * NEW + t]));
         }
 
 #ifdef FRT_ABLATE
