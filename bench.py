@@ -30,7 +30,12 @@ One JSON line is printed by rank 0; besides the contract fields it carries
                 configs[2] 1/3-octave bank 8 ch (exact IIR time-parallel, exact IIR sequential
                 = the bit-exact mode, FIR overlap-add bank), configs[3] 16384-point STFT 32 ch,
                 configs[4] GCC-PHAT 100 window pairs + 1/24-octave bank 8 ch
-  ranks_seen    the ranks an all-gather over the job's process group returned (RCCL on GPUs)
+  ranks_seen    the ranks an all-gather over the job's process group returned (RCCL on GPUs); the job exits non-zero
+                unless they are exactly 0..N-1
+  per_rank      every rank's own wall time per step (min / max / all): what the max-over-ranks hides
+  slab_gather   with --gather-slabs: the optional all-gather of the output slabs, issued asynchronously
+                behind each step and overlapped with the next one; `value` then includes its cost
+Exit status: 0, or 3 when a parity gate of the timed batch fails (the JSON line is printed either way).
 """
 from __future__ import annotations
 
@@ -91,8 +96,11 @@ def cpu_baseline(x: np.ndarray, n_fft: int, hop: int, weight, lut, budget_s: flo
         dsp.spectrogram_image(xs, n_fft, hop, weight, -140.0, 0.0, lut)
     dt = time.perf_counter() - t0
     result = {"value": frames * passes / dt, "unit": "spectra/s", "cores": 1, "kind": "port",
-              "sample": f"{passes} pass(es) over the first {frames} of {frames_total} spectra of channel 0 (same input), "
-                        f"numpy float64 oracle of audioproc.analyzelive + dB + A-weighting + colour LUT, {dt:.1f} s",
+              "sample": f"{passes} pass(es) over the first {frames} of {frames_total} spectra of channel 0 (same input), {dt:.1f} s; "
+                        f"timed code: oracle/dsp.py, the numpy float64 restatement of audioproc.analyzelive + dB + A-weighting + "
+                        f"colour LUT that is bit-exact against the reference (tests/golden) — the reference checkout itself is not "
+                        f"present on this box, hence kind = port; the restatement is the faster of the two (no per-frame Python "
+                        f"object overhead), so this baseline is conservative",
               "host_cpus": os.cpu_count()}
     # every core: one spawned worker per core (workers import numpy + the oracle only, never the GPU runtime)
     try:
@@ -133,6 +141,12 @@ def image_parity_report(eng, x, image, n_fft, hop, weight, lut, frames=4096):
     psd64 = dsp.stft_psd(xs[0].cpu().numpy().astype(np.float64), n_fft, hop)
     rep = dsp.image_parity(img, psd32, psd64, weight, -140.0, 0.0, lut)
     rep["frames_checked"] = frames
+    # the gates: the epilogue exact given its own PSD; every pixel that differs from the float64 reference image explained
+    # by the measured float32 PSD error at that bin (oracle/dsp.py:image_parity); the PSD within the 1e-5 bar
+    rep["gate"] = {"epilogue_exact": rep["epilogue_mismatch_outside_edge"] == 0,
+                   "every_mismatch_accounted": rep["mismatch_unaccounted"] == 0,
+                   "psd_within_1e-5": rep["psd_rel_max"] <= 1e-5}
+    rep["gate"]["pass"] = all(rep["gate"].values())
     rep["note"] = ("epilogue_*: GPU pixels against the reference's float64 dB -> normalise -> index -> LUT applied to the GPU's "
                    "own float32 PSD (exact outside 1e-6 of an index edge); pixels_mismatched: against the float64 reference "
                    "image, i.e. bins the float32 PSD error (psd_rel_max of the frame maximum) carried across an edge")
@@ -192,6 +206,9 @@ def octave_legs(dev, world, rank, ch, bpo, log2n, tag, with_sequential):
     wave_instr = sum((n >> j) * (quad_waves * 10 + row_waves * 7) for j in range(9))
     issue_bound_s = wave_instr * 4 / (SIMDS * MAX_CLOCK_HZ)
     legs = {}
+    # SURVEY.md §8d's algorithmic flops of the bank (mode 0): (2 bpo + 6) biquads x 2044 samples x 9 flop per channel and
+    # 1024-sample block (220.8 kflop at bpo 3, 993 kflop at bpo 24) — the figure every variant is priced against
+    survey_flops = ch * (n // 1024) * (2 * bpo + 6) * 2044 * 9
 
     def record(name, bank, steps, mode, extra):
         dt, ev_ms = leg(lambda k: bank.energies(x, 1024, alphas, out=out), steps, dev, distributed, torch)
@@ -199,7 +216,13 @@ def octave_legs(dev, world, rank, ch, bpo, log2n, tag, with_sequential):
                                  "config": f"{ch} ch/GPU x 2^{log2n} samples @ 48 kHz, {9 * bpo} bands (bpo {bpo}), smoothed "
                                            f"energies per 1024-sample block",
                                  "roofline": dict({"algorithmic_bytes_per_step": alg_bytes,
-                                                   "hbm_frac": alg_bytes / dt / 1e9 / HBM_PEAK_GBS}, **extra(dt))}
+                                                   "hbm_frac": alg_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                                                   "algorithmic_flops_per_step": survey_flops,
+                                                   "f64_tflops": survey_flops / dt / 1e12,
+                                                   "f64_frac": survey_flops / dt / 1e12 / F64_VECTOR_PEAK_TFLOPS,
+                                                   "f64_note": "SURVEY.md §8d flop model of the exact bank ((2 bpo + 6) biquads x 2044 "
+                                                               "samples x 9 flop per channel-block) over this variant's time, against "
+                                                               "the 78.6 TFLOP/s float64 vector peak"}, **extra(dt))}
 
     iir = IirBank(t["bdec"], t["adec"], list(t[f"boct_{bpo}"]), list(t[f"aoct_{bpo}"]), ch)
     chunk = 2048 if bpo <= 3 else 4096
@@ -235,30 +258,81 @@ def octave_legs(dev, world, rank, ch, bpo, log2n, tag, with_sequential):
 
 
 def stft16384_leg(dev, world, rank, consts):
-    """configs[3]: 256-ch batched spectrogram with 16384-point frames, 32 channels per GPU x 2^20 samples, hop N/2."""
+    """configs[3]: 256-ch batched spectrogram with 16384-point frames, 32 channels per GPU x 2^20 samples, at hop N/2 (the
+    overlap BASELINE's byte figure is quoted on) and hop N/4 (75 % overlap, the default of both reference widgets:
+    friture/spectrogram.py:91-93, friture/spectrum.py:66)."""
+    import torch
+
+    from friture_amd import distributed, tables
+    from friture_amd.stft import StftEngine
+    n_fft, ch, T = 16384, 32, 1 << 20
+    weight = tables.weighting_db(tables.rfft_frequencies(n_fft), 1e-50)[0]
+    xs = [torch.from_numpy(np.stack([synth_channel(5000 + 977 * b + rank * ch + c, T) for c in range(ch)])).to(dev) for b in range(3)]
+    legs = {}
+    for hop, tag in ((8192, ""), (4096, "_hop4096")):
+        eng = StftEngine(n_fft, hop, ch, 32)
+        eng.set_epilogue(weight, -140.0, 0.0, consts["lut"])
+        F = eng.frames_for(T)
+        bytes_per_launch = ch * F * (4 * hop + 4 * (n_fft // 2 + 1))
+        for kind, name in ((3, "image"), (0, "psd")):
+            outs = [torch.empty((ch, F, n_fft // 2 + 1), dtype=torch.int32 if kind == 3 else torch.float32, device=dev) for _ in range(3)]
+            dt, ev_ms = leg(lambda k: eng.run(kind, xs[k % 3], outs[k % 3]), 30, dev, distributed, torch)
+            legs[f"configs3_stft16384{tag}_{name}"] = {
+                "value": world * ch * F / dt, "unit": "spectra/s", "ms_per_step": dt * 1e3,
+                "config": f"{ch} ch/GPU x 2^20 samples, N = {n_fft}, hop {hop}, "
+                          f"{'dB + A-weighting + colour LUT -> u32 pixels' if kind == 3 else 'PSD'}, three batches rotated",
+                "roofline": {"bound": "hbm", "kernel": "stft_big_kernel", "unit": "GB/s", "achieved": bytes_per_launch / (ev_ms * 1e-3) / 1e9,
+                             "peak": HBM_PEAK_GBS, "frac": bytes_per_launch / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": ev_ms}}
+            del outs
+        del eng
+    return legs
+
+
+def stft1024_f64_leg(dev, world, rank, consts):
+    """configs[1] at the reference's own precision: float64 samples in (audio promoted at friture/audiobackend.py:466-468),
+    float64 PSD out (friture/audioproc.py:42-50) — 8 * 512 + 8 * 513 = 8200 bytes per spectrum — and the float64 colour kind
+    (u32 pixels out, 6148 bytes per spectrum), whose image must be the float64 reference's image pixel for pixel."""
     import torch
 
     from friture_amd import distributed
     from friture_amd.stft import StftEngine
-    n_fft, hop, ch, T = 16384, 8192, 32, 1 << 20
-    from friture_amd import tables
-    weight = tables.weighting_db(tables.rfft_frequencies(n_fft), 1e-50)[0]
-    xs = [torch.from_numpy(np.stack([synth_channel(5000 + 977 * b + rank * ch + c, T) for c in range(ch)])).to(dev) for b in range(3)]
-    eng = StftEngine(n_fft, hop, ch, 32)
-    eng.set_epilogue(weight, -140.0, 0.0, consts["lut"])
+    from oracle import dsp
+    n_fft, hop, T = 1024, 512, 1 << 25
+    nb = n_fft // 2 + 1
+    xs = [torch.from_numpy(synth_channel(7000 + 131 * b + rank, T).astype(np.float64)[None]).to(dev) for b in range(3)]
+    eng = StftEngine(n_fft, hop, 1, 64)
+    eng.set_epilogue(consts["weight"], -140.0, 0.0, consts["lut"])
     F = eng.frames_for(T)
     legs = {}
-    bytes_per_launch = ch * F * (4 * hop + 4 * (n_fft // 2 + 1))
-    for kind, name in ((3, "image"), (0, "psd")):
-        outs = [torch.empty((ch, F, n_fft // 2 + 1), dtype=torch.int32 if kind == 3 else torch.float32, device=dev) for _ in range(3)]
+    for kind, name, out_bytes in ((0, "psd", 8), (3, "image", 4)):
+        outs = [torch.empty((1, F, nb), dtype=torch.int32 if kind == 3 else torch.float64, device=dev) for _ in range(3)]
         dt, ev_ms = leg(lambda k: eng.run(kind, xs[k % 3], outs[k % 3]), 30, dev, distributed, torch)
-        legs[f"configs3_stft16384_{name}"] = {
-            "value": world * ch * F / dt, "unit": "spectra/s", "ms_per_step": dt * 1e3,
-            "config": f"{ch} ch/GPU x 2^20 samples, N = {n_fft}, hop {hop}, "
-                      f"{'dB + A-weighting + colour LUT -> u32 pixels' if kind == 3 else 'PSD'}, three batches rotated",
-            "roofline": {"bound": "hbm", "kernel": "stft_big_kernel", "unit": "GB/s", "achieved": bytes_per_launch / (ev_ms * 1e-3) / 1e9,
-                         "peak": HBM_PEAK_GBS, "frac": bytes_per_launch / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": ev_ms}}
+        bytes_per_launch = F * (8 * hop + out_bytes * nb)
+        rec = {"value": world * F / dt, "unit": "spectra/s", "ms_per_step": dt * 1e3, "dtype": "f64",
+               "config": f"1 ch/GPU x 2^25 samples, N = {n_fft}, hop {hop}, float64 in, "
+                         f"{'dB + A-weighting + colour LUT -> u32 pixels' if kind == 3 else 'float64 PSD out'}, three batches rotated",
+               "roofline": {"bound": "hbm", "kernel": "stft_kernel<double>", "unit": "GB/s", "achieved": bytes_per_launch / (ev_ms * 1e-3) / 1e9,
+                            "peak": HBM_PEAK_GBS, "frac": bytes_per_launch / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_spectrum": 8 * hop + out_bytes * nb,
+                            "kernel_ms": ev_ms}}
+        if rank == 0:
+            frames = 2048
+            Ts = n_fft + hop * (frames - 1)
+            ref = dsp.stft_psd(xs[0][0, :Ts].cpu().numpy(), n_fft, hop)
+            got = outs[0][0, :frames].cpu().numpy()
+            if kind == 0:
+                err = float(np.max(np.max(np.abs(got - ref), axis=1) / np.max(ref, axis=1)))
+                rec["parity"] = {"frames_checked": frames, "psd_rel_max": err, "gate": {"psd_within_1e-12": err <= 1e-12, "pass": err <= 1e-12}}
+            else:
+                psd_gpu = eng.psd(xs[0][:, :Ts].contiguous())[0].cpu().numpy()
+                rep = dsp.image_parity(got.view(np.uint32), psd_gpu, ref, consts["weight"], -140.0, 0.0, consts["lut"], edge=1e-9)
+                rep["frames_checked"] = frames
+                rep["gate"] = {"epilogue_exact": rep["epilogue_mismatch_outside_edge"] == 0,
+                               "pixel_exact_outside_1e-9_of_an_edge": rep["mismatch_outside_edge"] == 0}
+                rep["gate"]["pass"] = all(rep["gate"].values())
+                rec["parity"] = rep
+        legs[f"configs1_f64_{name}"] = rec
         del outs
     return legs
 
@@ -319,6 +393,9 @@ def main():
     ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed launches before the warm-up steps (GPU clock ramp)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for cpu_baseline (0 = skip)")
     ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--gather-slabs", action="store_true", help="all-gather every step's output slab over the job's process group, "
+                    "asynchronously behind the step and overlapped with the next one (SURVEY.md §8e; optional: nobody needs "
+                    "every channel's slab on every GPU by default)")
     ap.add_argument("--stub-engine", action="store_true", help="tests only: CPU stand-in engine over gloo, see StubEngine")
     args = ap.parse_args()
 
@@ -383,9 +460,19 @@ def main():
     outs = [torch.empty((len(my_channels), F, n_fft // 2 + 1), dtype=torch.int32 if kind == 3 else torch.float32, device=dev)
             for _ in range(nbatch)]
 
+    gather = None
+    if args.gather_slabs:
+        if nbatch < 2:
+            raise SystemExit("--gather-slabs needs --batches >= 2 (a slab is gathered while the next batch is computed)")
+        gather = distributed.SlabGather(outs[0], n_slots=nbatch)
+
     def step(k, rotate=True):
         b = k % nbatch if rotate else 0
+        if gather is not None:
+            gather.wait(b)                        # the previous gather of this buffer has read it
         eng.run(kind, xs[b], outs[b])             # one kernel launch on torch's current stream
+        if gather is not None:
+            gather.start(outs[b], b)              # behind the launch above, beside the next step's
 
     # Clock ramp: after idle the GPU needs tens of milliseconds of continuous work before it runs at its sustained
     # clocks; 55 launches (8 ms) straight after start-up read ~17 % slow.  Pre-warm with the same launches for
@@ -397,9 +484,21 @@ def main():
     # One HIP event pair brackets the K launches on the launch stream (torch's current stream, which the C ABI launches
     # on): average launch duration = elapsed / K.  Repeated three times for the run-to-run spread; `value` is the FIRST.
     wall, kernel_ms = timed(step, args.steps, dev, distributed, torch)
+    if gather is not None:
+        gather.wait_all()
     elapsed = distributed.max_over_ranks(wall, dev)
+    per_rank_wall = distributed.gather_scalars(wall, dev)
     kernel_ms_max = distributed.max_over_ranks(kernel_ms, dev)
     repeats = [kernel_ms_max] + [distributed.max_over_ranks(timed(step, args.steps, dev, distributed, torch)[1], dev) for _ in range(2)]
+    slab_check = None
+    if gather is not None:
+        # every rank's slab arrived: the receive buffer of batch 0 against what each rank holds (first pixel / PSD value of
+        # every channel, compared through the summary gather)
+        got = gather.wait(0)
+        firsts = distributed.gather_channel_summaries(outs[0][:, :1, 0].to(torch.float64), n_channels)
+        slab_check = bool(torch.equal(got.reshape(-1, *outs[0].shape[1:])[:, 0, 0].to(torch.float64), firsts[:, 0]))
+        gathered_bytes = gather.bytes_per_gather
+        gather = None                              # the remaining measurements run without it
     same_batch_ms = None
     if nbatch > 1:
         same_batch_ms = distributed.max_over_ranks(timed(lambda k: step(k, False), args.steps, dev, distributed, torch)[1], dev)
@@ -424,10 +523,12 @@ def main():
     if rank == 0 and kind == 3 and not stub:
         parity = image_parity_report(eng, xs[0], outs[0], n_fft, hop, consts["weight"], consts["lut"])
 
+    exit_code = 0
     legs = {}
     if not stub and not args.no_legs and n_fft == 1024:
         del xs, outs, out
         torch.cuda.empty_cache()
+        legs.update(stft1024_f64_leg(dev, world, rank, consts))
         legs.update(octave_legs(dev, world, rank, 8, 3, 22, "configs2_bank", True))
         legs.update(stft16384_leg(dev, world, rank, consts))
         legs.update(gcc_leg(dev, world, rank))
@@ -475,8 +576,15 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel_ms": kernel_ms_max, "kernel_ms_repeats": repeats},
             "ranks_seen": ranks_seen,
+            "per_rank": {"ms_per_step_min": min(per_rank_wall) / args.steps * 1e3, "ms_per_step_max": max(per_rank_wall) / args.steps * 1e3,
+                         "ms_per_step": [w / args.steps * 1e3 for w in per_rank_wall],
+                         "note": "every rank's own wall time of the K timed steps between the two barriers; value uses the maximum"},
             "digest": float(digest_all.sum().item()),
         }
+        if slab_check is not None:
+            result["slab_gather"] = {"enabled": True, "bytes_per_step_per_rank": gathered_bytes, "slabs_verified": slab_check,
+                                     "note": "all_gather_into_tensor of the step's output slab, async behind the step, overlapped with "
+                                             "the next step (one receive buffer per rotating batch); included in value / ms_per_step"}
         if parity is not None:
             result["parity"] = parity
         if psd_ms is not None:
@@ -492,10 +600,22 @@ def main():
         if world == 1 and args.cpu_budget > 0 and not stub:
             result["cpu_baseline"] = cpu_baseline(host_x[0], n_fft, hop, consts["weight"], consts["lut"], args.cpu_budget)
         print(json.dumps(result), flush=True)
+        gates = [result.get("parity", {}).get("gate", {}).get("pass", True)]
+        gates += [lg.get("parity", {}).get("gate", {}).get("pass", True) for lg in legs.values() if isinstance(lg, dict)]
+        if slab_check is not None:
+            gates.append(slab_check)
+        if not all(gates):
+            print("bench.py: a parity gate failed (see `parity` / legs[*].parity in the line above)", file=sys.stderr)
+            exit_code = 3
+    if ranks_seen != list(range(world)):
+        print(f"bench.py: ranks_seen = {ranks_seen}, expected 0..{world - 1}", file=sys.stderr)
+        exit_code = 4
 
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    if exit_code:
+        raise SystemExit(exit_code)
 
 
 if __name__ == "__main__":

@@ -35,6 +35,20 @@ __global__ void __launch_bounds__(256) ring_write_kernel(const double* __restric
     ring[p + ring_len] = v;
 }
 
+// Growth of the mirror ring (ringbuffer.py:102-130 grows by x1.5 and re-lays the data): the last `keep` samples, absolute
+// indices [offset - keep, offset), move from their places in the old ring to their places in the new one, both copies.
+__global__ void __launch_bounds__(256) ring_relay_kernel(const double* __restrict__ old_ring, long long old_len,
+                                                         double* __restrict__ new_ring, long long new_len, long long offset,
+                                                         long long keep) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= keep) return;
+    const long long a = offset - keep + t;
+    const double v = old_ring[a % old_len];
+    const long long p = a % new_len;
+    new_ring[p] = v;
+    new_ring[p + new_len] = v;
+}
+
 // One thread per (pixel column p, screen row h).  norm: [frames][nb] (frame-major, what stft_kernel writes).
 // np.interp with the interval index found on the host (frequency_resampler.py:80; same branches as freq_resample_kernel).
 __device__ __forceinline__ double freq_interp(const double* __restrict__ col, int nb, int j, double dx, double den) {
@@ -100,6 +114,8 @@ struct frt_specgram {
     size_t pin_bytes = 0;
     void* pin_in = nullptr;
     size_t pin_in_bytes = 0;
+    hipEvent_t in_done = nullptr;                // the last chunk has left the staging buffers (pin_in, chunk)
+    bool in_pending = false;
     std::vector<int> h_src;
     std::vector<double> h_a;
 };
@@ -112,6 +128,7 @@ extern "C" void frt_specgram_destroy(frt_specgram* h) {
     for (auto* b : bufs) b->release();
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->in_done) (void)hipEventDestroy(h->in_done);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -137,6 +154,7 @@ extern "C" int frt_specgram_create(frt_specgram** out, int fft_size, double over
         h->own_stream = true;
         rc = frt_stft_set_stream(h->stft, h->stream);
     }
+    if (!rc && hipEventCreateWithFlags(&h->in_done, hipEventDisableTiming) != hipSuccess) rc = FRT_ERR_HIP;
     if (!rc) rc = h->ring.reserve(2 * (size_t)ring_length * sizeof(double));
     if (!rc && hipMemsetAsync(h->ring.ptr, 0, h->ring.bytes, h->stream) != hipSuccess) rc = FRT_ERR_HIP;
     if (rc) {
@@ -219,27 +237,86 @@ extern "C" int frt_specgram_set_ratio(frt_specgram* h, double interp_factor_L, d
     return FRT_OK;
 }
 
-static int processable(const frt_specgram* h, int m) {           // online_linear_2D_resampler.py:57-58
-    return (int)std::ceil((h->orig_index + m - (h->resampled_index + h->ratio)) / h->ratio);
+// The ring grows like the reference's (x1.5 until the request fits, ringbuffer.py:102-130).
+static int grow_ring(frt_specgram* h, long long need) {
+    long long new_len = h->ring_len;
+    while (new_len < need) new_len = (long long)(new_len * 1.5) + 1;
+    DeviceBuffer grown;
+    int rc;
+    if ((rc = grown.reserve(2 * (size_t)new_len * sizeof(double)))) return rc;
+    FRT_HIP_CHECK(hipMemsetAsync(grown.ptr, 0, grown.bytes, h->stream));
+    const long long keep = h->offset < h->ring_len ? h->offset : h->ring_len;
+    if (keep > 0)
+        hipLaunchKernelGGL(ring_relay_kernel, dim3((unsigned)((keep + 255) / 256)), dim3(256), 0, h->stream, h->ring.as<double>(), h->ring_len,
+                           grown.as<double>(), new_len, h->offset, keep);
+    FRT_HIP_CHECK(hipGetLastError());
+    FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->ring.release();
+    h->ring = grown;
+    grown.ptr = nullptr;
+    grown.bytes = 0;
+    h->ring_len = new_len;
+    return FRT_OK;
 }
 
 // One chunk of new samples (host memory, float64).  pixels_out: [height][max_cols] uint32, rows top = highest frequency;
 // *n_cols_out pixel columns were produced (0 is common), *n_frames_out spectra computed.
+// Everything that can fail on the arguments is decided on copies of the scalar state BEFORE anything is changed: an
+// error leaves the object as it was.
 extern "C" int frt_specgram_push(frt_specgram* h, const double* chunk, int n, uint32_t* pixels_out, int max_cols, int* n_cols_out,
                                  int* n_frames_out) {
     FRT_REQUIRE(h && n >= 0 && n_cols_out, "frt_specgram_push: bad arguments");
     FRT_REQUIRE(h->has_map && h->has_lut, "frt_specgram_push: set_epilogue and set_screen first");
-    FRT_REQUIRE(n <= h->ring_len - h->fft_size, "frt_specgram_push: chunk of %d samples does not fit the ring", n);
+    FRT_REQUIRE(n == 0 || chunk, "frt_specgram_push: null chunk");
     *n_cols_out = 0;
     if (n_frames_out) *n_frames_out = 0;
     int rc;
+    // ---- what this chunk will yield (spectrogram.py:133-159, online_linear_2D_resampler.py:61-97), on copies ----------
+    const long long new_offset = h->offset + n;
+    long long new_old_index = h->old_index;
+    long long available = new_offset - new_old_index;
+    if (available < 0) {
+        available = 0;
+        new_old_index = new_offset;
+    }
+    const int realizable = (int)std::floor((double)available / h->needed);
+    double orig_index = h->orig_index, resampled_index = h->resampled_index;
+    h->h_src.clear();
+    h->h_a.clear();
+    for (int jf = 0; jf < realizable; ++jf) {
+        orig_index += 1.0;
+        const int cnt = (int)std::ceil((orig_index - (resampled_index + h->ratio)) / h->ratio);      // processable(0)
+        if (cnt <= 0) continue;
+        double last_index = resampled_index;
+        for (int k = 1; k <= cnt; ++k) {
+            last_index = resampled_index + h->ratio * (double)k;
+            h->h_a.push_back(orig_index - last_index);
+            h->h_src.push_back(jf);
+        }
+        resampled_index = last_index;
+    }
+    const int n_out = (int)h->h_src.size();
+    FRT_REQUIRE(n_out <= max_cols || !pixels_out, "frt_specgram_push: %d pixel columns, room for %d", n_out, max_cols);
+    // the ring must hold the chunk and every frame it completes
+    const long long span = realizable > 0 ? h->fft_size + (long long)(realizable - 1) * h->hop : 0;
+    const long long last = new_old_index + (long long)(realizable - 1) * h->hop;
+    long long need_len = (long long)n + h->fft_size;
+    if (realizable > 0 && new_offset - (last - span) > need_len) need_len = new_offset - (last - span);
+    if (need_len > h->ring_len && (rc = grow_ring(h, need_len))) return rc;
+
     if (n > 0) {
-        FRT_REQUIRE(chunk, "frt_specgram_push: null chunk");
+        // the staging buffers are reused from push to push: the previous chunk must have left them (a push that completes
+        // no frame returns without waiting for its copy)
+        if (h->in_pending) {
+            FRT_HIP_CHECK(hipEventSynchronize(h->in_done));
+            h->in_pending = false;
+        }
         if ((rc = h->chunk.reserve((size_t)n * sizeof(double)))) return rc;
         // through pinned memory: a copy from pageable memory is staged by the runtime and blocks the calling thread
         if ((size_t)n * sizeof(double) > h->pin_in_bytes) {
             if (h->pin_in) (void)hipHostFree(h->pin_in);
             h->pin_in = nullptr;
+            h->pin_in_bytes = 0;
             FRT_HIP_CHECK(hipHostMalloc(&h->pin_in, (size_t)n * sizeof(double) * 2, hipHostMallocDefault));
             h->pin_in_bytes = (size_t)n * sizeof(double) * 2;
         }
@@ -247,20 +324,14 @@ extern "C" int frt_specgram_push(frt_specgram* h, const double* chunk, int n, ui
         FRT_HIP_CHECK(hipMemcpyAsync(h->chunk.ptr, h->pin_in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(ring_write_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->chunk.as<double>(), n, h->ring.as<double>(),
                            h->ring_len, h->offset);
-        h->offset += n;
+        FRT_HIP_CHECK(hipGetLastError());
+        FRT_HIP_CHECK(hipEventRecord(h->in_done, h->stream));
+        h->in_pending = true;
     }
-    long long available = h->offset - h->old_index;
-    if (available < 0) {
-        available = 0;
-        h->old_index = h->offset;
-    }
-    const int realizable = (int)std::floor((double)available / h->needed);
-    if (realizable <= 0) {
-        return FRT_OK;                       // (the chunk was copied to pinned staging: nothing to wait for)
-    }
+    h->offset = new_offset;
+    h->old_index = new_old_index;
+    if (realizable <= 0) return FRT_OK;
     // frame i holds the fft_size samples ending at old_index + i hop (data_indexed(old_index, fft_size), then old_index += hop)
-    const long long span = h->fft_size + (long long)(realizable - 1) * h->hop;
-    const long long last = h->old_index + (long long)(realizable - 1) * h->hop;
     FRT_REQUIRE(span <= h->ring_len && h->offset - (last - span) <= h->ring_len, "frt_specgram_push: the ring no longer holds the frames");
     const long long stop0 = last % h->ring_len + h->ring_len;     // ringbuffer.py:91-92
     const double* window = h->ring.as<double>() + (stop0 - span);
@@ -271,25 +342,8 @@ extern "C" int frt_specgram_push(frt_specgram* h, const double* chunk, int n, ui
     FRT_REQUIRE(F == realizable, "frt_specgram_push: internal frame count %lld != %d", (long long)F, realizable);
     if (n_frames_out) *n_frames_out = realizable;
 
-    // the time resampler's scalar bookkeeping (online_linear_2D_resampler.py:61-97, linear_interp.py:47-49)
-    h->h_src.clear();
-    h->h_a.clear();
-    const int total = processable(h, realizable);
-    for (int jf = 0; jf < realizable; ++jf) {
-        h->orig_index += 1.0;
-        const int cnt = processable(h, 0);
-        if (cnt <= 0) continue;
-        double last_index = h->resampled_index;
-        for (int k = 1; k <= cnt; ++k) {
-            last_index = h->resampled_index + h->ratio * (double)k;
-            h->h_a.push_back(h->orig_index - last_index);
-            h->h_src.push_back(jf);
-        }
-        h->resampled_index = last_index;
-    }
-    const int n_out = (int)h->h_src.size();
-    (void)total;
-    FRT_REQUIRE(n_out <= max_cols || !pixels_out, "frt_specgram_push: %d pixel columns, room for %d", n_out, max_cols);
+    h->orig_index = orig_index;                // the time resampler's scalars, as simulated above
+    h->resampled_index = resampled_index;
     DeviceBuffer& old_in = h->old_is_a ? h->old_a : h->old_b;
     DeviceBuffer& old_out = h->old_is_a ? h->old_b : h->old_a;
     const int cols_alloc = n_out > 0 ? n_out : 1;
@@ -332,6 +386,7 @@ extern "C" int frt_specgram_push(frt_specgram* h, const double* chunk, int n, ui
         }
     }
     FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->in_pending = false;
     *n_cols_out = n_out;
     return FRT_OK;
 }

@@ -9,7 +9,10 @@ Two collectives exist around it, both tiny:
     coefficients) so that every rank computes with bit-identical constants;
   * after a batch: per-channel summaries (band energies, spectrogram digests) are all-gathered so
     that rank 0 can present all channels.  Full PSD / pixel slabs stay resident on the GPU that
-    produced them (an all-gather of those is per-link bound on xGMI and nobody consumes it whole).
+    produced them by default (an all-gather of those is per-link bound on xGMI: 7 links x ~153 GB/s
+    per GPU); `SlabGather` is the OPTIONAL gather of SURVEY.md §8e for a consumer that wants every
+    channel's slab on every GPU: one all-gather per batch, issued asynchronously behind the batch
+    that produced the slab and overlapped with the next batch's kernels (double-buffered).
 
 The same code runs on CPU tensors over gloo (tests/test_distributed_cpu.py, world_size 2).
 """
@@ -86,6 +89,57 @@ def gather_channel_summaries(local, n_channels: int):
     dist.all_gather(parts, padded)
     rows = [parts[r][: len(shard_channels(n_channels, r, world))] for r in range(world)]
     return torch.cat(rows, dim=0)
+
+
+def gather_scalars(value: float, device=None) -> list:
+    """One float from every rank, in rank order ([value] for a single process): per-rank step times next to the maximum."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    mine = torch.tensor([value], dtype=torch.float64, device=device)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [float(p.item()) for p in parts]
+
+
+class SlabGather:
+    """Optional all-gather of the per-rank output slabs, overlapped with the next batch.
+
+    `start(slab, slot)` enqueues an asynchronous all-gather of this rank's slab [C_local, ...] into receive buffer `slot`
+    ([world, C_local, ...]); with RCCL the collective is ordered behind the kernels already enqueued on the current stream
+    (the ones that produce the slab) and runs on the communicator's own stream, so the kernels of the next batch, enqueued
+    afterwards, overlap with it.  `wait(slot)` must be called before the slab buffer that was gathered is overwritten and
+    before the receive buffer is read.  Every rank must pass slabs of the same shape (equal channel counts).  A single
+    process needs no communication: the "gathered" tensor is a view of the slab."""
+
+    def __init__(self, like, n_slots: int = 2):
+        import torch
+        import torch.distributed as dist
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.recv = [torch.empty((self.world,) + tuple(like.shape), dtype=like.dtype, device=like.device) for _ in range(n_slots)] \
+            if self.world > 1 else [None] * n_slots
+        self.work = [None] * n_slots
+        self.bytes_per_gather = self.world * like.numel() * like.element_size()
+
+    def start(self, slab, slot: int):
+        import torch.distributed as dist
+        self.wait(slot)
+        if self.world == 1:
+            self.recv[slot] = slab[None]
+            return
+        self.work[slot] = dist.all_gather_into_tensor(self.recv[slot].view(-1), slab.contiguous().view(-1), async_op=True)
+
+    def wait(self, slot: int):
+        w = self.work[slot]
+        if w is not None:
+            w.wait()
+            self.work[slot] = None
+        return self.recv[slot]
+
+    def wait_all(self):
+        for s in range(len(self.work)):
+            self.wait(s)
 
 
 def gather_ranks(device=None) -> list:

@@ -169,8 +169,27 @@ def image_parity(image, psd_same_path, psd_reference, weight_db, spec_min, spec_
         # how far the float32 power moved the index value of the differing pixels
         out["max_index_shift_of_mismatch"] = float(np.max(np.abs(v255 - r255)[rbad])) if np.any(rbad) else 0.0
         ref = np.asarray(psd_reference, np.float64)
-        out["psd_rel_max"] = float(np.max(np.max(np.abs(np.asarray(psd_same_path, np.float64) - ref), axis=-1)
-                                          / np.max(ref, axis=-1)))
+        err_frame = np.max(np.abs(np.asarray(psd_same_path, np.float64) - ref), axis=-1, keepdims=True)   # e_f: every bin's |dP| <= e_f
+        out["psd_rel_max"] = float(np.max(err_frame[..., 0] / np.max(ref, axis=-1)))
+        # Accounting of every differing pixel: the index value is q = 255 (10 log10(P + 1e-30) + w - min) / (max - min), so a
+        # power error of at most e_f moves it by at most g |ln((P + 1e-30 -+ e_f) / (P + 1e-30))|, g = 2550 / (ln 10 (max - min))
+        # (unbounded when e_f reaches P: a bin at the error floor may take any colour below its own).  A differing pixel
+        # is ACCOUNTED FOR when the reference's q lies within that distance of the integer edge it was carried across;
+        # anything else is a defect of the transform or the epilogue, whatever its count.
+        g = 2550.0 / (np.log(10.0) * abs(spec_max - spec_min))
+        p = ref + 1e-30
+        with np.errstate(divide="ignore", invalid="ignore"):
+            up = g * np.log1p(err_frame / p)
+            down = np.where(err_frame < p, -g * np.log1p(-np.minimum(err_frame / p, 1.0 - 1e-16)), np.inf)
+        reach = np.maximum(up, down) + 1e-9                       # + the float64 rounding of the reference's own expression
+        # distance of the reference's UNCLIPPED index value from the nearest edge: the index changes at q = 1, 2, ..., 255
+        dbr = log_spectrum(ref)
+        if weight_db is not None:
+            dbr = dbr + np.asarray(weight_db)[None, :]
+        q = 255.0 * normalise(dbr, spec_min, spec_max)
+        to_edge = np.abs(q - np.clip(np.rint(q), 1.0, 255.0))
+        out["mismatch_unaccounted"] = int(np.sum(rbad & ~(to_edge <= reach)))
+        out["max_reach_of_mismatch"] = float(np.max(reach[rbad])) if np.any(rbad) else 0.0
     return out
 
 

@@ -95,6 +95,66 @@ def test_bench_rank_logic_two_ranks_gloo():
     assert abs(rec["digest"] - want) < 1e-6
 
 
+def test_bench_two_ranks_gloo_with_slab_gather():
+    """The optional slab all-gather of SURVEY.md §8e (--gather-slabs): issued asynchronously behind every step, one receive
+    buffer per rotating batch, verified against every rank's own slab; per-rank step times are reported next to the
+    maximum; ranks_seen is asserted by the job itself."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--stub-engine", "--log2-samples", "14", "--batches", "2", "--gather-slabs"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    F = (2 ** 14 - 1024) // 512 + 1
+    sg = rec["slab_gather"]
+    assert sg["enabled"] and sg["slabs_verified"] is True and sg["bytes_per_step_per_rank"] == 2 * F * 513 * 4
+    pr = rec["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and pr["ms_per_step_min"] <= pr["ms_per_step_max"]
+    assert abs(pr["ms_per_step_max"] - rec["ms_per_step"]) <= 1e-9 * rec["ms_per_step"]
+
+
+def _slab_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    distributed.init_process_group(backend="gloo")
+    slabs = [torch.full((3, 4, 5), float(10 * b + rank)) for b in range(2)]
+    g = distributed.SlabGather(slabs[0], n_slots=2)
+    for step in range(5):                                   # double-buffered: start(b) waits for the previous gather of slot b
+        b = step % 2
+        slabs[b] += 100.0                                   # "the next batch" overwrites the buffer only after wait(b) inside start
+        g.wait(b)
+        g.start(slabs[b], b)
+    g.wait_all()
+    for b in range(2):
+        got = g.wait(b)
+        for r in range(world):
+            n_updates = 3 if b == 0 else 2
+            assert torch.all(got[r] == 10 * b + r + 100.0 * n_updates), (b, r, got[r].flatten()[0])
+    assert distributed.gather_scalars(0.5 + rank) == [0.5 + r for r in range(world)]
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+def test_slab_gather_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slab_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
 def test_bench_stub_single_process():
     import json
     import subprocess

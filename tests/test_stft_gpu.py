@@ -269,8 +269,11 @@ def test_db_norm_image_against_golden(golden, engine_cls):
     assert rep["epilogue_mismatched"] <= 2, rep                       # pixels within 1e-6 of an edge: ~1e-6 of all
     assert rep["psd_rel_max"] <= TOL32
     assert np.array_equal(img != ref_img, img != lut[dsp.colour_index(psd_ref, A, smin, smax)[0]])
-    assert rep["pixels_mismatched"] < 2e-3 * img.size, rep
-    assert np.mean((img != ref_img)[strong]) < 2e-4, rep
+    # against the float64 reference image: every differing pixel must be a bin that the float32 PSD's measured error
+    # (at most psd_rel_max of the frame maximum per bin) can carry across the edge it crossed — accounted one by one
+    assert rep["mismatch_unaccounted"] == 0, rep
+    assert rep["psd_rel_max"] <= 1e-5, rep
+    assert np.mean((img != ref_img)[strong]) < 2e-4, rep          # bins above the float32 error floor: a handful at edges
     # float64 instance: pixel-exact everywhere but at exact bin edges
     e64 = engine_cls(1024, 512, 1, 64)
     e64.set_epilogue(A, smin, smax, lut)

@@ -116,7 +116,7 @@ def test_spectrogram_chain(hip):
     ratio = sg.sfft_rate_frac / (__import__("fractions").Fraction(600, 2000))
     tr = dsp.TimeResampler(sg.sfft_rate_frac, __import__("fractions").Fraction(600, 2000), 120)
     ring, old_index = dsp.MirrorRing(), 0
-    total_px, mismatched = 0, 0
+    total_px, mismatched, unaccounted = 0, 0, 0
     for c in range(16):
         chunk = x[None, c * 512:(c + 1) * 512]
         got = sg.handle_new_data(chunk)
@@ -130,12 +130,18 @@ def test_spectrogram_chain(hip):
             cols.append(dsp.psd_frame(ring.data_indexed(old_index, 1024)[0], dsp.hann_symmetric(1024)))
             old_index += 256
         norm = dsp.normalise(dsp.log_spectrum(np.stack(cols, axis=1)) + w[:, None], -140.0, 0.0)
-        want = dsp.colour_pixels(lut, tr.push(dsp.frequency_resample(tg, dsp.frequency_axis(1024), norm)))
+        vals = tr.push(dsp.frequency_resample(tg, dsp.frequency_axis(1024), norm))
+        want = dsp.colour_pixels(lut, vals)
         assert got.shape == want.shape and got.dtype == np.uint32
         total_px += want.size
-        mismatched += int(np.sum(got != want))
-    # the GPU STFT differs from pocketfft in the last bits: a pixel can flip only at a LUT bin edge
-    assert total_px > 0 and mismatched <= 1e-3 * total_px
+        bad = got != want
+        mismatched += int(np.sum(bad))
+        # the float64 GPU transform differs from pocketfft by ~1e-16 of the frame maximum: through dB and normalisation that
+        # is < 1e-12 index units for every bin above the 1e-30 floor, so a pixel may differ only where the value the colour
+        # is taken from sits within 1e-9 of an index edge — each differing pixel is checked for that, not counted
+        q = np.clip(vals, 0.0, 1.0) * 255
+        unaccounted += int(np.sum(bad & (np.abs(q - np.rint(q)) > 1e-9)))
+    assert total_px > 0 and unaccounted == 0 and mismatched <= 5, (mismatched, unaccounted, total_px)
 
 
 def test_spectrogram_stream_equals_host_chain(hip):
@@ -171,6 +177,62 @@ def test_spectrogram_stream_equals_host_chain(hip):
             blocks += 1
             cols += a.shape[1]
     assert blocks > 50 and cols > 300 and pos > 6000 * 9          # the 6000-sample ring wrapped nine times
+
+
+def test_spectrogram_stream_small_chunks_large_frames(hip):
+    """fft_size 16384 fed in 512-sample chunks back to back: seven of eight pushes complete no frame and return without
+    waiting for their upload, so the staging buffers are reused immediately (the copy of chunk k must have
+    left them before chunk k + 1 is written there).  Same pixels as the block-by-block chain, and as ONE large push."""
+    from fractions import Fraction
+
+    from friture_amd.spectrogram import Spectrogram, SpectrogramStream
+    kw = dict(fft_size=16384, overlap=Fraction(1, 2), weighting=1, screen_width=300, screen_height=97, timerange_s=2.0)
+    host, dev, big = Spectrogram(**kw), SpectrogramStream(**kw), SpectrogramStream(**kw)
+    x = synth("chirp", 512 * 200, 21).astype(np.float64)
+    got_host, got_dev = [], []
+    for k in range(200):
+        chunk = x[None, 512 * k:512 * (k + 1)]
+        a, b = host.handle_new_data(chunk), dev.handle_new_data(chunk)
+        assert (a is None) == (b is None), k
+        if a is not None:
+            got_host.append(a[::-1, :])
+            got_dev.append(b)
+    assert len(got_dev) >= 10
+    assert np.array_equal(np.concatenate(got_dev, axis=1), np.concatenate(got_host, axis=1))
+    # one push of everything: longer than the ring (65536 samples) -> the ring grows like the reference's (ringbuffer.py:102-130)
+    c = big.handle_new_data(x[None, :])
+    assert c is not None and np.array_equal(c, np.concatenate(got_dev, axis=1))
+    # and the grown object keeps streaming: the same continuation from both
+    y = synth("noise", 16384 * 2, 22).astype(np.float64)
+    d1 = [dev.handle_new_data(y[None, i:i + 4096]) for i in range(0, len(y), 4096)]
+    d2 = [big.handle_new_data(y[None, i:i + 4096]) for i in range(0, len(y), 4096)]
+    for u, v in zip(d1, d2):
+        assert (u is None) == (v is None)
+        if u is not None:
+            assert np.array_equal(u, v)
+
+
+def test_spectrogram_stream_error_leaves_state(hip):
+    """A push whose pixel columns do not fit the caller's block fails BEFORE any state changes: the same chunk pushed again
+    with room gives what an undisturbed object gives."""
+    import ctypes as ct
+    from fractions import Fraction
+
+    from friture_amd import _lib
+    from friture_amd.spectrogram import SpectrogramStream
+    kw = dict(fft_size=1024, overlap=Fraction(3, 4), weighting=0, screen_width=800, screen_height=64, timerange_s=0.5)
+    a, b = SpectrogramStream(**kw), SpectrogramStream(**kw)
+    x = synth("noise", 40000, 31).astype(np.float64)
+    ra = a.handle_new_data(x[None, :20000])
+    a._sync_screen()
+    tiny = np.zeros((64, 2), np.uint32)
+    ncols, nfr = ct.c_int(0), ct.c_int(0)
+    chunk = np.ascontiguousarray(x[20000:40000])
+    rc = a._lib.frt_specgram_push(a._h, chunk.ctypes.data, len(chunk), tiny.ctypes.data, 2, ct.byref(ncols), ct.byref(nfr))
+    assert rc != 0 and b"pixel columns" in a._lib.frt_last_error()
+    rb = b.handle_new_data(x[None, :20000])
+    assert np.array_equal(ra, rb)
+    assert np.array_equal(a.handle_new_data(x[None, 20000:40000]), b.handle_new_data(x[None, 20000:40000]))
 
 
 def test_octave_spectrum_stream_equals_host_chain(hip):

@@ -19,11 +19,12 @@ def stats(db_path):
     print("# vgpr / agpr: registers allocated per lane = 2 x the trace's VGPR_Count / Accum_VGPR_Count fields (on gfx950 the trace")
     print("#   reports the allocation in units of two registers: 76 for the 149 -> 152 registers of stft_kernel<9,4>; cross-checked")
     print("#   against hipcc -Rpass-analysis=kernel-resource-usage); waves/SIMD = min(8, 512 // (vgpr + agpr))")
-    print("# name | calls | total_us | avg_us | min_us | max_us | % | vgpr | agpr | waves/SIMD | sgpr | lds_bytes | grid | workgroup")
+    print("# name | calls | total_us | avg_us | min_us | max_us | % | vgpr | agpr | waves/SIMD | sgpr | lds_bytes | grid (threads x,y,z) | workgroup (x,y,z)")
     total = cur.execute("select sum(duration) from kernels").fetchone()[0]
     q = ("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), vgpr_count, accum_vgpr_count, sgpr_count, "
-         "lds_size, grid_x, workgroup_x from kernels group by name order by sum(duration) desc")
-    for name, n, tot, avg, mn, mx, vg, ag, sg, lds, grid, wg in cur.execute(q):
+         "lds_size, grid_x, grid_y, grid_z, workgroup_x, workgroup_y, workgroup_z from kernels group by name order by sum(duration) desc")
+    for name, n, tot, avg, mn, mx, vg, ag, sg, lds, gx, gy, gz, wx, wy, wz in cur.execute(q):
+        grid, wg = f"{gx}x{gy}x{gz}", f"{wx}x{wy}x{wz}"          # the full launch shape: a 4 x 100 grid is not 4 workgroups
         short = name if len(name) < 100 else name[:97] + "..."
         vg, ag = 2 * (vg or 0), 2 * (ag or 0)
         occ = min(8, 512 // max(vg + ag, 1))
