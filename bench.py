@@ -300,7 +300,7 @@ def stft1024_f64_leg(dev, world, rank, consts):
     from oracle import dsp
     n_fft, hop, T = 1024, 512, 1 << 25
     nb = n_fft // 2 + 1
-    xs = [torch.from_numpy(synth_channel(7000 + 131 * b + rank, T).astype(np.float64)[None]).to(dev) for b in range(3)]
+    xs = [torch.from_numpy(np.stack([synth_channel(7000 + 131 * b + rank, T).astype(np.float64)])).to(dev) for b in range(3)]
     eng = StftEngine(n_fft, hop, 1, 64)
     eng.set_epilogue(consts["weight"], -140.0, 0.0, consts["lut"])
     F = eng.frames_for(T)

@@ -128,6 +128,11 @@ __device__ __forceinline__ void stream_store(T* p, T v) {
 #ifndef FRT_WAVE_MIN_WAVES
 #define FRT_WAVE_MIN_WAVES 3
 #endif
+// float64: every hoisted constant and every point is a register pair; three waves per SIMD (168 registers) spilled 133 of
+// them to scratch (448 bytes per lane: 0.34 ms for 65 535 frames of N = 1024, a fifth of the HBM roofline)
+#ifndef FRT_WAVE_MIN_WAVES_F64
+#define FRT_WAVE_MIN_WAVES_F64 2
+#endif
 // SHIFT = -1: the RING instance (float32, hop = N/2, one wavefront per frame, 16-byte aligned rows).  The frame's samples
 // do not live in a register window: each wavefront owns a ring of two half-frames in LDS, the half-frame that the frame
 // after next needs is copied there from HBM by an LDS-DMA issued from inline assembly (stft_big.h explains why) as soon as
@@ -148,7 +153,7 @@ template <typename TIN, typename T, int LOG2M, int SHIFT>
 __global__ void
 #if defined(FRT_WAVE_MIN_WAVES)
 __launch_bounds__((Pow2Plan<LOG2M>::TPF < 256 ? 256 : Pow2Plan<LOG2M>::TPF),
-                  (Pow2Plan<LOG2M>::TPF <= 64 ? (SHIFT < 0 ? FRT_RING_MIN_WAVES : FRT_WAVE_MIN_WAVES) : 1))
+                  (Pow2Plan<LOG2M>::TPF <= 64 ? (SHIFT < 0 ? FRT_RING_MIN_WAVES : sizeof(T) == 8 ? FRT_WAVE_MIN_WAVES_F64 : FRT_WAVE_MIN_WAVES) : 1))
 #else
 __launch_bounds__((Pow2Plan<LOG2M>::TPF < 256 ? 256 : Pow2Plan<LOG2M>::TPF))
 #endif
@@ -650,8 +655,9 @@ static int launch_shift(const StftArgs& a, int shift, int blocks, hipStream_t st
     if (shift < 0) shift = 4;
     if constexpr (sizeof(T) == 4) {
         if (shift == 2) return launch_one<TIN, T, LOG2M, 2>(a, blocks, stream);
-        if (shift == 4) return launch_one<TIN, T, LOG2M, 4>(a, blocks, stream);
     }
+    // hop = N/2 keeps half of the register window (float64 too: the reference's own precision at BASELINE's overlap)
+    if (shift == 4) return launch_one<TIN, T, LOG2M, 4>(a, blocks, stream);
     return launch_one<TIN, T, LOG2M, 0>(a, blocks, stream);
 }
 

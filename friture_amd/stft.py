@@ -100,13 +100,14 @@ class StftEngine:
             raise ValueError(f"expected {self.n_channels} channels, got {x.shape[0]}")
         T = x.shape[1]
         F = self.frames_for(T)
+        xstride = x.stride(0) if x.shape[0] > 1 else T            # a size-1 axis may carry any stride (numpy's x[None] has 0)
         if out is None:
             odt = torch.int32 if kind == FRT_STFT_IMAGE else want      # torch has no uint32 arithmetic; same bits
             out = torch.empty((self.n_channels, F, self.n_bins), dtype=odt, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _lib.check(self._lib.frt_stft_set_stream(self._h, ctypes.c_void_p(stream)))
         nf = ctypes.c_int64(0)
-        _lib.check(self._lib.frt_stft_run(self._h, kind, ctypes.c_void_p(x.data_ptr()), T, x.stride(0),
+        _lib.check(self._lib.frt_stft_run(self._h, kind, ctypes.c_void_p(x.data_ptr()), T, xstride,
                                           ctypes.c_void_p(out.data_ptr()), ctypes.byref(nf)))
         return out
 

@@ -179,10 +179,10 @@ static int do_check() {
     return fails ? 1 : 0;
 }
 
-static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int iters) {
+static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int iters, int precision) {
     const int64_t T = 1ll << log2T;
     frt_stft* h = nullptr;
-    CK(frt_stft_create(&h, N, hop, C, 32));
+    CK(frt_stft_create(&h, N, hop, C, precision));
     CK(frt_stft_set_run_length(h, run));
     std::vector<uint32_t> lut(256);
     for (int i = 0; i < 256; ++i) lut[i] = 0xFF000000u | (i * 0x010101);
@@ -196,13 +196,17 @@ static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int ite
     // FRT_BENCH_SETS=k: the timed launches rotate over k distinct input/output buffer pairs, so that no launch
     // finds its input in the 256 MB Infinity Cache (k = 1: the same batch every launch)
     const int sets = getenv("FRT_BENCH_SETS") ? atoi(getenv("FRT_BENCH_SETS")) : 1;
-    float* dx0;
+    const size_t esz = precision == 32 ? 4 : 8, oesz = kind == FRT_STFT_IMAGE ? 4 : esz;
+    std::vector<double> xd;
+    if (precision == 64) xd.assign(x.begin(), x.end());
+    const void* xhost = precision == 32 ? (const void*)x.data() : (const void*)xd.data();
+    char* dx0;
     char* dout0;
-    const size_t out_bytes = (size_t)C * F * nb * 4;
-    HK(hipMalloc(&dx0, x.size() * 4 * sets));
+    const size_t out_bytes = (size_t)C * F * nb * oesz, in_bytes = x.size() * esz;
+    HK(hipMalloc(&dx0, in_bytes * sets));
     HK(hipMalloc(&dout0, out_bytes * sets));
-    for (int k = 0; k < sets; ++k) HK(hipMemcpy(dx0 + x.size() * k, x.data(), x.size() * 4, hipMemcpyHostToDevice));
-    float* dx = dx0;
+    for (int k = 0; k < sets; ++k) HK(hipMemcpy(dx0 + in_bytes * k, xhost, in_bytes, hipMemcpyHostToDevice));
+    char* dx = dx0;
     void* dout = dout0;
     hipStream_t s;
     HK(hipStreamCreate(&s));
@@ -217,7 +221,7 @@ static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int ite
         clock_gettime(CLOCK_MONOTONIC, &t0);
         int k = 0;
         for (;;) {
-            for (int i = 0; i < 64; ++i, ++k) CK(frt_stft_run(h, kind, dx0 + x.size() * (k % sets), T, T, dout0 + out_bytes * (k % sets), &nf));
+            for (int i = 0; i < 64; ++i, ++k) CK(frt_stft_run(h, kind, dx0 + in_bytes * (k % sets), T, T, dout0 + out_bytes * (k % sets), &nf));
             HK(hipStreamSynchronize(s));
             clock_gettime(CLOCK_MONOTONIC, &t1);
             if ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 >= prewarm_ms) break;
@@ -228,7 +232,7 @@ static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int ite
     HK(hipEventCreate(&e0));
     HK(hipEventCreate(&e1));
     HK(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) CK(frt_stft_run(h, kind, dx0 + x.size() * (i % sets), T, T, dout0 + out_bytes * (i % sets), &nf));
+    for (int i = 0; i < iters; ++i) CK(frt_stft_run(h, kind, dx0 + in_bytes * (i % sets), T, T, dout0 + out_bytes * (i % sets), &nf));
     HK(hipEventRecord(e1, s));
     HK(hipEventSynchronize(e1));
     float ms = 0;
@@ -251,9 +255,9 @@ static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int ite
     iso_ms /= iters;
     const double per = ms / iters * 1e-3;
     const double spectra = (double)C * F / per;
-    const double bytes = (double)C * F * (4.0 * hop + 4.0 * nb);
-    printf("bench N=%d hop=%d C=%d T=2^%d F=%lld kind=%d run=%d sets=%d: %.3f ms/launch  %.4e spectra/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)  [isolated launch: %.3f ms]\n",
-           N, hop, C, log2T, (long long)F, kind, run, sets, per * 1e3, spectra, bytes / per * 1e-9, bytes / per / 8e12 * 100, iso_ms);
+    const double bytes = (double)C * F * ((double)esz * hop + (double)oesz * nb);
+    printf("bench p%d N=%d hop=%d C=%d T=2^%d F=%lld kind=%d run=%d sets=%d: %.3f ms/launch  %.4e spectra/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)  [isolated launch: %.3f ms]\n",
+           precision, N, hop, C, log2T, (long long)F, kind, run, sets, per * 1e3, spectra, bytes / per * 1e-9, bytes / per / 8e12 * 100, iso_ms);
     frt_stft_destroy(h);
     HK(hipFree(dx0));
     HK(hipFree(dout0));
@@ -274,8 +278,9 @@ int main(int argc, char** argv) {
         int kind = argc > 6 ? atoi(argv[6]) : 0;
         int run = argc > 7 ? atoi(argv[7]) : 0;
         int iters = argc > 8 ? atoi(argv[8]) : 20;
-        return do_bench(N, hop, C, log2T, kind, run, iters);
+        int precision = argc > 9 ? atoi(argv[9]) : 32;
+        return do_bench(N, hop, C, log2T, kind, run, iters, precision);
     }
-    fprintf(stderr, "usage: stft_selftest check | bench [N hop C log2T kind run iters]\n");
+    fprintf(stderr, "usage: stft_selftest check | bench [N hop C log2T kind run iters precision]\n");
     return 2;
 }
