@@ -199,11 +199,11 @@ def octave_legs(dev, world, rank, ch, bpo, log2n, tag, with_sequential):
     out = torch.empty((ch, n // 1024, 9 * bpo), dtype=torch.float32, device=dev)
     units = world * ch * (n // 1024) * 9 * bpo
     alg_bytes = ch * (n // 1024) * (4096 + 4 * 9 * bpo)
-    # recurrence steps of the exact bank: per stage j every channel runs bpo band filters and one decimator over n / 2^j
-    # samples; a wavefront steps 16 band filters (quad slots: 4 arithmetic + 4 DPP + 2 energy instructions per sample in
-    # the contracted form the energy-only call uses) or 4 decimators (row slots: 3 + 4), 4 issue cycles each
-    quad_waves, row_waves = -(-ch * bpo // 16), -(-ch // 4)
-    wave_instr = sum((n >> j) * (quad_waves * 10 + row_waves * 7) for j in range(9))
+    # instruction floor of the output pass (round 3: one lane per (channel, chunk), the whole state vector in registers, wave-
+    # uniform coefficients as scalar operands): 2 * 4 + 1 + 2 = 11 float64 instructions per sample and band filter (9 of the
+    # recurrence, 2 of the block energy), 2 * 12 + 1 = 25 per sample for the decimator, 64 chunks per wavefront; a float64
+    # vector instruction occupies its SIMD for 4 cycles
+    wave_instr = sum((n >> j) * ch * (11 * bpo + 25) / 64 for j in range(9))
     issue_bound_s = wave_instr * 4 / (SIMDS * MAX_CLOCK_HZ)
     legs = {}
     # SURVEY.md §8d's algorithmic flops of the bank (mode 0): (2 bpo + 6) biquads x 2044 samples x 9 flop per channel and
@@ -225,17 +225,16 @@ def octave_legs(dev, world, rank, ch, bpo, log2n, tag, with_sequential):
                                                                "the 78.6 TFLOP/s float64 vector peak"}, **extra(dt))}
 
     iir = IirBank(t["bdec"], t["adec"], list(t[f"boct_{bpo}"]), list(t[f"aoct_{bpo}"]), ch)
-    chunk = 2048 if bpo <= 3 else 4096
+    chunk = 1024
     iir.set_chunk(chunk)
     record("iir_time_parallel", iir, 5,
-           f"exact IIR bank, time-parallel chunks of {chunk} samples: the same recurrences re-associated, the output pass of "
-           f"this energy-only call with contracted multiply-adds; band energies equal to the bit-exact sequential mode's "
-           f"at float32 output precision (1.2e-7; bar 1e-5)",
+           f"exact IIR bank, time-parallel chunks of {chunk} samples: the same recurrences re-associated; output pass with one lane "
+           f"per (channel, chunk) and contracted multiply-adds (energy-only call); band energies equal to the bit-exact "
+           f"sequential mode's at float32 output precision (bar 1e-5)",
            lambda dt: {"bound": "f64_valu_issue", "unit": "s", "achieved": dt, "peak": issue_bound_s, "frac": issue_bound_s / dt,
-                       "model": "sum over stages of samples x (quad wavefronts x 10 + row wavefronts x 7 float64 VALU / DPP "
-                                "instructions: 16 band filters or 4 decimators per wavefront) x 4 issue cycles / (1024 SIMDs x "
-                                "2.4 GHz): the arithmetic of the output pass alone, no group fetch, no loop overhead; the "
-                                "time-parallel mode adds the zero-state products and chunk scans on top"})
+                       "model": "sum over stages of samples x channels x (11 bpo + 25) float64 instructions / 64 lanes x 4 cycles / "
+                                "(1024 SIMDs x 2.4 GHz): the arithmetic of the output pass alone; the time-parallel mode adds the "
+                                "zero-state products (matrix cores) and the chunk scans on top"})
     if with_sequential:
         seq = IirBank(t["bdec"], t["adec"], list(t[f"boct_{bpo}"]), list(t[f"aoct_{bpo}"]), ch)
         xs, outs = x[:, : 1 << 16].contiguous(), torch.empty((ch, 64, 9 * bpo), dtype=torch.float32, device=dev)

@@ -40,7 +40,6 @@ namespace frt {
 #ifndef FRT_IIR_VEC_OUT             // 16-byte stores of the decimated output (measured: no gain over the per-sample stores)
 #define FRT_IIR_VEC_OUT 0
 #endif
-constexpr int kScanRowsDecl = 32;   // = kScanRows (iir_scan_kernel, below)
 
 struct IirStageArgs {
     const void* x;             // [C][x_stride] stage input
@@ -57,9 +56,10 @@ struct IirStageArgs {
     int pass;                  // 0 sequential, 1 zero-state scan pass, 2 output pass from chunk_init
     double* chunk_end;         // [C][nfilt][nchunks][kStates] pass 1 result
     const double* chunk_init;  // [C][nfilt][nchunks][kStates] pass 2: a chunk's state had its scan row started from zero ...
-    const double* group_start; // [C][nfilt][kScanRows][kStates] ... the rows' true initial states ...
+    const double* group_start; // [C][nfilt][scan_rows][kStates] ... the rows' true initial states ...
     const double* group_pow;   // [nfilt][scan_group][kStates][kStates] ... and (A^L)^i, i = the chunk's index in its row
     int scan_group;            // chunks per scan row
+    int scan_rows;             // scan rows per (channel, filter)
     double* y;                 // band outputs (packed per channel) or null
     long long y_cstride;
     long long y_off[kMaxFilters];   // offset of each filter's band inside a channel's packed row
@@ -96,8 +96,9 @@ __device__ __forceinline__ double dpp_row_bcast0(double v) {
 template <int T>
 __device__ __forceinline__ double dpp_row_bcast(double v) {          // lane T of every 16-lane row, to its row
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + T, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + T, 0xF, 0xF, false);
+    // every lane of every row reads a valid lane: with bound_ctrl the "old" operand is dead and costs no move
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + T, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + T, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -215,7 +216,7 @@ __device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long 
             // true initial state = zero-start prefix + (A^L)^i x the scan row's initial state (iir_scan_kernel)
             const int srow = q / a.scan_group, i = q - srow * a.scan_group;
             const double* pw = a.group_pow + (((size_t)f * a.scan_group + i) * kStates + s) * kStates;
-            const double* gs = a.group_start + (((size_t)c * a.nfilt + f) * kScanRowsDecl + srow) * kStates;
+            const double* gs = a.group_start + (((size_t)c * a.nfilt + f) * a.scan_rows + srow) * kStates;
             double acc = a.chunk_init[cidx];
             for (int t = 0; t < ord; ++t) acc += pw[t] * gs[t];
             z = acc;
@@ -390,6 +391,188 @@ static int launch_iir_stage(IirStageArgs a, const int* orders, int n_channels, h
     a.waves_row = (int)wr;
     if (wr + wq == 0) return FRT_OK;
     hipLaunchKernelGGL(iir_stage_kernel, dim3((unsigned)(wr + wq)), dim3(64), 0, stream, a);
+    FRT_HIP_CHECK(hipGetLastError());
+    return FRT_OK;
+}
+
+// ---- time-parallel mode, output pass of ENERGY-ONLY calls: one LANE per (channel, time chunk) ------------------------
+// The slot kernel above spreads ONE filter over the lanes of a quad or a DPP row (lane = state index): right for the
+// sequential mode, where a channel offers a handful of independent recurrences, but a wavefront then advances 16 band
+// filters (or 4 decimators) by one sample in ~10 instructions.  A time-parallel stage has thousands of chunks per
+// channel, each an independent recurrence once its initial state is known: here a lane owns one chunk, keeps the whole
+// state vector of its filters in registers and steps through the chunk's samples with plain multiply-adds — the
+// coefficients are wave-uniform (every lane runs the same filters), so they sit in scalar registers and the loop is
+// 2 ORD + 1 (+ 2 for the block energy) float64 instructions per sample and filter for 64 chunks at once: 11 per band
+// filter instead of 10 per 16 filter-steps, i.e. ~5.8x the filter-steps per instruction (the decimator: 25 instead of 7 per
+// 4).  Multiply-adds are contracted like the slot kernel's FUSED form (energies to 1e-5; band signals are never
+// produced here: calls that return signals keep the slot kernel and the reference's separately rounded operations).
+// A wavefront = 64 consecutive chunks of one channel x one filter group (up to kLaneBands band filters, or the decimator,
+// which also writes the even samples of its output as the next stage's input).
+constexpr int kLaneBands = 3;
+
+template <int NF, int ORD, bool DEC, bool F32>
+__device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0) {
+    const int lane = threadIdx.x;
+    const int nblk = (a.nchunks + 63) / 64;
+    const int c = blockIdx.x / nblk;
+    const int q = (blockIdx.x - c * nblk) * 64 + lane;
+    const bool valid = q < a.nchunks;
+    const int qc = valid ? q : a.nchunks - 1;                  // lanes past the end shadow the last chunk, store nothing
+    const int L = a.chunk;
+
+    // initial state of every filter of the group: zero-start prefix + (A^L)^i x the scan row's true start (iir_scan_kernel)
+    double z[NF][ORD], acc[NF], alpha[NF], decay[NF];
+    const int srow = qc / a.scan_group, irow = qc - srow * a.scan_group;
+#pragma unroll
+    for (int m = 0; m < NF; ++m) {
+        const int f = f0 + m;
+        const double* init = a.chunk_init + (((size_t)c * a.nfilt + f) * a.nchunks + qc) * kStates;
+        const double* pw = a.group_pow + ((size_t)f * a.scan_group + irow) * kStates * kStates;
+        const double* gs = a.group_start + (((size_t)c * a.nfilt + f) * a.scan_rows + srow) * kStates;
+        double g[ORD];
+#pragma unroll
+        for (int t = 0; t < ORD; ++t) g[t] = gs[t];
+#pragma unroll
+        for (int st = 0; st < ORD; ++st) {
+            double v = init[st];
+#pragma unroll
+            for (int t = 0; t < ORD; ++t) v += pw[st * kStates + t] * g[t];
+            z[m][st] = v;
+            asm volatile("" ::: "memory");                      // one row of the power table in flight at a time (144 loads otherwise)
+        }
+        const int band = a.band_index[f];
+        alpha[m] = (!DEC && band >= 0) ? a.alpha[band] : 0.0;
+        decay[m] = 1.0 - alpha[m];
+        acc[m] = 0.0;
+    }
+    // coefficients: wave-uniform, read ONCE through the constant address space (s_load: the table is never written by a
+    // kernel; as plain global loads the compiler re-reads all of them every iteration, next to stores it cannot prove
+    // disjoint) and used as scalar operands of the multiply-adds
+    typedef const double __attribute__((address_space(4))) * ktable;
+    double cb[NF][ORD + 1], ca[NF][ORD + 1];
+#pragma unroll
+    for (int m = 0; m < NF; ++m) {
+        const ktable t = (ktable)(uintptr_t)(a.coef + (size_t)(f0 + m) * kCoefStride);
+#pragma unroll
+        for (int i = 0; i <= ORD; ++i) {
+            cb[m][i] = t[i];
+            ca[m][i] = i ? -t[kMaxOrder + 1 + i] : 0.0;          // the update subtracts a[i] y: the negated value is what fma takes
+        }
+    }
+
+    const long long s0 = (long long)qc * L;                    // first sample of the chunk in its channel's stage signal
+    const float* xf = (const float*)a.x + (long long)c * a.x_stride + s0;
+    const double* xd = (const double*)a.x + (long long)c * a.x_stride + s0;
+    double* xn = DEC && a.xnext ? a.xnext + (long long)c * a.xnext_stride + (s0 >> 1) : nullptr;
+    const int elen = a.eblock_len;
+    const bool energy = !DEC && a.eblock != nullptr;
+    constexpr bool f32 = F32;
+
+    // Sixteen samples per trip (chunks are multiples of 64): the next sixteen — one 64-byte (float) or 128-byte (double)
+    // piece of the lane's own stream — are requested before these are filtered and converted only when their turn comes.
+    // Every lane walks its own cache lines (the chunks lie L samples apart), so a request is an L2 round trip, often an HBM
+    // one: with four samples per trip the 100 instructions in between did not cover it and every trip began with a wait.
+    constexpr int G = 16;
+    float4 rf[4];
+    double2 rd[8];
+    auto request = [&](int k) {
+        if (f32) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rf[i] = *(const float4*)(xf + k + 4 * i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rd[i] = *(const double2*)(xd + k + 2 * i);
+        }
+    };
+    request(0);
+    for (int k0 = 0; k0 < L; k0 += G) {
+        double xg[G];
+        if (f32) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xg[4 * i] = rf[i].x; xg[4 * i + 1] = rf[i].y; xg[4 * i + 2] = rf[i].z; xg[4 * i + 3] = rf[i].w; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { xg[2 * i] = rd[i].x; xg[2 * i + 1] = rd[i].y; }
+        }
+        if (k0 + G < L) request(k0 + G);
+        double yd[G / 2];
+#pragma unroll
+        for (int u4 = 0; u4 < G; u4 += 4) {
+            const int k = k0 + u4;
+            if (energy && (k & (elen - 1)) == 0) {
+#pragma unroll
+                for (int m = 0; m < NF; ++m) acc[m] = 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double x = xg[u4 + u];
+#pragma unroll
+                for (int m = 0; m < NF; ++m) {
+                    const double y = __builtin_fma(cb[m][0], x, z[m][0]);
+#pragma unroll
+                    for (int st = 0; st + 1 < ORD; ++st) z[m][st] = __builtin_fma(ca[m][st + 1], y, __builtin_fma(cb[m][st + 1], x, z[m][st + 1]));
+                    z[m][ORD - 1] = __builtin_fma(ca[m][ORD], y, cb[m][ORD] * x);
+                    if (!DEC) acc[m] = __builtin_fma(acc[m], decay[m], y * y);
+                    else if (!(u & 1)) yd[(u4 + u) / 2] = y;                  // decimate.py:41: samples 0, 2, 4, ...
+                }
+            }
+            if (energy && ((k + 4) & (elen - 1)) == 0 && valid) {
+                const long long blk = (s0 + k) >> a.eblock_shift;
+#pragma unroll
+                for (int m = 0; m < NF; ++m) {
+                    const int band = a.band_index[f0 + m];
+                    if (band >= 0) a.eblock[((size_t)c * a.nblocks + blk) * a.nbands + band] = alpha[m] * acc[m];
+                }
+            }
+        }
+        if (DEC && xn && valid) {
+#pragma unroll
+            for (int i = 0; i < G / 4; ++i) *(double2*)(xn + (k0 >> 1) + 2 * i) = double2{yd[2 * i], yd[2 * i + 1]};
+        }
+    }
+    if (valid && q == a.nchunks - 1) {                          // the stage's carried state: end of the channel's last chunk
+#pragma unroll
+        for (int m = 0; m < NF; ++m)
+#pragma unroll
+            for (int st = 0; st < ORD; ++st) a.state[((size_t)c * a.nfilt + f0 + m) * kStates + st] = z[m][st];
+    }
+}
+
+// grid: x = n_channels * ceil(nchunks / 64), y = filter groups (band filters kLaneBands at a time, then the decimator)
+template <bool F32>
+__global__ void __launch_bounds__(64) iir_lane_kernel(const IirStageArgs a, int n_band, int n_band_groups) {
+    const int g = blockIdx.y;
+    if (g < n_band_groups) {
+        const int f0 = g * kLaneBands, left = n_band - f0;
+        if (left >= 3) iir_lane_body<3, 4, false, F32>(a, f0);
+        else if (left == 2) iir_lane_body<2, 4, false, F32>(a, f0);
+        else iir_lane_body<1, 4, false, F32>(a, f0);
+    } else {
+        iir_lane_body<1, 12, true, F32>(a, a.dec_filter);
+    }
+}
+
+// The lane kernel serves the output pass of an energy-only time-parallel stage when the stage is whole chunks of whole
+// 4-sample groups on 16-byte boundaries, its filters are the bank's (4th-order bands in front of a 12th-order decimator)
+// and nobody asked for band signals; everything else takes the slot kernel.
+static bool lane_kernel_serves(const IirStageArgs& a, const int* orders) {
+    if (!a.fused || a.pass != 2 || a.y != nullptr || a.nchunks < 1 || a.n != (long long)a.nchunks * a.chunk) return false;
+    if (a.dec_filter != a.nfilt - 1 || orders[a.dec_filter] != 12) return false;
+    for (int f = 0; f < a.dec_filter; ++f)
+        if (orders[f] != 4 || a.band_index[f] < 0) return false;
+    if (a.eblock && (a.eblock_len < 4 || a.chunk % a.eblock_len != 0)) return false;
+    const bool vec_x = ((uintptr_t)a.x % 16 == 0) && (a.x_stride % (a.in_f32 ? 4 : 2) == 0);
+    const bool vec_xn = !a.xnext || (((uintptr_t)a.xnext % 16 == 0) && (a.xnext_stride % 2 == 0));
+    static const bool off = getenv("FRT_IIR_NO_LANE_KERNEL") != nullptr;      // A/B runs
+    return vec_x && vec_xn && !off;
+}
+
+static int launch_iir_lane(const IirStageArgs& a, int n_channels, hipStream_t stream) {
+    const int n_band = a.dec_filter, groups = (n_band + kLaneBands - 1) / kLaneBands;
+    const long long bx = (long long)n_channels * ((a.nchunks + 63) / 64);
+    FRT_REQUIRE(bx < (1ll << 31), "iir lane pass: too many wavefronts");
+    if (a.in_f32) hipLaunchKernelGGL(iir_lane_kernel<true>, dim3((unsigned)bx, groups + 1), dim3(64), 0, stream, a, n_band, groups);
+    else hipLaunchKernelGGL(iir_lane_kernel<false>, dim3((unsigned)bx, groups + 1), dim3(64), 0, stream, a, n_band, groups);
     FRT_HIP_CHECK(hipGetLastError());
     return FRT_OK;
 }
@@ -626,7 +809,8 @@ template <int NT>
 __device__ __forceinline__ double row_matvec(const double (&m)[kStates], double z) {
     double p[4] = {0.0, 0.0, 0.0, 0.0};
     static_assert(kStates == 16 && NT % 4 == 0 && NT <= 16, "one 16-lane row per filter");
-#define FRT_SCAN_TERM(T) if (T < NT) p[(T) & 3] += m[T] * dpp_row_bcast<T>(z);
+    // (contracted: the scan belongs to the time-parallel mode, which re-associates the recurrence anyway)
+#define FRT_SCAN_TERM(T) if (T < NT) p[(T) & 3] = __builtin_fma(m[T], dpp_row_bcast<T>(z), p[(T) & 3]);
     FRT_SCAN_TERM(0) FRT_SCAN_TERM(1) FRT_SCAN_TERM(2) FRT_SCAN_TERM(3) FRT_SCAN_TERM(4) FRT_SCAN_TERM(5)
     FRT_SCAN_TERM(6) FRT_SCAN_TERM(7) FRT_SCAN_TERM(8) FRT_SCAN_TERM(9) FRT_SCAN_TERM(10) FRT_SCAN_TERM(11)
     FRT_SCAN_TERM(12) FRT_SCAN_TERM(13) FRT_SCAN_TERM(14) FRT_SCAN_TERM(15)
@@ -634,36 +818,50 @@ __device__ __forceinline__ double row_matvec(const double (&m)[kStates], double 
     return (p[0] + p[1]) + (p[2] + p[3]);
 }
 
-// z_{q+1} = A^L z_q + s_q over the chunks of one (channel, filter): chunk_end (s_q, the zero-state end states
-// of pass 1) -> chunk_init (z_q).  One workgroup per (channel, filter), one 16-lane row per GROUP of `group`
-// consecutive chunks: (1) every row runs its group from a zero state, (2) row 0 chains the groups with
-// A^(L group), (3) every row replays its group from its true start.  3 x nchunks / rows serial steps instead
-// of nchunks.  power_l / power_g: [nfilt][16][16] row-major A^L and A^(L group).  The end states of eight chunks
-// are fetched at a time, so that no serial step waits for memory.
-constexpr int kScanRows = 32;
-static_assert(kScanRows == kScanRowsDecl, "one constant");
+// z_{q+1} = A^L z_q + s_q over the chunks of one (channel, filter): chunk_end (s_q, the zero-state end states of pass 1)
+// -> what the output pass needs to give every chunk its true initial state.
+//
+// The chunks are cut into scan ROWS of `group` consecutive chunks; a row is a 16-lane DPP row (lane s = state s) that runs
+// its chunks from a ZERO state and records, per chunk, the state it would start from had its row started at zero
+// (chunk_init) and its own end state E[r].  The true state at the start of row r is S[r] = E[r-1] + M S[r-1], M = A^(L group).
+// Rounds 1-2 chained that recurrence serially (row 0 of a single workgroup walked all 32 rows of a (channel, filter), the
+// rows being 128 chunks long: 160 serial steps of ~0.3 us, 52 us per stage with 32 of 256 CUs busy — after the lane-per-
+// chunk output pass the largest item of the bank).  But the filters are stable: the host picks `group` so that M^2 has
+// vanished in float64 (max |M^2| < 1e-20: L group >= ~3000 samples for the decimator's pole radius 0.9923), and then
+//     S[r] = E[r-1] + M E[r-2]          (r >= 2;  S[1] = E[0] + M S[0];  S[0] = the carried state)
+// is the same sum to the last bit that matters — no chain: every row depends on its two predecessors only, rows are a few
+// chunks long at the high-rate stages (4 chunks of 1024 samples) and all of them run at once.  A workgroup owns 30
+// consecutive rows and re-runs the two rows in front of them (halo) so that it needs nobody else's end states.
+// The output pass composes a chunk's initial state itself: chunk_init[q] + (A^L)^(q - row start) S[row]
+// (iir_stage_body, iir_lane_body).  power_l / power_g: [nfilt][16][16] row-major A^L and M.
+constexpr int kScanRows = 32;             // rows per workgroup: 2 halo + 30 owned
+constexpr int kScanOwned = kScanRows - 2;
 constexpr int kScanBatch = 8;
 
 template <int NT>
 __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l, const double* __restrict__ power_g,
                                               const double* __restrict__ state, const double* __restrict__ chunk_end,
-                                              double* __restrict__ chunk_init, double* __restrict__ group_start, int gid, int f, bool live,
-                                              int nchunks, int group, double (*gend)[kStates]) {
+                                              double* __restrict__ chunk_init, double* __restrict__ group_start, int gid, int seg, int f,
+                                              bool live, int nchunks, int group, int nrows, double (*gend)[kStates]) {
     const int row = threadIdx.x >> 4, s = threadIdx.x & 15;
+    const int r = seg * kScanOwned - 2 + row;                 // global row; rows 0 and 1 of the workgroup are the halo
+    const bool row_ok = r >= 0 && r < nrows;
+    const bool owned = row >= 2 && row_ok;
     double m[kStates];
 #pragma unroll
     for (int t = 0; t < kStates; ++t) m[t] = power_l[((size_t)f * kStates + s) * kStates + t];
     const double* ce = chunk_end + (size_t)gid * nchunks * kStates + s;
     double* ci = chunk_init + (size_t)gid * nchunks * kStates + s;
-    const int q0 = row * group;
-    const int q1 = (q0 + group) < nchunks ? (q0 + group) : nchunks;
-    // zero-state end states of chunks q .. q+7; lanes above the order stay 0 whatever the scratch holds
+    const int q0 = row_ok ? r * group : 0;
+    const int q1 = row_ok ? ((q0 + group) < nchunks ? (q0 + group) : nchunks) : 0;
+    // zero-state end states of chunks q .. q+7; lanes above the order stay 0 whatever the scratch holds.  (Summing the
+    // K-slices of the table product here instead of in a launch of their own was measured in round 3: slower — the rows'
+    // strided reads of four slices, the halo rows' included, cost more than the streaming kernel's 5 us.)
     auto end_states = [&](int q, double (&e)[kScanBatch]) {
 #pragma unroll
         for (int j = 0; j < kScanBatch; ++j) e[j] = (live && q + j < q1) ? ce[(size_t)(q + j) * kStates] : 0.0;
     };
-
-    // (1) the row's chunks from a zero state: chunk_init[q] = the state chunk q would start from, had its row started at 0
+    // the row's chunks from a zero state
     double z = 0.0;
     for (int q = q0; q < q1; q += kScanBatch) {
         double e[kScanBatch];
@@ -671,43 +869,40 @@ __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l
 #pragma unroll
         for (int j = 0; j < kScanBatch; ++j) {
             if (q + j < q1) {
-                ci[(size_t)(q + j) * kStates] = z;
+                if (owned) ci[(size_t)(q + j) * kStates] = z;
                 z = e[j] + row_matvec<NT>(m, z);
             }
         }
     }
     gend[row][s] = z;
     __syncthreads();
-    // (2) row 0 chains the rows with A^(L group): group_start[row] = the true state at the row's first chunk.  The output
-    // pass adds (A^L)^(q - q0) group_start[row] to chunk_init[q] itself (iir_stage_body) — replaying every row from its
-    // true start here, as this kernel used to, was 64 more of the 160 serial steps that are all its time.
-    if (row == 0) {
-        double mg[kStates];
+    // the true state at the start of every owned row, from its two predecessors (or the carried state next to the start)
+    double mg[kStates];
 #pragma unroll
-        for (int t = 0; t < kStates; ++t) mg[t] = power_g[((size_t)f * kStates + s) * kStates + t];
-        double zz = live ? state[(size_t)gid * kStates + s] : 0.0;
-        for (int r = 0; r < kScanRows; ++r) {
-            group_start[((size_t)gid * kScanRows + r) * kStates + s] = zz;
-            zz = gend[r][s] + row_matvec<NT>(mg, zz);
-        }
-    }
+    for (int t = 0; t < kStates; ++t) mg[t] = power_g[((size_t)f * kStates + s) * kStates + t];
+    const double s0 = live ? state[(size_t)gid * kStates + s] : 0.0;
+    const double e1 = (row >= 1 && r >= 1) ? gend[row - 1][s] : 0.0;
+    const double e2 = (row >= 2 && r >= 2) ? gend[row - 2][s] : (r == 1 ? s0 : 0.0);
+    const double start = r == 0 ? s0 : e1 + row_matvec<NT>(mg, e2);
+    if (owned) group_start[((size_t)gid * nrows + r) * kStates + s] = start;
 }
 
+// grid.x = (channel, filter) pairs x segments of kScanOwned rows
 __global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* __restrict__ power_l,
                                                                   const double* __restrict__ power_g,
                                                                   const double* __restrict__ state,
                                                                   const double* __restrict__ chunk_end,
                                                                   const int* __restrict__ order,
                                                                   double* __restrict__ chunk_init, double* __restrict__ group_start, int nfilt,
-                                                                  int nchunks, int group) {
+                                                                  int nchunks, int group, int nrows, int nseg) {
     __shared__ double gend[kScanRows][kStates];
-    const int gid = blockIdx.x;                               // (channel, filter) pair
+    const int gid = blockIdx.x / nseg, seg = blockIdx.x - gid * nseg;      // gid: (channel, filter) pair
     const int f = gid % nfilt;
     const int ord = order[f];                                 // uniform in the workgroup
     const bool live = (int)(threadIdx.x & 15) < ord;
-    if (ord <= 4) iir_scan_body<4>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, f, live, nchunks, group, gend);
-    else if (ord <= 12) iir_scan_body<12>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, f, live, nchunks, group, gend);
-    else iir_scan_body<16>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, f, live, nchunks, group, gend);
+    if (ord <= 4) iir_scan_body<4>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, seg, f, live, nchunks, group, nrows, gend);
+    else if (ord <= 12) iir_scan_body<12>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, seg, f, live, nchunks, group, nrows, gend);
+    else iir_scan_body<16>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, seg, f, live, nchunks, group, nrows, gend);
 }
 
 // sp_blk = E_blk + sp_{blk-1} * (1-alpha)^n  (exp_smoothing.py:52-54), optional dB + weighting.
@@ -1066,8 +1261,27 @@ static int stage_chunk(int chunk0, int j) {
     return c < 64 ? 64 : c;
 }
 
-// chunks a scan row chains (iir_scan_kernel)
-static int scan_group(int nchunks) { return (nchunks + kScanRows - 1) / kScanRows; }
+// Chunks per scan row of a stage (iir_scan_kernel): the smallest power of two g for which M = A^(L g) satisfies
+// max |M^2| < 1e-20 for every filter of the bank, so that a row's true initial state needs its two predecessors only.
+static int scan_group_for(const frt_octbank* h, int L, int nchunks) {
+    int g = 1;
+    std::vector<double> M(kStates * kStates);
+    for (; g < nchunks; g *= 2) {
+        double worst = 0.0;
+        for (int f = 0; f < h->nfilt; ++f) {
+            const double* ac = &h->h_coef[(size_t)f * kCoefStride + kMaxOrder + 1];
+            transition_power(ac, h->h_order[f], (long long)L * g, M.data());
+            for (int i = 0; i < kStates; ++i)
+                for (int j = 0; j < kStates; ++j) {
+                    double acc = 0.0;
+                    for (int k = 0; k < kStates; ++k) acc += M[i * kStates + k] * M[k * kStates + j];
+                    worst = std::fmax(worst, std::fabs(acc));
+                }
+        }
+        if (worst < 1e-20) break;
+    }
+    return g < nchunks ? g : (nchunks > 0 ? nchunks : 1);
+}
 
 // A^L and A^(L group) of every (stage, filter) for the current chunking of n input samples.
 static int ensure_powers(frt_octbank* h, int n) {
@@ -1076,13 +1290,15 @@ static int ensure_powers(frt_octbank* h, int n) {
     stage_lengths(n, len);
     const size_t per = (size_t)kNOctave * h->nfilt * kStates * kStates;
     std::vector<double> p(2 * per);
+    h->sgroup.assign(kNOctave, 1);
     for (int j = 0; j < kNOctave; ++j) {
         const int cj = stage_chunk(h->chunk0, j);
         const int nj = (len[j] + cj - 1) / cj;
+        h->sgroup[j] = scan_group_for(h, cj, nj);
         for (int f = 0; f < h->nfilt; ++f) {
             const double* ac = &h->h_coef[(size_t)f * kCoefStride + kMaxOrder + 1];
             transition_power(ac, h->h_order[f], cj, &p[((size_t)j * h->nfilt + f) * kStates * kStates]);
-            transition_power(ac, h->h_order[f], (long long)cj * scan_group(nj), &p[per + ((size_t)j * h->nfilt + f) * kStates * kStates]);
+            transition_power(ac, h->h_order[f], (long long)cj * h->sgroup[j], &p[per + ((size_t)j * h->nfilt + f) * kStates * kStates]);
         }
     }
     int rc = upload(h->power, p);
@@ -1095,14 +1311,16 @@ static int ensure_powers(frt_octbank* h, int n) {
         for (int j = 0; j < kNOctave; ++j) {
             const int cj = stage_chunk(h->chunk0, j);
             h->gpow_offset[j] = total;
-            total += (size_t)h->nfilt * scan_group((len[j] + cj - 1) / cj) * kStates * kStates;
+            total += (size_t)h->nfilt * h->sgroup[j] * kStates * kStates;
+            (void)cj;
         }
         std::vector<double> gp(total, 0.0);
         const int d = kStates;
         std::vector<long double> A(d * d), R(d * d), T(d * d);
         for (int j = 0; j < kNOctave; ++j) {
             const int cj = stage_chunk(h->chunk0, j);
-            const int group = scan_group((len[j] + cj - 1) / cj);
+            const int group = h->sgroup[j];
+            (void)cj;
             for (int f = 0; f < h->nfilt; ++f) {
                 const double* AL = &p[((size_t)j * h->nfilt + f) * kStates * kStates];        // A^L, rounded to double: the matrix the scan applies
                 for (int i = 0; i < d * d; ++i) A[i] = (long double)AL[i];
@@ -1184,8 +1402,7 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
         int rc = ensure_powers(h, n);
         if (rc) return rc;
         const size_t ws = (size_t)h->n_channels * h->nfilt * nchunks * kStates * sizeof(double);
-        if ((rc = h->chunk_end.reserve(ws * kMaxSlices)) || (rc = h->chunk_init.reserve(ws)) ||
-            (rc = h->gstart.reserve((size_t)h->n_channels * h->nfilt * kScanRows * kStates * sizeof(double))))
+        if ((rc = h->chunk_end.reserve(ws * kMaxSlices)) || (rc = h->chunk_init.reserve(ws)) || (rc = h->gstart.reserve(ws)))      // rows <= chunks
             return rc;
     }
     for (int j = 1; j < kNOctave; ++j) {
@@ -1214,7 +1431,8 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
         a.chunk_init = h->chunk_init.as<double>();
         a.group_start = h->gstart.as<double>();
         a.group_pow = parallel ? h->gpow.as<double>() + h->gpow_offset[j] : nullptr;
-        a.scan_group = parallel ? scan_group(a.nchunks) : 1;
+        a.scan_group = parallel ? h->sgroup[j] : 1;
+        a.scan_rows = (a.nchunks + a.scan_group - 1) / a.scan_group;
         a.y = d_y;
         a.y_cstride = y_cstride;
         for (int i = 0; i < h->bpo; ++i) {
@@ -1276,14 +1494,18 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
                                        h->chunk_end.as<double>(), slice_stride, n_slices, slice_stride);
             }
             const size_t per = (size_t)kNOctave * h->nfilt * kStates * kStates, off = (size_t)j * h->nfilt * kStates * kStates;
-            hipLaunchKernelGGL(iir_scan_kernel, dim3(h->n_channels * h->nfilt), dim3(kScanRows * 16), 0, h->stream,
+            const int nseg = (a.scan_rows + kScanOwned - 1) / kScanOwned;
+            hipLaunchKernelGGL(iir_scan_kernel, dim3((unsigned)(h->n_channels * h->nfilt * nseg)), dim3(kScanRows * 16), 0, h->stream,
                                h->power.as<double>() + off, h->power.as<double>() + per + off, a.state, h->chunk_end.as<double>(),
                                h->order.as<int>(), h->chunk_init.as<double>(), h->gstart.as<double>(), h->nfilt, a.nchunks,
-                               scan_group(a.nchunks));
+                               a.scan_group, a.scan_rows, nseg);
             a.pass = 2;
             static const bool exact_ops = getenv("FRT_IIR_EXACT_OPS") != nullptr;      // A/B runs
             a.fused = (d_y == nullptr && d_eblock != nullptr && !exact_ops) ? 1 : 0;
-            if ((rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream))) return rc;
+            a.n_channels = h->n_channels;
+            if (lane_kernel_serves(a, h->h_order.data())) rc = launch_iir_lane(a, h->n_channels, h->stream);
+            else rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream);
+            if (rc) return rc;
             a.fused = 0;
         }
         FRT_HIP_CHECK(hipGetLastError());
