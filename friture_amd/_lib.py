@@ -76,6 +76,8 @@ SIGNATURES = {
     "frt_specgram_push": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, POINTER(c_int), POINTER(c_int)]),
     "frt_specgram_reset": (c_int, [c_void_p]),
     "frt_colour_map": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "frt_screen_columns": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                   c_void_p, c_void_p]),
     "frt_exp_smooth_2d": (c_int, [c_void_p, c_int, c_double, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "frt_spectrum_post": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_int, c_double, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_int)]),

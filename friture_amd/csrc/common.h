@@ -85,4 +85,34 @@ int upload_if_changed(DeviceBuffer& buf, std::vector<T>& cache, const std::vecto
 
 int device_cu_count();
 
+// ---- packed staging of host arrays for the stateless entry points ------------------------------------------------------
+// The widget-facing functions of pipeline.hip / spectrum.hip take host arrays (the reference's numpy arguments).  Rounds
+// 1-2 gave every argument its own hipMalloc + blocking hipMemcpy + hipFree: 0.3 ms for a chain whose arithmetic is
+// microseconds.  A StageCall packs all host inputs of a call into ONE pinned block (one asynchronous upload), hands out
+// device addresses inside one device arena, and brings all outputs back with ONE download and ONE stream synchronisation.
+// The arena (pinned block, device block, stream) is a process-level object created on first use and never freed: no HIP
+// call runs from a static or thread-local destructor at exit.  Calls are serialised by its mutex (the reference calls from
+// one GUI thread).  Arguments that already live in device memory pass through untouched; a call with any such argument
+// launches on the null stream, which is ordered behind the (blocking) stream that produced them.
+class StageCall {
+  public:
+    StageCall();
+    ~StageCall();
+    // register arguments first (any order), then begin(); ids index ptr()
+    int add_in(const void* host_or_dev, size_t bytes);
+    int add_out(void* host_or_dev, size_t bytes);
+    int add_scratch(size_t bytes);                       // device-only workspace inside the arena
+    int begin();                                         // capacity, host -> pinned, one async upload
+    template <typename T>
+    T* ptr(int id) const { return reinterpret_cast<T*>(arg_[id].dev); }
+    hipStream_t stream() const { return launch_stream_; }
+    int finish();                                        // one async download of the outputs, one synchronisation, pinned -> host
+  private:
+    struct Arg { const void* src; void* dst; void* dev; size_t bytes, off; int kind; bool staged; };
+    std::vector<Arg> arg_;
+    size_t in_bytes_ = 0, out_bytes_ = 0, scratch_bytes_ = 0;
+    hipStream_t launch_stream_ = nullptr;
+    bool locked_ = false, any_device_ = false, zero_copy_ = false;
+};
+
 }  // namespace frt

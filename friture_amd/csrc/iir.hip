@@ -1668,9 +1668,38 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
     FRT_REQUIRE(dx == dout, "frt_octbank_energies: input and output must both be host or both be device memory");
     const void* d_x = x;
     float* d_out = energy_out;
+    // host buffers of the widget-sized calls travel through the handle's pinned blocks (from pageable memory the runtime
+    // stages the copy itself and blocks the caller)
+    const size_t xbytes = (size_t)h->n_channels * n * sizeof(float), obytes = ecount * sizeof(float);
+    const bool pinned = !dx && xbytes <= ((size_t)1 << 20) && obytes <= ((size_t)1 << 20);
     if (!dx) {
-        if ((rc = h->xin.reserve((size_t)h->n_channels * n * sizeof(float))) || (rc = h->eout.reserve(ecount * sizeof(float)))) return rc;
-        FRT_HIP_CHECK(hipMemcpyAsync(h->xin.ptr, x, (size_t)h->n_channels * n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        if ((rc = h->xin.reserve(xbytes)) || (rc = h->eout.reserve(obytes))) return rc;
+        if (pinned) {
+            if (xbytes > h->pin_in_bytes || obytes > h->pin_out_bytes) {
+                // captured graphs of frt_octbank_filter carry the pinned addresses: they are rebuilt at their next use
+                for (auto& e : h->graphs)
+                    if (e.exec) (void)hipGraphExecDestroy(e.exec);
+                h->graphs.clear();
+            }
+            if (xbytes > h->pin_in_bytes) {
+                FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+                if (h->pin_in) (void)hipHostFree(h->pin_in);
+                h->pin_in = nullptr;
+                h->pin_in_bytes = 0;
+                FRT_HIP_CHECK(hipHostMalloc(&h->pin_in, 2 * xbytes, hipHostMallocDefault));
+                h->pin_in_bytes = 2 * xbytes;
+            }
+            if (obytes > h->pin_out_bytes) {
+                FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+                if (h->pin_out) (void)hipHostFree(h->pin_out);
+                h->pin_out = nullptr;
+                h->pin_out_bytes = 0;
+                FRT_HIP_CHECK(hipHostMalloc(&h->pin_out, 2 * obytes, hipHostMallocDefault));
+                h->pin_out_bytes = 2 * obytes;
+            }
+            memcpy(h->pin_in, x, xbytes);
+        }
+        FRT_HIP_CHECK(hipMemcpyAsync(h->xin.ptr, pinned ? (const void*)h->pin_in : (const void*)x, xbytes, hipMemcpyHostToDevice, h->stream));
         d_x = h->xin.ptr;
         d_out = h->eout.as<float>();
     }
@@ -1694,8 +1723,9 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
     }
     FRT_HIP_CHECK(hipGetLastError());
     if (!dx) {
-        FRT_HIP_CHECK(hipMemcpyAsync(energy_out, d_out, ecount * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        FRT_HIP_CHECK(hipMemcpyAsync(pinned ? h->pin_out : (void*)energy_out, d_out, obytes, hipMemcpyDeviceToHost, h->stream));
         FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (pinned) memcpy(energy_out, h->pin_out, obytes);
     }
     return FRT_OK;
 }

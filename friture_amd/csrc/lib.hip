@@ -1,4 +1,6 @@
 // lib.hip — library-level entry points of libfriture_hip.so (init, errors, pointer queries).
+#include <mutex>
+
 #include "common.h"
 
 namespace frt {
@@ -32,6 +34,103 @@ int device_cu_count() {
         g_cu_count = prop.multiProcessorCount;
     if (g_cu_count <= 0) g_cu_count = 256;  // MI355X
     return g_cu_count;
+}
+
+// ---- StageCall (common.h) ---------------------------------------------------------------------------------------------
+namespace {
+struct StageArena {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    char* pin = nullptr;
+    char* dev = nullptr;
+    size_t pin_bytes = 0, dev_bytes = 0;
+};
+StageArena& arena() {
+    static StageArena* a = new StageArena();          // never destroyed: see common.h
+    return *a;
+}
+constexpr size_t kStageAlign = 256;
+constexpr size_t kZeroCopyMax = 256 * 1024;
+size_t stage_round(size_t n) { return (n + kStageAlign - 1) / kStageAlign * kStageAlign; }
+}  // namespace
+
+StageCall::StageCall() {
+    arena().mu.lock();
+    locked_ = true;
+}
+
+StageCall::~StageCall() {
+    if (locked_) arena().mu.unlock();
+}
+
+int StageCall::add_in(const void* p, size_t bytes) {
+    const bool dev = is_device_pointer(p);
+    any_device_ |= dev;
+    arg_.push_back({p, nullptr, dev ? const_cast<void*>(p) : nullptr, bytes, in_bytes_, 0, !dev});
+    if (!dev) in_bytes_ += stage_round(bytes);
+    return (int)arg_.size() - 1;
+}
+
+int StageCall::add_out(void* p, size_t bytes) {
+    const bool dev = is_device_pointer(p);
+    any_device_ |= dev;
+    arg_.push_back({nullptr, p, dev ? p : nullptr, bytes, out_bytes_, 1, !dev});
+    if (!dev) out_bytes_ += stage_round(bytes);
+    return (int)arg_.size() - 1;
+}
+
+int StageCall::add_scratch(size_t bytes) {
+    arg_.push_back({nullptr, nullptr, nullptr, bytes, scratch_bytes_, 2, true});
+    scratch_bytes_ += stage_round(bytes);
+    return (int)arg_.size() - 1;
+}
+
+int StageCall::begin() {
+    StageArena& a = arena();
+    if (!a.stream) FRT_HIP_CHECK(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
+    const size_t host_need = in_bytes_ + out_bytes_, dev_need = in_bytes_ + out_bytes_ + scratch_bytes_;
+    if (host_need > a.pin_bytes) {
+        FRT_HIP_CHECK(hipStreamSynchronize(a.stream));
+        if (a.pin) (void)hipHostFree(a.pin);
+        a.pin = nullptr;
+        a.pin_bytes = 0;
+        FRT_HIP_CHECK(hipHostMalloc((void**)&a.pin, 2 * host_need + 4096, hipHostMallocDefault));
+        a.pin_bytes = 2 * host_need + 4096;
+    }
+    if (dev_need > a.dev_bytes) {
+        FRT_HIP_CHECK(hipStreamSynchronize(a.stream));
+        if (a.dev) (void)hipFree(a.dev);
+        a.dev = nullptr;
+        a.dev_bytes = 0;
+        FRT_HIP_CHECK(hipMalloc((void**)&a.dev, 2 * dev_need + 4096));
+        a.dev_bytes = 2 * dev_need + 4096;
+    }
+    // Small calls (the widgets': a few KB per argument) skip the copy engines altogether: pinned host memory is mapped into
+    // the device's address space, the kernel reads its inputs from the pinned block and writes its outputs there — one PCIe
+    // round trip inside the kernel instead of two DMA set-ups around it (about half of such a call's wall time).
+    zero_copy_ = host_need <= kZeroCopyMax;
+    // device arena: [inputs][outputs][scratch]; pinned block: [inputs][outputs]
+    for (Arg& g : arg_) {
+        if (!g.staged) continue;
+        const size_t base = g.kind == 0 ? 0 : g.kind == 1 ? in_bytes_ : in_bytes_ + out_bytes_;
+        g.dev = (zero_copy_ && g.kind != 2) ? a.pin + base + g.off : a.dev + base + g.off;
+        if (g.kind == 0 && g.bytes) memcpy(a.pin + g.off, g.src, g.bytes);
+    }
+    // device-resident arguments were produced on a stream this call does not know: the null stream waits for the blocking ones
+    launch_stream_ = any_device_ ? nullptr : a.stream;
+    if (in_bytes_ && !zero_copy_) FRT_HIP_CHECK(hipMemcpyAsync(a.dev, a.pin, in_bytes_, hipMemcpyHostToDevice, launch_stream_));
+    return FRT_OK;
+}
+
+int StageCall::finish() {
+    StageArena& a = arena();
+    FRT_HIP_CHECK(hipGetLastError());
+    if (out_bytes_ && !zero_copy_)
+        FRT_HIP_CHECK(hipMemcpyAsync(a.pin + in_bytes_, a.dev + in_bytes_, out_bytes_, hipMemcpyDeviceToHost, launch_stream_));
+    FRT_HIP_CHECK(hipStreamSynchronize(launch_stream_));
+    for (const Arg& g : arg_)
+        if (g.staged && g.kind == 1 && g.bytes) memcpy(g.dst, a.pin + in_bytes_ + g.off, g.bytes);
+    return FRT_OK;
 }
 
 }  // namespace frt

@@ -81,41 +81,6 @@ __global__ void __launch_bounds__(64) exp_smooth_kernel(const double* __restrict
     if (threadIdx.x == 0) out[r] = alpha * acc + previous[r] * decay;
 }
 
-struct Staged {
-    // host <-> device staging for the stateless entry points below
-    std::vector<DeviceBuffer> bufs;
-    ~Staged() {
-        for (auto& b : bufs) b.release();
-    }
-    template <typename T>
-    int in(const T* host, size_t count, const T** dev) {
-        if (is_device_pointer(host)) {
-            *dev = host;
-            return FRT_OK;
-        }
-        bufs.emplace_back();
-        int rc = bufs.back().reserve(count * sizeof(T));
-        if (rc) return rc;
-        FRT_HIP_CHECK(hipMemcpy(bufs.back().ptr, host, count * sizeof(T), hipMemcpyHostToDevice));
-        *dev = bufs.back().as<T>();
-        return FRT_OK;
-    }
-    template <typename T>
-    int out(T* host, size_t count, T** dev, bool* staged) {
-        *staged = !is_device_pointer(host);
-        if (!*staged) {
-            *dev = host;
-            return FRT_OK;
-        }
-        bufs.emplace_back();
-        int rc = bufs.back().reserve(count * sizeof(T));
-        if (rc) return rc;
-        *dev = bufs.back().as<T>();
-        return FRT_OK;
-    }
-};
-
-
 // ---- Fourier resampling of a column (scipy_resample.py:51-141 as used by Online_Linear_2D_resampler.set_height,
 // online_linear_2D_resampler.py:45-55): X = fft(x); keep the N = min(n, m) lowest frequencies; y = ifft(Y) * m / n.
 // A resize event, n and m a few hundred to a few thousand and of any factorisation (screen heights): two direct DFT
@@ -188,27 +153,15 @@ extern "C" int frt_freq_resample(const double* freq, int n_bins, const double* t
             den[h] = freq[lo + 1] - freq[lo];
         }
     }
-    Staged st;
-    const double* d_data;
-    double* d_out;
-    bool staged;
+    StageCall st;
+    const int i_data = st.add_in(data, (size_t)n_bins * n_cols * sizeof(double)), i_j = st.add_in(j.data(), (size_t)height * sizeof(int)),
+              i_dx = st.add_in(dx.data(), (size_t)height * sizeof(double)), i_den = st.add_in(den.data(), (size_t)height * sizeof(double)),
+              i_out = st.add_out(out, (size_t)height * n_cols * sizeof(double));
     int rc;
-    if ((rc = st.in(data, (size_t)n_bins * n_cols, &d_data)) || (rc = st.out(out, (size_t)height * n_cols, &d_out, &staged))) return rc;
-    DeviceBuffer dj, ddx, dden;
-    if ((rc = upload(dj, j)) || (rc = upload(ddx, dx)) || (rc = upload(dden, den))) return rc;
-    hipLaunchKernelGGL(freq_resample_kernel, dim3((n_cols + 63) / 64, height), dim3(64), 0, nullptr, d_data, n_bins, n_cols,
-                       dj.as<int>(), ddx.as<double>(), dden.as<double>(), height, d_out);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = staged ? hipMemcpy(out, d_out, (size_t)height * n_cols * sizeof(double), hipMemcpyDeviceToHost)
-                                    : hipDeviceSynchronize();
-    dj.release();
-    ddx.release();
-    dden.release();
-    if (e != hipSuccess) {
-        set_last_error("frt_freq_resample: %s", hipGetErrorString(e));
-        return FRT_ERR_HIP;
-    }
-    return FRT_OK;
+    if ((rc = st.begin())) return rc;
+    hipLaunchKernelGGL(freq_resample_kernel, dim3((n_cols + 63) / 64, height), dim3(64), 0, st.stream(), st.ptr<const double>(i_data), n_bins,
+                       n_cols, st.ptr<const int>(i_j), st.ptr<const double>(i_dx), st.ptr<const double>(i_den), height, st.ptr<double>(i_out));
+    return st.finish();
 }
 
 extern "C" int frt_time_resample(const double* data, const double* old, int height, int n_cols, const int* src_col,
@@ -218,45 +171,32 @@ extern "C" int frt_time_resample(const double* data, const double* old, int heig
     FRT_REQUIRE(data && old && src_col && a && out, "frt_time_resample: null buffer");
     FRT_REQUIRE(!is_device_pointer(src_col) && !is_device_pointer(a), "frt_time_resample: src_col/a are host tables");
     for (int p = 0; p < n_out; ++p) FRT_REQUIRE(src_col[p] >= 0 && src_col[p] < n_cols, "frt_time_resample: source column out of range");
-    Staged st;
-    const double *d_data, *d_old;
-    const int* d_src;
-    const double* d_a;
-    double* d_out;
-    bool staged;
+    StageCall st;
+    const int i_data = st.add_in(data, (size_t)height * n_cols * sizeof(double)), i_old = st.add_in(old, (size_t)height * sizeof(double)),
+              i_src = st.add_in(src_col, (size_t)n_out * sizeof(int)), i_a = st.add_in(a, (size_t)n_out * sizeof(double)),
+              i_out = st.add_out(out, (size_t)height * n_out * sizeof(double));
     int rc;
-    if ((rc = st.in(data, (size_t)height * n_cols, &d_data)) || (rc = st.in(old, (size_t)height, &d_old)) ||
-        (rc = st.in(src_col, (size_t)n_out, &d_src)) || (rc = st.in(a, (size_t)n_out, &d_a)) ||
-        (rc = st.out(out, (size_t)height * n_out, &d_out, &staged)))
-        return rc;
-    hipLaunchKernelGGL(time_resample_kernel, dim3((n_out + 63) / 64, height), dim3(64), 0, nullptr, d_data, d_old, height, n_cols,
-                       d_src, d_a, n_out, d_out);
-    FRT_HIP_CHECK(hipGetLastError());
-    if (staged) FRT_HIP_CHECK(hipMemcpy(out, d_out, (size_t)height * n_out * sizeof(double), hipMemcpyDeviceToHost));
-    else FRT_HIP_CHECK(hipDeviceSynchronize());
-    return FRT_OK;
+    if ((rc = st.begin())) return rc;
+    hipLaunchKernelGGL(time_resample_kernel, dim3((n_out + 63) / 64, height), dim3(64), 0, st.stream(), st.ptr<const double>(i_data),
+                       st.ptr<const double>(i_old), height, n_cols, st.ptr<const int>(i_src), st.ptr<const double>(i_a), n_out,
+                       st.ptr<double>(i_out));
+    return st.finish();
 }
 
 extern "C" int frt_colour_map(const uint32_t* lut256, const double* values, int64_t count, uint32_t* out) {
     FRT_REQUIRE(lut256 && count >= 0, "frt_colour_map: bad arguments");
     if (count == 0) return FRT_OK;
     FRT_REQUIRE(values && out, "frt_colour_map: null buffer");
-    Staged st;
-    const uint32_t* d_lut;
-    const double* d_v;
-    uint32_t* d_out;
-    bool staged;
+    StageCall st;
+    const int i_lut = st.add_in(lut256, 256 * sizeof(uint32_t)), i_v = st.add_in(values, (size_t)count * sizeof(double)),
+              i_out = st.add_out(out, (size_t)count * sizeof(uint32_t));
     int rc;
-    if ((rc = st.in(lut256, (size_t)256, &d_lut)) || (rc = st.in(values, (size_t)count, &d_v)) ||
-        (rc = st.out(out, (size_t)count, &d_out, &staged)))
-        return rc;
+    if ((rc = st.begin())) return rc;
     long long blocks = (count + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(colour_map_kernel, dim3((unsigned)blocks), dim3(256), 0, nullptr, d_lut, d_v, (long long)count, d_out);
-    FRT_HIP_CHECK(hipGetLastError());
-    if (staged) FRT_HIP_CHECK(hipMemcpy(out, d_out, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    else FRT_HIP_CHECK(hipDeviceSynchronize());
-    return FRT_OK;
+    hipLaunchKernelGGL(colour_map_kernel, dim3((unsigned)blocks), dim3(256), 0, st.stream(), st.ptr<const uint32_t>(i_lut),
+                       st.ptr<const double>(i_v), (long long)count, st.ptr<uint32_t>(i_out));
+    return st.finish();
 }
 
 extern "C" int frt_exp_smooth_2d(const double* kernel, int nk, double alpha, const double* data, int nf, int nt, int64_t row_stride,
@@ -279,20 +219,14 @@ extern "C" int frt_exp_smooth_2d(const double* kernel, int nk, double alpha, con
         FRT_HIP_CHECK(hipMemcpy(out, previous, (size_t)nf * sizeof(double), hipMemcpyDefault));
         return FRT_OK;
     }
-    Staged st;
-    const double *d_k, *d_data = nullptr, *d_prev;
-    double* d_out;
-    bool staged;
+    StageCall st;
+    const int i_k = st.add_in(kernel + (nk - n), (size_t)n * sizeof(double)), i_prev = st.add_in(previous, (size_t)nf * sizeof(double)),
+              i_data = st.add_in(data, ((size_t)(nf - 1) * row_stride + nt) * sizeof(double)), i_out = st.add_out(out, (size_t)nf * sizeof(double));
     int rc;
-    if ((rc = st.in(kernel + (nk - n), (size_t)n, &d_k)) || (rc = st.in(previous, (size_t)nf, &d_prev)) ||
-        (rc = st.out(out, (size_t)nf, &d_out, &staged)) || (rc = st.in(data, (size_t)(nf - 1) * row_stride + nt, &d_data)))
-        return rc;
-    hipLaunchKernelGGL(exp_smooth_kernel, dim3(nf), dim3(64), 0, nullptr, d_data, (long long)row_stride, n, d_k, alpha, decay,
-                       d_prev, d_out, nf);
-    FRT_HIP_CHECK(hipGetLastError());
-    if (staged) FRT_HIP_CHECK(hipMemcpy(out, d_out, (size_t)nf * sizeof(double), hipMemcpyDeviceToHost));
-    else FRT_HIP_CHECK(hipDeviceSynchronize());
-    return FRT_OK;
+    if ((rc = st.begin())) return rc;
+    hipLaunchKernelGGL(exp_smooth_kernel, dim3(nf), dim3(64), 0, st.stream(), st.ptr<const double>(i_data), (long long)row_stride, n,
+                       st.ptr<const double>(i_k), alpha, decay, st.ptr<const double>(i_prev), st.ptr<double>(i_out), nf);
+    return st.finish();
 }
 
 
@@ -314,26 +248,15 @@ extern "C" int frt_fourier_resample(const double* x, int n, int count, double* y
         wm[2 * r] = (double)cosl(pi2 * r / m);
         wm[2 * r + 1] = (double)sinl(pi2 * r / m);
     }
-    Staged st;
-    const double* d_x;
-    double* d_y;
-    bool staged;
+    StageCall st;
+    const int i_x = st.add_in(x, (size_t)count * n * sizeof(double)), i_wn = st.add_in(wn.data(), wn.size() * sizeof(double)),
+              i_wm = st.add_in(wm.data(), wm.size() * sizeof(double)), i_X = st.add_scratch((size_t)count * N * 2 * sizeof(double)),
+              i_y = st.add_out(y, (size_t)count * m * sizeof(double));
     int rc;
-    if ((rc = st.in(x, (size_t)count * n, &d_x)) || (rc = st.out(y, (size_t)count * m, &d_y, &staged))) return rc;
-    DeviceBuffer dwn, dwm, dX;
-    if ((rc = upload(dwn, wn)) || (rc = upload(dwm, wm)) || (rc = dX.reserve((size_t)count * N * 2 * sizeof(double)))) return rc;
-    hipLaunchKernelGGL(fourier_bins_kernel, dim3((N + 255) / 256, count), dim3(256), 0, nullptr, d_x, n, count, npos, nneg,
-                       dwn.as<double>(), dX.as<double>());
-    hipLaunchKernelGGL(fourier_synth_kernel, dim3((m + 255) / 256, count), dim3(256), 0, nullptr, dX.as<double>(), n, m, count, npos,
-                       nneg, dwm.as<double>(), d_y);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = staged ? hipMemcpy(y, d_y, (size_t)count * m * sizeof(double), hipMemcpyDeviceToHost) : hipDeviceSynchronize();
-    dwn.release();
-    dwm.release();
-    dX.release();
-    if (e != hipSuccess) {
-        set_last_error("frt_fourier_resample: %s", hipGetErrorString(e));
-        return FRT_ERR_HIP;
-    }
-    return FRT_OK;
+    if ((rc = st.begin())) return rc;
+    hipLaunchKernelGGL(fourier_bins_kernel, dim3((N + 255) / 256, count), dim3(256), 0, st.stream(), st.ptr<const double>(i_x), n, count, npos,
+                       nneg, st.ptr<const double>(i_wn), st.ptr<double>(i_X));
+    hipLaunchKernelGGL(fourier_synth_kernel, dim3((m + 255) / 256, count), dim3(256), 0, st.stream(), st.ptr<const double>(i_X), n, m, count,
+                       npos, nneg, st.ptr<const double>(i_wm), st.ptr<double>(i_y));
+    return st.finish();
 }

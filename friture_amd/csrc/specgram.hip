@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(64) screen_columns_kernel(const double* __rest
                                                             const int* __restrict__ src_tab, const double* __restrict__ a_tab,
                                                             const ColumnTable inl, int n_out,
                                                             const uint32_t* __restrict__ lut, uint32_t* __restrict__ pixels,
-                                                            int pixel_stride) {
+                                                            int pixel_stride, int flip) {
     const int* src = src_tab ? src_tab : inl.src;
     const double* a = a_tab ? a_tab : inl.a;
     const int p = blockIdx.x * 64 + threadIdx.x;
@@ -90,12 +90,69 @@ __global__ void __launch_bounds__(64) screen_columns_kernel(const double* __rest
     const double w = a[p];
     double v = cur * (1.0 - w) + prev * w;               // linear_interp.py:57-60
     v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);             // numpy.clip (NaN falls through to the cast like numpy's)
-    pixels[(size_t)(height - 1 - h) * pixel_stride + p] = lut[(int)(v * 255.0)];
+    pixels[(size_t)(flip ? height - 1 - h : h) * pixel_stride + p] = lut[(int)(v * 255.0)];
+}
+
+// numpy.interp's interval search for the screen rows (largest j with freq[j] <= x; -1 / nb outside the table)
+static void interval_search(const double* freq, int nb, const double* targets, int height, int* j, double* dx, double* den) {
+    for (int r = 0; r < height; ++r) {
+        const double x = targets[r];
+        dx[r] = 0.0;
+        den[r] = 1.0;
+        if (!(x >= freq[0])) { j[r] = -1; continue; }
+        if (x > freq[nb - 1]) { j[r] = nb; continue; }
+        int lo = 0, hi = nb;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) / 2;
+            if (freq[mid] <= x) lo = mid; else hi = mid;
+        }
+        j[r] = lo;
+        if (lo < nb - 1) {
+            dx[r] = x - freq[lo];
+            den[r] = freq[lo + 1] - freq[lo];
+        }
+    }
 }
 
 }  // namespace frt
 
 using namespace frt;
+
+// The three blocks of the spectrogram's Transform_Pipeline (friture/spectrogram.py:62-68: Frequency_Resampler ->
+// Online_Linear_2D_resampler -> Color_Transform) as ONE call on host arrays: what Transform_Pipeline.push of the drop-in
+// package does when its blocks are those three (friture_amd/signal/transform_pipeline.py) — three staged calls become one.
+// norm: [n_cols][nb] (frame-major: column c of the reference's (bins, columns) block is row c); old_in: the time resampler's
+// carried column (already on the screen rows); src / a: its (source column, weight) pairs for the n_out pixel columns of this
+// push (the scalar index recurrence stays with the caller, as in the reference).  pixels_out: [height][n_out], row 0 =
+// lowest frequency like the reference's block (the widget flips later); old_out: the last column on the screen rows.
+extern "C" int frt_screen_columns(const double* norm, int nb, int n_cols, const double* freq, const double* targets, int height,
+                                  const double* old_in, const int* src, const double* a, int n_out, const uint32_t* lut256,
+                                  uint32_t* pixels_out, double* old_out) {
+    FRT_REQUIRE(norm && freq && targets && old_in && lut256 && old_out && nb >= 1 && n_cols >= 1 && height >= 1 && n_out >= 0,
+                "frt_screen_columns: bad arguments");
+    FRT_REQUIRE(n_out == 0 || (src && a && pixels_out), "frt_screen_columns: null buffer");
+    for (int p = 0; p < n_out; ++p) FRT_REQUIRE(src[p] >= 0 && src[p] < n_cols, "frt_screen_columns: source column out of range");
+    std::vector<int> j(height);
+    std::vector<double> dx(height), den(height);
+    interval_search(freq, nb, targets, height, j.data(), dx.data(), den.data());
+    const int cols_alloc = n_out > 0 ? n_out : 1;
+    StageCall st;
+    const int i_norm = st.add_in(norm, (size_t)n_cols * nb * sizeof(double)), i_j = st.add_in(j.data(), (size_t)height * sizeof(int)),
+              i_dx = st.add_in(dx.data(), (size_t)height * sizeof(double)), i_den = st.add_in(den.data(), (size_t)height * sizeof(double)),
+              i_old = st.add_in(old_in, (size_t)height * sizeof(double)), i_lut = st.add_in(lut256, 256 * sizeof(uint32_t)),
+              i_src = st.add_in(src ? src : j.data(), (size_t)cols_alloc * sizeof(int)),
+              i_a = st.add_in(a ? a : dx.data(), (size_t)cols_alloc * sizeof(double)),
+              i_pix = n_out > 0 ? st.add_out(pixels_out, (size_t)height * n_out * sizeof(uint32_t)) : st.add_scratch((size_t)height * sizeof(uint32_t)),
+              i_oldo = st.add_out(old_out, (size_t)height * sizeof(double));
+    int rc;
+    if ((rc = st.begin())) return rc;
+    ColumnTable none{};
+    hipLaunchKernelGGL(screen_columns_kernel, dim3((cols_alloc + 63) / 64, height), dim3(64), 0, st.stream(), st.ptr<const double>(i_norm), nb,
+                       n_cols, st.ptr<const int>(i_j), st.ptr<const double>(i_dx), st.ptr<const double>(i_den), height,
+                       st.ptr<const double>(i_old), st.ptr<double>(i_oldo), st.ptr<const int>(i_src), st.ptr<const double>(i_a), none, n_out,
+                       st.ptr<const uint32_t>(i_lut), st.ptr<uint32_t>(i_pix), cols_alloc, 0);
+    return st.finish();
+}
 
 struct frt_specgram {
     int fft_size = 0, hop = 0, nb = 0;
@@ -185,21 +242,7 @@ extern "C" int frt_specgram_set_screen(frt_specgram* h, const double* freq, cons
     const int nb = h->nb;
     std::vector<int> j(height);
     std::vector<double> dx(height, 0.0), den(height, 1.0);
-    for (int r = 0; r < height; ++r) {                           // numpy.interp's interval search (largest j with freq[j] <= x)
-        const double x = targets[r];
-        if (!(x >= freq[0])) { j[r] = -1; continue; }
-        if (x > freq[nb - 1]) { j[r] = nb; continue; }
-        int lo = 0, hi = nb;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) / 2;
-            if (freq[mid] <= x) lo = mid; else hi = mid;
-        }
-        j[r] = lo;
-        if (lo < nb - 1) {
-            dx[r] = x - freq[lo];
-            den[r] = freq[lo + 1] - freq[lo];
-        }
-    }
+    interval_search(freq, nb, targets, height, j.data(), dx.data(), den.data());
     int rc;
     if ((rc = upload(h->jidx, j)) || (rc = upload(h->dx, dx)) || (rc = upload(h->den, den))) return rc;
     DeviceBuffer& cur = h->old_is_a ? h->old_a : h->old_b;
@@ -364,7 +407,7 @@ extern "C" int frt_specgram_push(frt_specgram* h, const double* chunk, int n, ui
     hipLaunchKernelGGL(screen_columns_kernel, dim3((cols_alloc + 63) / 64, h->height), dim3(64), 0, h->stream, h->norm.as<double>(), h->nb,
                        realizable, h->jidx.as<int>(), h->dx.as<double>(), h->den.as<double>(), h->height, old_in.as<double>(),
                        old_out.as<double>(), inline_cols ? nullptr : h->src.as<int>(), inline_cols ? nullptr : h->a.as<double>(), inl, n_out,
-                       h->lut.as<uint32_t>(), h->pixels.as<uint32_t>(), n_out > 0 ? n_out : 1);
+                       h->lut.as<uint32_t>(), h->pixels.as<uint32_t>(), n_out > 0 ? n_out : 1, 1);
     FRT_HIP_CHECK(hipGetLastError());
     h->old_is_a = !h->old_is_a;
     if (n_out > 0 && pixels_out) {

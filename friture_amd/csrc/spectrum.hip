@@ -102,60 +102,33 @@ extern "C" int frt_spectrum_post(const void* psd, int psd_is_f32, int n_frames, 
                     (!ref_smoothed || dev == is_device_pointer(ref_smoothed)),
                 "frt_spectrum_post: buffers must all be host or all be device memory");
     const size_t esz = psd_is_f32 ? 4 : 8;
-    // device scratch of this stateless entry point: grow-only, per calling thread (it used to be allocated and freed on
-    // every call — the spectrum widget calls once per audio chunk)
-    struct Scratch {
-        DeviceBuffer psd, prev, w, ref, sm, db, k, idx;
-        ~Scratch() { for (DeviceBuffer* b : {&psd, &prev, &w, &ref, &sm, &db, &k, &idx}) b->release(); }
-    };
-    static thread_local Scratch scratch;
-    DeviceBuffer &b_psd = scratch.psd, &b_prev = scratch.prev, &b_w = scratch.w, &b_ref = scratch.ref, &b_sm = scratch.sm,
-                 &b_db = scratch.db, &b_k = scratch.k, &b_idx = scratch.idx;
-    auto release = [&]() {};
-    const void* d_psd = psd;
-    const double *d_prev = previous, *d_w = weight_db, *d_ref = ref_smoothed;
-    double *d_sm = smoothed_out, *d_db = db_out;
-    int rc = FRT_OK;
-    hipError_t e = hipSuccess;
-    std::vector<double> ktail(kernel + (nk - n), kernel + nk);
-    if (ktail.empty()) ktail.push_back(0.0);
-    if ((rc = upload(b_k, ktail)) || (rc = b_idx.reserve(2 * sizeof(int)))) { release(); return rc; }
-    if (!dev) {
-        const size_t pbytes = n_frames ? ((size_t)(n_frames - 1) * frame_stride + n_bins) * esz : 0;
-        if ((pbytes && (rc = b_psd.reserve(pbytes))) || (rc = b_prev.reserve(n_bins * 8)) || (rc = b_sm.reserve(n_bins * 8)) ||
-            (rc = b_db.reserve(n_bins * 8)) || (weight_db && (rc = b_w.reserve(n_bins * 8))) ||
-            (ref_smoothed && (rc = b_ref.reserve(n_bins * 8)))) { release(); return rc; }
-        if (pbytes) e = hipMemcpy(b_psd.ptr, psd, pbytes, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(b_prev.ptr, previous, n_bins * 8, hipMemcpyHostToDevice);
-        if (e == hipSuccess && weight_db) e = hipMemcpy(b_w.ptr, weight_db, n_bins * 8, hipMemcpyHostToDevice);
-        if (e == hipSuccess && ref_smoothed) e = hipMemcpy(b_ref.ptr, ref_smoothed, n_bins * 8, hipMemcpyHostToDevice);
-        d_psd = b_psd.ptr;
-        d_prev = b_prev.as<double>();
-        d_w = weight_db ? b_w.as<double>() : nullptr;
-        d_ref = ref_smoothed ? b_ref.as<double>() : nullptr;
-        d_sm = b_sm.as<double>();
-        d_db = b_db.as<double>();
-    }
-    if (e == hipSuccess) {
-        if (psd_is_f32)
-            hipLaunchKernelGGL(spectrum_post_kernel<float>, dim3(1), dim3(kPostThreads), 0, nullptr, (const float*)d_psd,
-                               (long long)frame_stride, n, n_bins, b_k.as<double>(), alpha, decay, d_prev, d_w, d_ref, d_sm, d_db,
-                               b_idx.as<int>());
-        else
-            hipLaunchKernelGGL(spectrum_post_kernel<double>, dim3(1), dim3(kPostThreads), 0, nullptr, (const double*)d_psd,
-                               (long long)frame_stride, n, n_bins, b_k.as<double>(), alpha, decay, d_prev, d_w, d_ref, d_sm, d_db,
-                               b_idx.as<int>());
-        e = hipGetLastError();
-    }
+    // all host arguments in one pinned block, one upload, one download (StageCall, common.h): seven blocking copies and a
+    // thread-local set of device buffers until round 3
+    StageCall st;
+    const size_t pbytes = n_frames ? ((size_t)(n_frames - 1) * frame_stride + n_bins) * esz : 0;
+    const size_t vbytes = (size_t)n_bins * sizeof(double);
+    const double zero = 0.0;
+    const int i_k = n > 0 ? st.add_in(kernel + (nk - n), (size_t)n * sizeof(double)) : st.add_in(&zero, sizeof(double));
+    const int i_psd = pbytes ? st.add_in(psd, pbytes) : -1;
+    const int i_prev = st.add_in(previous, vbytes);
+    const int i_w = weight_db ? st.add_in(weight_db, vbytes) : -1;
+    const int i_ref = ref_smoothed ? st.add_in(ref_smoothed, vbytes) : -1;
+    const int i_sm = st.add_out(smoothed_out, vbytes), i_db = st.add_out(db_out, vbytes);
     int idx[2] = {0, 0};
-    if (e == hipSuccess) e = hipMemcpy(idx, b_idx.ptr, sizeof(idx), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && !dev) e = hipMemcpy(smoothed_out, d_sm, n_bins * 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && !dev) e = hipMemcpy(db_out, d_db, n_bins * 8, hipMemcpyDeviceToHost);
-    release();
-    if (e != hipSuccess) {
-        set_last_error("frt_spectrum_post: %s", hipGetErrorString(e));
-        return FRT_ERR_HIP;
-    }
+    const int i_idx = st.add_out(idx, sizeof(idx));
+    int rc;
+    if ((rc = st.begin())) return rc;
+    const double* d_w = i_w >= 0 ? st.ptr<const double>(i_w) : nullptr;
+    const double* d_ref = i_ref >= 0 ? st.ptr<const double>(i_ref) : nullptr;
+    if (psd_is_f32)
+        hipLaunchKernelGGL(spectrum_post_kernel<float>, dim3(1), dim3(kPostThreads), 0, st.stream(),
+                           i_psd >= 0 ? st.ptr<const float>(i_psd) : nullptr, (long long)frame_stride, n, n_bins, st.ptr<const double>(i_k),
+                           alpha, decay, st.ptr<const double>(i_prev), d_w, d_ref, st.ptr<double>(i_sm), st.ptr<double>(i_db), st.ptr<int>(i_idx));
+    else
+        hipLaunchKernelGGL(spectrum_post_kernel<double>, dim3(1), dim3(kPostThreads), 0, st.stream(),
+                           i_psd >= 0 ? st.ptr<const double>(i_psd) : nullptr, (long long)frame_stride, n, n_bins, st.ptr<const double>(i_k),
+                           alpha, decay, st.ptr<const double>(i_prev), d_w, d_ref, st.ptr<double>(i_sm), st.ptr<double>(i_db), st.ptr<int>(i_idx));
+    if ((rc = st.finish())) return rc;
     if (peak_index_out) *peak_index_out = idx[0];
     if (pitch_index_out) *pitch_index_out = idx[1];
     return FRT_OK;

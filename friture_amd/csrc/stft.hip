@@ -694,6 +694,8 @@ struct frt_stft {
     bool has_weight = false, has_lut = false;
     double spec_min = -140.0, spec_max = 0.0;
     DeviceBuffer stage_in, stage_out;
+    char* pin = nullptr;          // pinned staging of the host-buffer path: [input][output]
+    size_t pin_bytes = 0;
 };
 
 template <typename T>
@@ -766,6 +768,7 @@ extern "C" void frt_stft_destroy(frt_stft* h) {
     h->lut.release();
     h->stage_in.release();
     h->stage_out.release();
+    if (h->pin) (void)hipHostFree(h->pin);
     delete h;
 }
 
@@ -970,16 +973,38 @@ extern "C" int frt_stft_run(frt_stft* h, int kind, const void* x, int64_t T, int
     const size_t out_esz = (kind == FRT_STFT_IMAGE) ? 4 : in_esz;
     if (dx) return stft_launch(h, kind, x, x_stride, out, F, h->stream);
 
-    // host buffers: stage through device memory, return when the result is back
+    // host buffers: stage through device memory, return when the result is back.  Small calls (the widgets' one frame at a
+    // time: audioproc.analyzelive) go through the handle's pinned block — from pageable memory the runtime stages every
+    // copy itself and blocks the caller twice; large ones are copied in place.
     const size_t in_bytes = (size_t)h->n_channels * x_stride * in_esz;
     const size_t out_bytes = (size_t)h->n_channels * F * nb * out_esz;
     int rc;
     if ((rc = h->stage_in.reserve(in_bytes))) return rc;
     if ((rc = h->stage_out.reserve(out_bytes))) return rc;
-    FRT_HIP_CHECK(hipMemcpyAsync(h->stage_in.ptr, x, in_bytes, hipMemcpyHostToDevice, h->stream));
+    const size_t in_pad = (in_bytes + 255) / 256 * 256;
+    const bool pinned = in_pad + out_bytes <= (size_t)1 << 22;
+    if (pinned && in_pad + out_bytes > h->pin_bytes) {
+        FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (h->pin) (void)hipHostFree(h->pin);
+        h->pin = nullptr;
+        h->pin_bytes = 0;
+        FRT_HIP_CHECK(hipHostMalloc((void**)&h->pin, 2 * (in_pad + out_bytes), hipHostMallocDefault));
+        h->pin_bytes = 2 * (in_pad + out_bytes);
+    }
+    if (pinned) memcpy(h->pin, x, in_bytes);
+    if (pinned && in_pad + out_bytes <= 256 * 1024) {
+        // one frame or a few (audioproc.analyzelive): the kernel reads the pinned block and writes the spectrum into it — no
+        // copy engine on either side, one launch and one synchronisation per call
+        if ((rc = stft_launch(h, kind, h->pin, x_stride, h->pin + in_pad, F, h->stream))) return rc;
+        FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+        memcpy(out, h->pin + in_pad, out_bytes);
+        return FRT_OK;
+    }
+    FRT_HIP_CHECK(hipMemcpyAsync(h->stage_in.ptr, pinned ? (const void*)h->pin : x, in_bytes, hipMemcpyHostToDevice, h->stream));
     if ((rc = stft_launch(h, kind, h->stage_in.ptr, x_stride, h->stage_out.ptr, F, h->stream))) return rc;
-    FRT_HIP_CHECK(hipMemcpyAsync(out, h->stage_out.ptr, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    FRT_HIP_CHECK(hipMemcpyAsync(pinned ? (void*)(h->pin + in_pad) : out, h->stage_out.ptr, out_bytes, hipMemcpyDeviceToHost, h->stream));
     FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (pinned) memcpy(out, h->pin + in_pad, out_bytes);
     return FRT_OK;
 }
 

@@ -45,13 +45,12 @@ class Online_Linear_2D_resampler:
     def processable(self, m):
         return int(np.ceil((self.orig_index + m - (self.resampled_index + self.resampling_ratio)) / self.resampling_ratio))
 
-    def push(self, data):
-        data = np.ascontiguousarray(data, np.float64)
-        self.set_height(data.shape[0])
-        n_cols = data.shape[1]
+    def advance(self, n_cols):
+        """The scalar index bookkeeping of a push of n_cols columns, as in the reference (online_linear_2D_resampler.py:61-97):
+        returns (columns the reference allocates, source column per emitted pixel column, its weight)."""
         total = self.processable(n_cols)
         src, weights = [], []
-        for j in range(n_cols):                      # scalar index bookkeeping, as in the reference
+        for j in range(n_cols):
             self.orig_index += 1.
             n = self.processable(0)
             if n <= 0:
@@ -60,10 +59,17 @@ class Online_Linear_2D_resampler:
             weights.append(self.orig_index - new_indices)
             src += [j] * n
             self.resampled_index = float(new_indices[-1])
+        a = np.ascontiguousarray(np.concatenate(weights)) if weights else np.zeros(0)
+        return total, np.ascontiguousarray(src, np.int32), a
+
+    def push(self, data):
+        data = np.ascontiguousarray(data, np.float64)
+        self.set_height(data.shape[0])
+        n_cols = data.shape[1]
+        total, s, a = self.advance(n_cols)
+        src = s
         out = np.zeros((self.height, max(total, 0)))
-        if src:
-            a = np.ascontiguousarray(np.concatenate(weights))
-            s = np.ascontiguousarray(src, np.int32)
+        if len(src):
             old = np.ascontiguousarray(self.old_data, np.float64)
             res = np.empty((self.height, len(src)))
             _lib.check(self._lib.frt_time_resample(data.ctypes.data, old.ctypes.data, self.height, n_cols, s.ctypes.data,

@@ -226,6 +226,16 @@ int frt_time_resample(const double* data, const double* old, int height, int n_c
 int frt_fourier_resample(const double* x, int n, int count, double* y, int m);
 /* P7 Color_Transform.push (friture/signal/color_tranform.py:48-51): out[i] = lut[int(clip(v[i],0,1)*255)] */
 int frt_colour_map(const uint32_t* lut256, const double* values, int64_t count, uint32_t* out);
+/* P5 + P6 + P7 in one call: Transform_Pipeline.push (friture/signal/transform_pipeline.py:29-34) over the spectrogram's three
+ * blocks (friture/spectrogram.py:62-68) — np.interp onto the screen rows (frequency_resampler.py:67-83), the online time
+ * resampler's lerp against its carried column (online_linear_2D_resampler.py:61-97, linear_interp.py:47-60), clip + LUT
+ * (color_tranform.py:48-51) — the reference's operations in the reference's order, host arrays in and out.
+ * norm [n_cols][nb] frame-major; freq [nb], targets [height]: Frequency_Resampler's freq and xscaled; old_in / old_out
+ * [height]: the time resampler's carried column before / after; src, a [n_out]: its (source column, weight) pairs;
+ * pixels_out [height][n_out] uint32, row 0 = lowest frequency. */
+int frt_screen_columns(const double* norm, int nb, int n_cols, const double* freq, const double* targets, int height,
+                       const double* old_in, const int* src, const double* a, int n_out, const uint32_t* lut256,
+                       uint32_t* pixels_out, double* old_out);
 /* P8 exp_smoothed_value_2d (friture/signal/exp_smoothing.py:91-107); nf = 1 gives exp_smoothed_value:
  * out[r] = alpha * dot(data[r][:n], kernel[nk-n:]) + previous[r] * (1-alpha)^n, n = min(nt, nk)
  * (previous is dropped when nt > nk). */

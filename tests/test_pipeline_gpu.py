@@ -106,3 +106,42 @@ def test_exp_smoothing(golden, hip):
     row = np.random.default_rng(0).random(20)
     out = exp_smoothed_value_2d(dsp.smoothing_kernel(0.1, 32), 0.1, np.stack([row, row, 2 * row]), np.zeros(3))
     assert out[0] == out[1] and out[2] > out[0]
+
+
+def test_fused_transform_pipeline_equals_block_by_block(hip):
+    """Transform_Pipeline.push over the spectrogram's three blocks runs as ONE device call (frt_screen_columns); the same
+    blocks pushed one after the other (the reference's reduce(), three calls) give the same pixels and leave the same state
+    — over many pushes, a resize of the screen (Fourier-resampled carried column) and a change of the pixel rate."""
+    from functools import reduce
+
+    from friture_amd.plotting import frequency_scales as fs
+    from friture_amd.signal.color_tranform import Color_Transform
+    from friture_amd.signal.frequency_resampler import Frequency_Resampler
+    from friture_amd.signal.online_linear_2D_resampler import Online_Linear_2D_resampler
+    from friture_amd.signal.transform_pipeline import Transform_Pipeline
+
+    def chain():
+        fr = Frequency_Resampler(fs.Mel, 20., 20000., 137)
+        fr.setfreq(np.linspace(0, 24000, 513))
+        tr = Online_Linear_2D_resampler()
+        tr.set_ratio(0.1875, 0.08)
+        return [fr, tr, Color_Transform()]
+
+    fused, plain = chain(), chain()
+    pipe = Transform_Pipeline(fused)
+    assert pipe._fusable()
+    rng = np.random.default_rng(7)
+    for step in range(40):
+        if step == 15:
+            for b in (fused, plain):
+                b[0].setnsamples(211)
+        if step == 25:
+            for b in (fused, plain):
+                b[1].set_ratio(0.1875, 0.3)
+        data = rng.uniform(-0.2, 1.2, (513, int(rng.integers(1, 6))))
+        got = pipe.push(data)
+        want = reduce(lambda cols, stage: stage.push(cols), plain, data)
+        assert got.dtype == np.uint32 and got.shape == want.shape, (step, got.shape, want.shape)
+        assert np.array_equal(got, want), step
+        assert np.array_equal(fused[1].old_data, plain[1].old_data)
+        assert (fused[1].orig_index, fused[1].resampled_index) == (plain[1].orig_index, plain[1].resampled_index)

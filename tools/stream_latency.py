@@ -48,6 +48,45 @@ def main():
         for name, obj in (("device_resident", dev), ("block_by_block", host)):
             time_pushes(obj.handle_new_data, chunks[:50])                 # warm-up: allocations, first launches
             res[f"spectrogram_N{n_fft}_{name}"] = stats(time_pushes(obj.handle_new_data, chunks[50:]))
+        # the import swap proper: the widget's own body (friture/spectrogram.py:131-177) on the swapped classes —
+        # host RingBuffer, audioproc.analyzelive PER FRAME, numpy log / normalise, Transform_Pipeline.push
+        from friture_amd.audioproc import audioproc as Proc
+        from friture_amd.ringbuffer import RingBuffer
+        from friture_amd.signal.color_tranform import Color_Transform
+        from friture_amd.signal.frequency_resampler import Frequency_Resampler
+        from friture_amd.signal.online_linear_2D_resampler import Online_Linear_2D_resampler
+        from friture_amd.signal.transform_pipeline import Transform_Pipeline
+        from friture_amd.plotting import frequency_scales as fsc
+        proc = Proc()
+        proc.set_fftsize(n_fft)
+        fr, trs = Frequency_Resampler(fsc.Mel, 20., 20000., 400), Online_Linear_2D_resampler()
+        fr.setfreq(proc.get_freq_scale())
+        pipe = Transform_Pipeline([fr, trs, Color_Transform()])
+        wA = proc.get_freq_weighting()[0]
+        rb, stw = RingBuffer(), {"old": 0}
+        sfft_w = Fraction(48000, n_fft) / (Fraction(1) - Fraction(3, 4)) / 1000
+        needed_w = n_fft * (1. - 0.75)
+
+        def widget_push(c):
+            rb.push(c, 0.)
+            available = rb.offset - stw["old"]
+            realizable = int(np.floor(available / needed_w))
+            if realizable <= 0:
+                return None
+            spn = np.zeros((n_fft // 2 + 1, realizable), dtype=np.float64)
+            for i in range(realizable):
+                floatdata = rb.data_indexed(stw["old"], n_fft)
+                spn[:, i] = proc.analyzelive(floatdata[0, :])
+                stw["old"] += int(needed_w)
+            w = np.tile(wA, (realizable, 1)).transpose()
+            norm = (10. * np.log10(spn + 1e-30) + w - (-140.)) / 140.
+            trs.set_height(400)
+            trs.set_ratio(sfft_w, Fraction(800, 10000))
+            fr.setnsamples(400)
+            return pipe.push(norm)
+
+        time_pushes(widget_push, chunks[:50])
+        res[f"spectrogram_N{n_fft}_import_swap"] = stats(time_pushes(widget_push, chunks[50:]))
         # the oracle's chain (numpy float64, the reference's arithmetic)
         lut = dsp.colour_lut(dsp.cmrmap())
         w = dsp.weighting_curves(dsp.frequency_axis(n_fft))[0]
