@@ -20,7 +20,7 @@ for ch, bpo, log2n in ((8, 3, 22), (64, 24, 20), (8, 24, 20)):
     out = torch.empty((ch, n // 1024, 9 * bpo), dtype=torch.float32, device=dev)
     banks = {"fir": FirBank(bpo, ch, t)}
     iir = IirBank(t["bdec"], t["adec"], list(t[f"boct_{bpo}"]), list(t[f"aoct_{bpo}"]), ch)
-    iir.set_chunk(2048 if bpo == 3 else 4096)
+    iir.set_chunk(1024)
     banks["iir"] = iir
     res = {}
     for name, bank in banks.items():

@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(256, 3) k(float* out, long long n_rows, int ru
     const long long grp = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long f0 = grp * run;
     const float v = (float)lane;
-    if (MODE <= 2 || MODE == 5 || MODE >= 6) {
+    if (MODE <= 2 || MODE == 5 || MODE >= 6) {   // (13 included)
         for (int g = 0; g < run; ++g) {
             const long long f = f0 + g;
             if (f >= n_rows) break;
@@ -37,6 +37,19 @@ __global__ void __launch_bounds__(256, 3) k(float* out, long long n_rows, int ru
 #pragma unroll
                 for (int j = 0; j < 8; ++j) row[lane + 64 * j] = v;
                 if (lane == 0) row[512] = v;
+            } else if (MODE == 13) {
+                // the kernel's nine stores of a row SPREAD through the arithmetic (one store, a ninth of the multiply-adds, ...)
+                // instead of issued back to back
+                float acc = v;
+                const int part = spin / 9;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    if (j < 4) row[lane + 64 * j] = v;
+                    else if (j < 8) row[512 - lane - 64 * (j - 4)] = v;
+                    else if (lane == 0) row[256] = v;
+                    for (int t = 0; t < part; ++t) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(acc));
+                }
+                if (acc == 12345.f) row[0] = acc;
             } else if (MODE >= 10) {
                 // two 16-byte-per-lane stores per row (2048 of its 2052 bytes, alignment ignored: timing only) + the arithmetic
                 f4* p4 = (f4*)(out + (f * 513 & ~3ll)) + lane;
@@ -196,7 +209,10 @@ int main() {
         run_mode<3>("3 aligned dwordx4 chunks of the run's byte range", out, n_rows, run);
         run_mode<4>("4 aligned dwordx4 chunks, nontemporal", out, n_rows, run);
     }
-    for (int spin : {0, 100, 200, 300}) run_split(out, n_rows, 16, spin);
+    for (int spin : {90, 180, 270}) {
+        run_mode<13>("13 kernel shape, stores spread through the arithmetic", out, n_rows, 16, spin);
+        run_mode<7>("7 kernel shape, stores back to back", out, n_rows, 16, spin);
+    }
     for (int spin : {0, 100, 200}) {
         run_mode<10>("10 two dwordx4 stores per row", out, n_rows, 16, spin);
         run_mode<11>("11 two dwordx4 stores per row, nontemporal", out, n_rows, 16, spin);

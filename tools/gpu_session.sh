@@ -2,7 +2,7 @@
 # One GPU-box session: parity tests, smoke, bench, rocprofv3 kernel stats + PMC traffic.  Outputs -> gpurun_out/.
 set -u
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r02}
+TAG=${1:-r03}
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 echo "== selftest"; timeout 300 tools/bin/stft_selftest check | tail -2
