@@ -11,6 +11,12 @@
 // DFT and writes the results to (j - k) R + k + q p.  Reads of consecutive butterflies are consecutive
 // addresses.  The pass runs in place: every thread first gathers all of its butterflies into
 // registers, the workgroup meets at a barrier, then every thread scatters.
+//
+// Twiddles and indices (round 3).  The factor of point q of butterfly j depends on k = j mod p only: the plan carries one
+// table per pass, [q - 1][k] (k < p, contiguous in k), so consecutive butterflies read consecutive entries.  Rounds 1-2
+// indexed ONE table exp(-2 pi i t / n) at t = (q k step) mod n — a gather with stride q step across the lanes and two
+// integer divisions by run-time operands (~30 instructions each) per point.  k itself comes from a multiply-high with
+// ceil(2^32 / p) (exact for the j < 2^16, p < 2^13 of this path).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -26,6 +32,8 @@ struct MixedPlan {
     int n;
     int npass;
     int radix[kMaxPasses];
+    int tw_off[kMaxPasses];          // first entry of the pass's twiddle table [R - 1][p] (make_pass_twiddles)
+    unsigned magic[kMaxPasses];      // ceil(2^32 / p): j / p = umulhi(j, magic) for j < 2^16
 };
 
 // Factor n into radices {4, 5, 3, 2}; returns false when n is not 5-smooth.
@@ -41,7 +49,35 @@ inline bool make_mixed_plan(int n, MixedPlan* plan) {
     while (m % 5 == 0) { push(5); m /= 5; }
     while (m % 3 == 0) { push(3); m /= 3; }
     while (m % 2 == 0) { push(2); m /= 2; }
-    return m == 1 && plan->npass <= kMaxPasses && n >= 1;
+    if (!(m == 1 && plan->npass <= kMaxPasses && n >= 1 && n < (1 << 16))) return false;
+    int p = 1, off = 0;
+    for (int i = 0; i < plan->npass; ++i) {
+        plan->tw_off[i] = off;
+        plan->magic[i] = p > 1 ? (unsigned)((0x100000000ull + (unsigned long long)p - 1) / (unsigned long long)p) : 0u;
+        off += (plan->radix[i] - 1) * p;
+        p *= plan->radix[i];
+    }
+    return true;
+}
+
+// Per-pass twiddle tables of a plan, concatenated: pass i holds exp(-2 pi i q k / (p R)) at tw_off[i] + (q - 1) p + k.
+template <typename T>
+inline std::vector<T> make_pass_twiddles(const MixedPlan& plan) {
+    std::vector<T> t;
+    const long double pi2 = 6.283185307179586476925286766559L;
+    int p = 1;
+    for (int i = 0; i < plan.npass; ++i) {
+        const int R = plan.radix[i];
+        for (int q = 1; q < R; ++q)
+            for (int k = 0; k < p; ++k) {
+                const long double a = pi2 * (long double)q * (long double)k / ((long double)p * (long double)R);
+                t.push_back((T)cosl(a));
+                t.push_back((T)(-sinl(a)));
+            }
+        p *= R;
+    }
+    if (t.empty()) t.assign(2, (T)0);
+    return t;
 }
 
 // Host table tw[i] = exp(-2 pi i * i / n), i < n, as interleaved (re, im) of type T.
@@ -88,29 +124,29 @@ __device__ __forceinline__ void dft5(cpx<T>& a0, cpx<T>& a1, cpx<T>& a2, cpx<T>&
 }
 
 // Forward FFT of buf[0..n) in place; all `nthreads` threads of the workgroup must call it.
-// MAXB >= ceil((n/2) / nthreads) butterflies per thread per pass.  tw: exp(-2 pi i t / n), t < n.
+// MAXB >= ceil((n/2) / nthreads) butterflies per thread per pass.  tw: the plan's per-pass tables (make_pass_twiddles).
 // Ends with a barrier: results are visible to the whole workgroup on return.
-// POW2: n is a power of two (radices 4 and 2 only): index arithmetic by masks instead of integer division.
-template <typename T, int MAXB, bool POW2 = false>
+template <typename T, int MAXB>
 __device__ void fft_mixed_forward(cpx<T>* buf, const cpx<T>* __restrict__ tw, const MixedPlan& plan, int tid, int nthreads) {
     const int n = plan.n;
-    int p = 1;
+    int p = 1, m = n;
     for (int pass = 0; pass < plan.npass; ++pass) {
         const int R = plan.radix[pass];
-        // (POW2: R is 4 or 2 and p a power of two — shifts)
-        const int m = POW2 ? (R == 4 ? n >> 2 : n >> 1) : n / R;
-        const int step = POW2 ? (m >> (31 - __clz(p))) : n / (p * R);
+        // butterflies of the pass, n / R, without a division (R is 4, 5, 3 or 2)
+        m = R == 4 ? n >> 2 : R == 2 ? n >> 1 : (int)__umulhi((unsigned)n, R == 5 ? 0x33333334u : 0x55555556u);
+        const unsigned magic = plan.magic[pass];
+        const cpx<T>* twp = tw + plan.tw_off[pass];
         cpx<T> v[MAXB][5];
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) {
             const int j = tid + b * nthreads;
             if (j < m) {
-                const int k = POW2 ? (j & (p - 1)) : j % p;
+                const int k = p > 1 ? j - p * (int)__umulhi((unsigned)j, magic) : 0;
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {
                     if (q < R) {
                         cpx<T> a = buf[j + q * m];
-                        if (q > 0 && p > 1) a = cmul(a, tw[POW2 ? ((q * k * step) & (n - 1)) : (q * k * step) % n]);
+                        if (q > 0 && p > 1) a = cmul(a, twp[(q - 1) * p + k]);
                         v[b][q] = a;
                     }
                 }
@@ -125,7 +161,7 @@ __device__ void fft_mixed_forward(cpx<T>* buf, const cpx<T>* __restrict__ tw, co
         for (int b = 0; b < MAXB; ++b) {
             const int j = tid + b * nthreads;
             if (j < m) {
-                const int k = POW2 ? (j & (p - 1)) : j % p;
+                const int k = p > 1 ? j - p * (int)__umulhi((unsigned)j, magic) : 0;
                 const int base = (j - k) * R + k;
 #pragma unroll
                 for (int q = 0; q < 5; ++q)

@@ -37,7 +37,7 @@ struct GccArgs {
     double* means;         // [pairs][2] or null
     const double* window;  // [L] numpy.hanning(L)
     const double* twm;     // [M] exp(-2 pi i t / M)
-    const double* tw2;     // [M2] exp(-2 pi i t / M2)
+    const double* tw2;     // per-pass twiddle tables of the M2-point plan (fft_mixed.h, make_pass_twiddles)
     const double* twl;     // [M+1] exp(-2 pi i k / L)
     double* scratch;       // [pairs][4 M + 2] complex
     MixedPlan plan;        // for M2
@@ -751,7 +751,7 @@ extern "C" int frt_gcc_create(frt_gcc** out, int length, int n_pairs) {
         return FRT_OK;
     }
     if ((rc = upload(h->window, win)) || (rc = upload(h->twm, make_twiddles<double>(h->M))) ||
-        (rc = upload(h->tw2, make_twiddles<double>(h->M2))) || (rc = upload(h->twl, make_twiddles<double>(length, h->M + 1))) ||
+        (rc = upload(h->tw2, make_pass_twiddles<double>(h->plan))) || (rc = upload(h->twl, make_twiddles<double>(length, h->M + 1))) ||
         (rc = h->scratch.reserve((size_t)n_pairs * (4 * (size_t)h->M + 2) * 2 * sizeof(double)))) {
         frt_gcc_destroy(h);
         return rc;

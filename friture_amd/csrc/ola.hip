@@ -157,7 +157,7 @@ int frt_ola_create(frt_octbank* h, const double* boct_fir, const double* bdec_fi
         const int M = F / 2;
         o->fft_size[j] = F;
         FRT_REQUIRE(F % 2 == 0 && M <= kOlaMaxM && make_mixed_plan(M, &o->plan[j]), "frt_ola_create: bad FFT size %d", F);
-        if ((rc = upload(o->tw[j], make_twiddles<double>(M))) || (rc = upload(o->twl[j], make_twiddles<double>(F, M + 1)))) return rc;
+        if ((rc = upload(o->tw[j], make_pass_twiddles<double>(o->plan[j]))) || (rc = upload(o->twl[j], make_twiddles<double>(F, M + 1)))) return rc;
         // H_f[k] = sum_t h_f[t] exp(-2 pi i k t / F): the rfft of the zero-padded taps
         std::vector<long double> ct(F), st(F);
         const long double pi2 = 6.283185307179586476925286766559L;
