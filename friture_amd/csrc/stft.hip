@@ -52,6 +52,7 @@ struct StftArgs {
     const double* edge_pow;// [256] power at which the unweighted index value reaches n: 10^((min + n (max - min)/255)/10)
     const double* bin_pow; // [M+1] 10^(-weight[k]/10)
     float edge2;           // width of the zone above an index edge that is decided in float64
+    double image_thr;      // float64 instance: the margin the float32 table of the float32 instance carries inside wimage
     int rising;            // max > min: the index grows with the power
     int eps_free;          // P + 1e-30 == P in float32 wherever it matters: the add is skipped
 #ifdef FRT_ABLATE
@@ -85,18 +86,26 @@ __device__ __forceinline__ T shfl_t(T v, int lane) { return __shfl(v, lane, 64);
 // Such bins are served one at a time with wave-uniform operands: the two table values arrive through SCALAR loads
 // (lgkmcnt).  A vector load here would have to be waited for with vmcnt(0), i.e. behind the acknowledgement of every row
 // store still in flight — measured: +7 % on the whole kernel for a path that one frame in five enters.
-__device__ __forceinline__ int exact_colour_index(bool near_edge, float p, int k, int n, const StftArgs& a) {
+__device__ __forceinline__ double readlane_power(float p, int src) {
+    return (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p), src));
+}
+__device__ __forceinline__ double readlane_power(double p, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(p), src), hi = __builtin_amdgcn_readlane(__double2hiint(p), src);
+    return __hiloint2double(hi, lo);
+}
+template <typename TP>
+__device__ __forceinline__ int exact_colour_index(bool near_edge, TP p, int k, int n, const StftArgs& a) {
     unsigned long long todo = __ballot(near_edge);
     const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     while (todo) {
         const int src = __builtin_ctzll(todo);
         todo &= todo - 1;
         const int ks = __builtin_amdgcn_readlane(k, src), ns = __builtin_amdgcn_readlane(n, src);
-        const float ps = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p), src));
+        const double ps = readlane_power(p, src);
         // constant address space + uniform index = s_load_dwordx2 (the tables are never written by a kernel)
         typedef const double __attribute__((address_space(4))) * ktable;
         const double edge = ((ktable)(uintptr_t)a.edge_pow)[ns] * ((ktable)(uintptr_t)a.bin_pow)[ks];
-        const bool at_least = ((double)ps + 1e-30 >= edge) == (a.rising != 0);
+        const bool at_least = (ps + 1e-30 >= edge) == (a.rising != 0);
         if (lane == src) n = at_least ? ns : ns - 1;
     }
     return n;
@@ -503,11 +512,18 @@ stft_kernel(const StftArgs a) {
                     // is not clamped to index 0 anyway, and the add is left out (eps_free, frt_stft_set_epilogue)
                     auto colour_row = [&](auto eps_free) {
                         constexpr bool EPS_FREE = decltype(eps_free)::value;
-                        auto index_value = [&](T pw, T w) -> T {
-                            if constexpr (EPS_FREE) return clamp_index(image_gain * log2_t(pw) + w);
-                            else return clamp_index(image_gain * log2_t(pw + (T)1e-30) + w);
+                        // float64 instance: the same float32 evaluation of the index from the power rounded to float32 (its own
+                        // 2^-24 is inside `thr`), the float64 comparison for the few bins next to an edge — no float64 logarithm
+                        // (software, ~40 instructions) per bin
+                        const float gain32 = (float)image_gain;
+                        auto index_value = [&](T pw, T w) -> float {
+                            float wf;
+                            if constexpr (sizeof(T) == 8) wf = (float)(w + (T)a.image_thr);
+                            else wf = (float)w;
+                            if constexpr (EPS_FREE) return clamp_index(gain32 * __log2f((float)pw) + wf);
+                            else return clamp_index(gain32 * __log2f((float)pw + 1e-30f) + wf);
                         };
-                        T q[9];
+                        float q[9];
                         uint32_t colour[9];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -517,7 +533,7 @@ stft_kernel(const StftArgs a) {
                         q[8] = index_value(res_mid, wdb_mid);               // stored by thread 0 only
 #pragma unroll
                         for (int j = 0; j < 9; ++j) colour[j] = lut_lds[(int)q[j]];
-                        if constexpr (sizeof(T) == 4) {
+                        {
                             // Bins within 2 thr above an index edge (3e-4 of them) are decided in float64 (exact_colour_index).
                             // The LUT reads above are issued first, with the float32 index, so that the frame's only branch
                             // sits behind them and in front of nothing but the stores; the rare path recomputes what it
@@ -549,7 +565,7 @@ stft_kernel(const StftArgs a) {
                                         psel = jsel == j ? res[j] : jsel == 4 + j ? res[4 + j] : psel;
                                         wsel = jsel == j ? wl[j] : jsel == 4 + j ? wh[j] : wsel;
                                     }
-                                    const T qsel = index_value(psel, wsel);
+                                    const float qsel = index_value(psel, wsel);
                                     const int ksel = jsel < 4 ? klo + jsel * TPF : jsel < 8 ? khi - (jsel - 4) * TPF : M / 2;
                                     const uint32_t c = lut_lds[exact_colour_index(pend != 0, psel, ksel, (int)qsel, a)];
 #pragma unroll
@@ -565,7 +581,7 @@ stft_kernel(const StftArgs a) {
                         }
                         if (i == 0) stream_store(prow + M / 2, colour[8]);
                     };
-                    if (sizeof(T) == 4 && a.eps_free) colour_row(std::true_type{});
+                    if (a.eps_free) colour_row(std::true_type{});
                     else colour_row(std::false_type{});
                 } else {
 #pragma unroll
@@ -691,6 +707,7 @@ struct frt_stft {
     DeviceBuffer window, tw, twn, tws, weight, wimage, edge_pow, bin_pow, lut;
     bool eps_free = false;
     float edge2 = 0.f;            // see exact_colour_index
+    double image_thr = 0.0;
     bool has_weight = false, has_lut = false;
     double spec_min = -140.0, spec_max = 0.0;
     DeviceBuffer stage_in, stage_out;
@@ -796,16 +813,18 @@ extern "C" int frt_stft_set_epilogue(frt_stft* h, const double* weight_db, doubl
     h->has_weight = weight_db != nullptr;
     // per-bin offset of the colour index (IMAGE kind), weighting and dB range folded in
     const double span = spec_max - spec_min;
-    if (h->precision == 32) {
+    {
         // q = fma(gain, L, wimage[k]) in float32, L = v_log_f32(P + 1e-30), against v * 255 in float64.  Error terms, in
         // index units, for a q inside the LUT's range (|q| < 256, hence |gain L| < |wimage| + 256):
         //   v_log_f32: 1 ulp of its result (ISA), |L| < 128                      gain * 2^-17
         //   P + 1e-30 rounded (or left out: eps_free, relative 2^-24.7)          gain * 1.45 * 2^-24
+        //   (float64 instance: P rounded to float32 first)                       gain * 1.45 * 2^-24
         //   gain rounded to float32                                              2^-24 (|wimage| + 256)
         //   wimage[k] rounded to float32                                         2^-24 |wimage|
         //   the fma's single rounding                                            2^-24 * 256
-        // thr = their sum (+5 %); wimage carries +thr, so the float64 value lies in (q - 2 thr, q) and the kernel
-        // re-decides exactly the bins with fract(q) < 2 thr.
+        // thr = their sum (+5 %); the index value carries +thr (inside the float32 instance's table, added per bin by the
+        // float64 instance), so the float64 value lies in (q - 2 thr, q) and the kernel re-decides exactly the bins with
+        // fract(q) < 2 thr.
         const double gain = std::fabs(255.0 * 3.01029995663981195 / span);
         // (|wimage| over the bins that can reach the LUT's range at all: with |log2| < 128 a bin whose offset lies more than
         // 128 gain outside [0, 256] is clamped whatever its power — bin 0 of the A curve sits at -1000 dB — and needs no margin)
@@ -815,15 +834,13 @@ extern "C" int frt_stft_set_epilogue(frt_stft* h, const double* weight_db, doubl
             if (wk + 128.0 * gain >= 0.0 && wk - 128.0 * gain <= 256.0) wmax = std::fmax(wmax, std::fabs(wk));
         }
         const double eps24 = 1.0 / 16777216.0;
-        const double thr = 1.05 * (gain * (1.0 / 131072.0 + 1.5 * eps24) + eps24 * (2.0 * (wmax + 1.0) + 512.0));
+        const double thr = 1.05 * (gain * (1.0 / 131072.0 + (h->precision == 32 ? 1.5 : 3.0) * eps24) + eps24 * (2.0 * (wmax + 1.0) + 512.0));
         h->edge2 = (float)(2.0 * thr);
-        std::vector<float> w(nb), wi(nb);
+        h->image_thr = thr;
         std::vector<double> bp(nb), ep(256);
         double wmax_db = -1e300;
         for (int k = 0; k < nb; ++k) {
             const double wk = weight_db ? weight_db[k] : 0.0;
-            w[k] = (float)wk;
-            wi[k] = (float)(255.0 * (wk - spec_min) / span + thr);
             bp[k] = std::pow(10.0, -wk / 10.0);
             wmax_db = std::fmax(wmax_db, wk);
         }
@@ -831,16 +848,23 @@ extern "C" int frt_stft_set_epilogue(frt_stft* h, const double* weight_db, doubl
         // P < 2^-75 (2.6e-23) is where P + 1e-30 differs from P in float32; if even there, with the largest weight, the
         // index value stays below 0, every such bin is clamped to index 0 with or without the 1e-30
         h->eps_free = span > 0 && (10.0 * std::log10(2.7e-23) + wmax_db - spec_min) / span * 255.0 + thr < 0.0;
-        if ((rc = upload(h->weight, w)) || (rc = upload(h->wimage, wi)) || (rc = upload(h->edge_pow, ep)) ||
-            (rc = upload(h->bin_pow, bp)))
-            return rc;
-    } else {
-        std::vector<double> w(nb), wi(nb);
-        for (int k = 0; k < nb; ++k) {
-            w[k] = weight_db ? weight_db[k] : 0.0;
-            wi[k] = 255.0 * (w[k] - spec_min) / span;
+        if ((rc = upload(h->edge_pow, ep)) || (rc = upload(h->bin_pow, bp))) return rc;
+        if (h->precision == 32) {
+            std::vector<float> w(nb), wi(nb);
+            for (int k = 0; k < nb; ++k) {
+                const double wk = weight_db ? weight_db[k] : 0.0;
+                w[k] = (float)wk;
+                wi[k] = (float)(255.0 * (wk - spec_min) / span + thr);
+            }
+            if ((rc = upload(h->weight, w)) || (rc = upload(h->wimage, wi))) return rc;
+        } else {
+            std::vector<double> w(nb), wi(nb);
+            for (int k = 0; k < nb; ++k) {
+                w[k] = weight_db ? weight_db[k] : 0.0;
+                wi[k] = 255.0 * (w[k] - spec_min) / span;          // exact: the large-frame float64 instance evaluates in float64
+            }
+            if ((rc = upload(h->weight, w)) || (rc = upload(h->wimage, wi))) return rc;
         }
-        if ((rc = upload(h->weight, w)) || (rc = upload(h->wimage, wi))) return rc;
     }
     h->has_lut = lut256 != nullptr;
     if (lut256) {
@@ -884,6 +908,7 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     a.edge_pow = h->edge_pow.as<double>();
     a.bin_pow = h->bin_pow.as<double>();
     a.edge2 = h->edge2;
+    a.image_thr = h->image_thr;
     if (const char* e = getenv("FRT_EDGE_SCALE")) a.edge2 *= (float)atof(e);      // experiments only (tools/exp)
     a.rising = h->spec_max > h->spec_min;
     a.eps_free = h->eps_free;
