@@ -121,33 +121,44 @@ __global__ void __launch_bounds__(256, 3) k(float* out, long long n_rows, int ru
     }
 }
 
-// producer / consumer split: 320-thread workgroups, wavefronts 0-3 only do the arithmetic of their rows, wavefront 4 stores
-// the rows of all four (no hand-off: timing of the split only)
-__global__ void __launch_bounds__(320, 1) k_split(float* out, long long n_rows, int run, int spin) {
+// producer / consumer split: 320-thread workgroups, wavefronts 0-3 do the arithmetic of their rows and leave the row in an LDS
+// slot (nine ds_write_b32), wavefront 4 takes the four rows of the previous step from LDS and stores them (dwordx4 where the
+// alignment allows): one workgroup barrier per step, double-buffered slots.  Same occupancy as the kernel (three workgroups
+// per CU: launch bound and LDS as there).
+__global__ void __launch_bounds__(320, 3) k_split(float* out, long long n_rows, int run, int spin) {
+    __shared__ float slot[2][4][516];
+    __shared__ float pad[4608];                                   // the transform's exchange buffers of the real kernel (occupancy)
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const float v = (float)lane;
-    if (w < 4) {
-        float acc = v;
-        for (int g = 0; g < run; ++g) {
-            for (int t = 0; t < spin; ++t) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(acc));
-        }
-        if (acc == 12345.f) out[0] = acc;
-    } else {
-        for (int g = 0; g < run; ++g) {
-            for (int ww = 0; ww < 4; ++ww) {
-                const long long f = ((long long)blockIdx.x * 4 + ww) * run + g;
-                if (f >= n_rows) continue;
-                float* row = out + f * 513;
+    if (spin < 0) pad[threadIdx.x] = v;
+    float acc = v;
+    for (int g = 0; g <= run; ++g) {
+        if (w < 4) {
+            if (g < run) {
+                for (int t = 0; t < spin; ++t) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(acc));
+                float* r = slot[g & 1][w];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    row[lane + 64 * j] = v;
-                    row[512 - lane - 64 * j] = v;
+                    r[lane + 64 * j] = acc;
+                    r[512 - lane - 64 * j] = acc;
                 }
-                if (lane == 0) row[256] = v;
+                if (lane == 0) r[256] = acc;
+            }
+        } else if (g > 0) {
+            for (int ww = 0; ww < 4; ++ww) {
+                const long long f = ((long long)blockIdx.x * 4 + ww) * run + (g - 1);
+                if (f >= n_rows) continue;
+                float* row = out + f * 513;
+                const float* r = slot[(g - 1) & 1][ww];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) row[lane + 64 * j] = r[lane + 64 * j];
+                if (lane == 0) row[512] = r[512];
             }
         }
+        __syncthreads();
     }
+    if (acc == 12345.f) out[0] = acc;
 }
 
 static void run_split(float* out, long long n_rows, int run, int spin) {
@@ -165,7 +176,7 @@ static void run_split(float* out, long long n_rows, int run, int spin) {
     float ms;
     HK(hipEventElapsedTime(&ms, e0, e1));
     ms /= iters;
-    printf("%-60s run=%2d spin=%3d  %.4f ms  %.0f GB/s written\n", "12 four arithmetic wavefronts + one storing wavefront", run, spin, ms, n_rows * 2052.0 / ms * 1e-6);
+    printf("%-60s run=%2d spin=%3d  %.4f ms  %.0f GB/s written\n", "12 four arithmetic wavefronts + one storing wavefront (LDS hand-off)", run, spin, ms, n_rows * 2052.0 / ms * 1e-6);
 }
 
 template <int MODE>
@@ -209,6 +220,7 @@ int main() {
         run_mode<3>("3 aligned dwordx4 chunks of the run's byte range", out, n_rows, run);
         run_mode<4>("4 aligned dwordx4 chunks, nontemporal", out, n_rows, run);
     }
+    for (int spin : {0, 100, 200, 300}) run_split(out, n_rows, 16, spin);
     for (int spin : {90, 180, 270}) {
         run_mode<13>("13 kernel shape, stores spread through the arithmetic", out, n_rows, 16, spin);
         run_mode<7>("7 kernel shape, stores back to back", out, n_rows, 16, spin);
