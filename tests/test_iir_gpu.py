@@ -237,6 +237,39 @@ def test_full_size_bank_properties(tabs):
             assert np.max(np.abs(e[c, blk].cpu().numpy() / np.array(prev) - 1)) <= 1e-5, (c, blk)
 
 
+def test_full_size_bank_every_block_against_sequential_mode_and_oracle(tabs):
+    """BASELINE configs[2] at full size, every block of every channel: the time-parallel mode as `bench.py` runs it (chunk
+    1024: zero-state products on the matrix cores, row scan, one lane per chunk) against (a) the SEQUENTIAL mode of the same
+    bank, which is bit-identical to the reference's recurrence (golden tests above) — all 8 x 4096 x 27 energies within 1e-5 —
+    and (b) the oracle itself run over the whole of one channel (4096 blocks through oracle/iir_ref.c), within 1e-5."""
+    import torch
+    from friture_amd.filter import IirBank
+    bpo, C, n = 3, 8, 1 << 22
+    boct, aoct = list(tabs[f"boct_{bpo}"]), list(tabs[f"aoct_{bpo}"])
+    alphas, kernels = dsp.band_smoothing_setup(bpo, 1.0)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = 0.25 * torch.randn((C, n), generator=gen, device="cuda", dtype=torch.float32)
+    par = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, C)
+    par.set_chunk(1024)
+    e = par.energies(x, 1024, alphas)
+    seq = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, C)            # chunk 0: sequential in time
+    es = seq.energies(x, 1024, alphas)
+    torch.cuda.synchronize()
+    assert e.shape == es.shape == (C, n // 1024, 27)
+    worst = float(((e - es).abs() / es).max())
+    assert worst <= 1e-5, worst
+    xs = x[3].cpu().numpy().astype(np.float64)
+    zs = dsp.iir_bank_filtic(tabs["bdec"], tabs["adec"], boct, aoct)
+    prev = [0.0] * 27
+    got = e[3].cpu().numpy()
+    worst_o = 0.0
+    for blk in range(n // 1024):
+        y, _, zs = dsp.iir_bank(tabs["bdec"], tabs["adec"], boct, aoct, xs[blk * 1024:(blk + 1) * 1024], zs)
+        prev = dsp.band_energies(y, kernels, alphas, prev)
+        worst_o = max(worst_o, float(np.max(np.abs(got[blk] / np.array(prev) - 1))))
+    assert worst_o <= 1e-5, worst_o
+
+
 def test_configs4_bank_full_size_properties(tabs):
     """BASELINE configs[4], the filter-bank half on one GPU's shard scale: 64 ch x 2^20 samples, 1/24 octave
     (216 bands), device resident: exact linearity, chunking invariance, first blocks of two channels vs the oracle."""
