@@ -92,6 +92,14 @@ SIGNATURES = {
     "frt_pitch_set_scratch_limit": (c_int, [c_void_p, c_int64]),
     "frt_pitch_frames_for": (c_int64, [c_void_p, c_int64]),
     "frt_pitch_track": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, POINTER(c_int64)]),
+    "frt_delay_create": (c_int, [POINTER(c_void_p), POINTER(c_double), POINTER(c_double), c_int, c_int]),
+    "frt_delay_destroy": (None, [c_void_p]),
+    "frt_delay_stream": (c_void_p, [c_void_p]),
+    "frt_delay_push": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_int64)]),
+    "frt_delay_reserve": (c_int, [c_void_p, c_int]),
+    "frt_delay_window": (c_int, [c_void_p, c_int64, c_int, POINTER(c_void_p), POINTER(c_void_p)]),
+    "frt_delay_window_std": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(c_double)]),
+    "frt_delay_demean": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "frt_lfilter_f64": (c_int, [POINTER(c_double), POINTER(c_double), c_int, POINTER(c_double), c_int, POINTER(c_double),
                                 POINTER(c_double), POINTER(c_double)]),
 }

@@ -192,7 +192,10 @@ __device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long 
     const long long nslots = (long long)a.n_channels * a.nchunks * nf;
     const long long gslot = wave * SPW + sl;
     const bool valid = gslot < nslots;
-    const long long gs = valid ? gslot : 0;
+    // slots past the end shadow the LAST slot (same samples, same arithmetic, nothing stored): a wavefront with spare slots —
+    // every streaming call: one or two channels fill 1-2 of the 4 rows — then still runs the straight-line loop below
+    // instead of the masked per-sample one (measured on the 2-channel decimator of the delay estimator: 117 -> 18 ns / sample)
+    const long long gs = valid ? gslot : nslots - 1;
     const int fi = (int)(gs % nf);
     const long long cq = gs / nf;
     const int q = (int)(cq % a.nchunks), c = (int)(cq / a.nchunks);
@@ -241,7 +244,6 @@ __device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long 
     const long long start = (long long)q * a.chunk;
     long long stop = start + a.chunk;
     if (stop > a.n) stop = a.n;
-    if (!valid) stop = start;
     double* xy = lds + sl * 64;
     const long long xrow = (long long)c * a.x_stride;
 
@@ -327,13 +329,13 @@ __device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long 
 #pragma unroll
                         for (int j = 0; j < (SPW + 3) / 4; ++j) {
                             const int m = 2 * (s + LPS * j);                                      // decimated index of the pair
-                            if (m < 32) *(double2*)(xn + m) = double2{xy[2 * m], xy[2 * m + 2]};
+                            if (m < 32 && valid) *(double2*)(xn + m) = double2{xy[2 * m], xy[2 * m + 2]};
                         }
                     } else {
 #pragma unroll
                         for (int j = 0; j < SPW; ++j) {
                             const int k = s + LPS * j;
-                            if (!(k & 1) && k < cnt) xn[k >> 1] = xy[k];
+                            if (!(k & 1) && k < cnt && valid) xn[k >> 1] = xy[k];
                         }
                     }
                 }
@@ -342,7 +344,7 @@ __device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long 
 #pragma unroll
                 for (int j = 0; j < SPW; ++j) {
                     const int k = s + LPS * j;
-                    if (k < cnt) yrow[k] = xy[k];
+                    if (k < cnt && valid) yrow[k] = xy[k];
                 }
             }
         }
@@ -1838,5 +1840,261 @@ extern "C" int frt_lfilter_f64(const double* b, const double* a, int n_coef, con
         return FRT_ERR_HIP;
     }
     for (int t = 0; t < order; ++t) zf[t] = st[t];
+    return FRT_OK;
+}
+
+// ---- the delay estimator's per-chunk part as one device-resident object --------------------------------------------
+// Delay_Estimator_Widget.handle_new_data (friture/delay_estimator.py:87-131), per chunk of both channels: two chained
+// decimations by 2 with carried state (decimate_multiple, :97-98), push into the two private ring buffers (:99-100), and —
+// once per `needed` decimated samples, 94 chunks at the default range — a window of both rings for GCC-PHAT.  Round 2's
+// stream class drove this through torch (an upload from pageable memory, two allocations, the decimation launches, two
+// ring pushes of several torch kernels each: 124 us per chunk against 30 us of numpy).  Here the chunk goes through a
+// pinned slot that the first decimation stage reads in place (zero copy), both stages and ONE ring-write launch are
+// enqueued on the object's stream, and the call returns without waiting: nothing comes back per chunk.  Windows are handed
+// out as device pointers into the mirror rings (ringbuffer.py:87-99: the `length` samples ending at an absolute index), with
+// the two helpers the reference's window handling needs: the standard deviations of the gate (:127) and the in-place mean
+// removal generalized_cross_correlation applies to its views (correlation.py:27-28).
+namespace frt {
+
+__global__ void __launch_bounds__(256) delay_ring_write_kernel(const double* __restrict__ dec, int m, double* __restrict__ ring,
+                                                               long long ring_len, long long offset) {
+    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (t >= m) return;
+    const long long p = (offset + t) % ring_len;
+    const double v = dec[(size_t)c * m + t];
+    double* r = ring + (size_t)c * 2 * ring_len;
+    r[p] = v;                               // ringbuffer.py:52-59: the second copy makes every window a linear view
+    r[p + ring_len] = v;
+}
+
+// RingBuffer.grow_if_needed (ringbuffer.py:102-130) moves the old ring PHYSICALLY: its first copy lands `shift` positions
+// further (shift chosen so that the write head keeps its absolute index), the mirror copy follows and folds around the
+// end.  Samples that had wrapped in the old ring therefore do not land where their absolute index would put them; the
+// windows the reference hands out afterwards contain exactly that, so the same three slice copies are made here.
+__global__ void __launch_bounds__(256) delay_ring_relay_kernel(const double* __restrict__ old_ring, long long old_len,
+                                                               double* __restrict__ new_ring, long long new_len, long long shift) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (p >= old_len) return;
+    const double v = old_ring[(size_t)c * 2 * old_len + p];
+    double* r = new_ring + (size_t)c * 2 * new_len;
+    const long long direct = old_len < new_len - shift ? old_len : new_len - shift;
+    r[shift + p] = v;                                   // :120 first copy, always complete
+    if (p < direct) r[new_len + shift + p] = v;         // :124 second copy ...
+    else r[p - direct] = v;                             // :125 ... folded
+}
+
+// numpy.std of a window (population, two passes: mean, then mean of squared deviations), one workgroup per channel
+__global__ void __launch_bounds__(1024) delay_window_std_kernel(const double* __restrict__ d0, const double* __restrict__ d1, int length,
+                                                                double* __restrict__ out) {
+    __shared__ double red[16];
+    const double* d = blockIdx.x == 0 ? d0 : d1;
+    const int tid = threadIdx.x;
+    auto block_sum = [&](double v) -> double {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        double s = 0.0;
+        for (int w = 0; w < 16; ++w) s += red[w];
+        return s;
+    };
+    double acc = 0.0;
+    for (int i = tid; i < length; i += 1024) acc += d[i];
+    const double mean = block_sum(acc) / (double)length;
+    acc = 0.0;
+    for (int i = tid; i < length; i += 1024) {
+        const double t = d[i] - mean;
+        acc += t * t;
+    }
+    const double var = block_sum(acc) / (double)length;
+    if (tid == 0) out[blockIdx.x] = sqrt(var);
+}
+
+// d -= mean on a window of a mirror ring: the window's samples and their mirror images (the reference's view aliases the
+// ring storage, whose two halves its push keeps identical only for the samples it writes — the mirror copy of a de-meaned
+// sample is NOT updated there either: ringbuffer.py:87-99 returns buffer[:, start:stop] of the doubled array)
+__global__ void __launch_bounds__(256) delay_demean_kernel(double* __restrict__ w0, double* __restrict__ w1, int length,
+                                                           const double* __restrict__ means) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= length) return;
+    if (blockIdx.y == 0) w0[i] -= means[0];
+    else w1[i] -= means[1];
+}
+
+}  // namespace frt
+
+struct frt_delay {
+    frt_octbank* dec = nullptr;             // two channels, decimator only
+    int n_stages = 2;
+    hipStream_t stream = nullptr;
+    DeviceBuffer ring;                      // [2][2 ring_len]
+    long long ring_len = 0, offset = 0;     // offset: decimated samples pushed so far
+    static constexpr int kSlots = 4;        // pinned chunks in flight
+    char* pin[kSlots] = {};
+    size_t pin_bytes[kSlots] = {};
+    hipEvent_t done[kSlots] = {};
+    bool pending[kSlots] = {};
+    int slot = 0;
+    DeviceBuffer stats, xin;
+};
+
+extern "C" void frt_delay_destroy(frt_delay* h) {
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->dec) frt_octbank_destroy(h->dec);
+    h->ring.release();
+    h->stats.release();
+    h->xin.release();
+    for (int s = 0; s < frt_delay::kSlots; ++s) {
+        if (h->pin[s]) (void)hipHostFree(h->pin[s]);
+        if (h->done[s]) (void)hipEventDestroy(h->done[s]);
+    }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int frt_delay_create(frt_delay** out, const double* bdec, const double* adec, int n_stages, int ring_length) {
+    FRT_REQUIRE(out && bdec && adec, "frt_delay_create: null argument");
+    *out = nullptr;
+    FRT_REQUIRE(n_stages >= 1 && n_stages < kNOctave && ring_length >= 16, "frt_delay_create: bad n_stages %d / ring length %d", n_stages,
+                ring_length);
+    frt_delay* h = new frt_delay();
+    h->n_stages = n_stages;
+    h->ring_len = ring_length;
+    int rc = frt_octbank_create(&h->dec, 0, 2, 0, nullptr, nullptr, bdec, adec, nullptr, nullptr);
+    if (!rc && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) rc = FRT_ERR_HIP;
+    if (!rc) rc = frt_octbank_set_stream(h->dec, h->stream);
+    for (int s = 0; !rc && s < frt_delay::kSlots; ++s)
+        if (hipEventCreateWithFlags(&h->done[s], hipEventDisableTiming) != hipSuccess) rc = FRT_ERR_HIP;
+    if (!rc) rc = h->ring.reserve((size_t)2 * 2 * ring_length * sizeof(double));
+    if (!rc) rc = h->stats.reserve(2 * sizeof(double));
+    if (!rc && hipMemsetAsync(h->ring.ptr, 0, h->ring.bytes, h->stream) != hipSuccess) rc = FRT_ERR_HIP;
+    if (rc) {
+        frt_delay_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return FRT_OK;
+}
+
+extern "C" void* frt_delay_stream(frt_delay* h) { return h ? (void*)h->stream : nullptr; }
+
+// The rings hold at least `length` samples from now on (RingBuffer.grow_if_needed, ringbuffer.py:102-130: x1.5).
+extern "C" int frt_delay_reserve(frt_delay* h, int length) {
+    FRT_REQUIRE(h && length >= 1, "frt_delay_reserve: bad arguments");
+    if (length <= h->ring_len) return FRT_OK;
+    const long long new_len = (long long)(1.5 * length);
+    DeviceBuffer grown;
+    int rc;
+    if ((rc = grown.reserve((size_t)2 * 2 * new_len * sizeof(double)))) return rc;
+    FRT_HIP_CHECK(hipMemsetAsync(grown.ptr, 0, grown.bytes, h->stream));
+    const long long shift = ((h->offset % new_len - h->offset % h->ring_len) % new_len + new_len) % new_len;
+    hipLaunchKernelGGL(delay_ring_relay_kernel, dim3((unsigned)((h->ring_len + 255) / 256), 2), dim3(256), 0, h->stream,
+                       h->ring.as<double>(), h->ring_len, grown.as<double>(), new_len, shift);
+    FRT_HIP_CHECK(hipGetLastError());
+    FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->ring.release();
+    h->ring = grown;
+    grown.ptr = nullptr;
+    grown.bytes = 0;
+    h->ring_len = new_len;
+    return FRT_OK;
+}
+
+// One chunk of both channels: x [2][n] float64 in host memory.  Returns (offset_out) the number of decimated samples in
+// the rings afterwards.  Asynchronous: the work is enqueued on the object's stream, nothing is waited for.
+extern "C" int frt_delay_push(frt_delay* h, const double* x, int n, int64_t* offset_out) {
+    FRT_REQUIRE(h && n >= 0, "frt_delay_push: bad arguments");
+    if (offset_out) *offset_out = h->offset;
+    if (n == 0) return FRT_OK;
+    FRT_REQUIRE(x && !is_device_pointer(x), "frt_delay_push: x must be a host array");
+    int len[kNOctave];
+    stage_lengths(n, len);
+    const int m = len[h->n_stages];
+    int rc;
+    if (m > h->ring_len && (rc = frt_delay_reserve(h, m))) return rc;
+    // the chunk travels through a pinned slot (an asynchronous copy needs page-locked memory to be asynchronous)
+    const int s = h->slot;
+    h->slot = (s + 1) % frt_delay::kSlots;
+    if (h->pending[s]) {
+        FRT_HIP_CHECK(hipEventSynchronize(h->done[s]));
+        h->pending[s] = false;
+    }
+    const size_t xbytes = (size_t)2 * n * sizeof(double);
+    if (xbytes > h->pin_bytes[s]) {
+        if (h->pin[s]) (void)hipHostFree(h->pin[s]);
+        h->pin[s] = nullptr;
+        h->pin_bytes[s] = 0;
+        FRT_HIP_CHECK(hipHostMalloc((void**)&h->pin[s], 2 * xbytes, hipHostMallocDefault));
+        h->pin_bytes[s] = 2 * xbytes;
+    }
+    memcpy(h->pin[s], x, xbytes);
+    if ((rc = h->xin.reserve(xbytes))) return rc;
+    FRT_HIP_CHECK(hipMemcpyAsync(h->xin.ptr, h->pin[s], xbytes, hipMemcpyHostToDevice, h->stream));
+    FRT_HIP_CHECK(hipEventRecord(h->done[s], h->stream));
+    h->pending[s] = true;
+    frt_octbank* d = h->dec;
+    for (int j = 1; j <= h->n_stages; ++j)
+        if ((rc = d->xbuf[j].reserve((size_t)2 * len[j] * sizeof(double)))) return rc;
+    for (int j = 0; j < h->n_stages; ++j) {
+        IirStageArgs a{};
+        a.x = j == 0 ? h->xin.ptr : d->xbuf[j].ptr;
+        a.x_stride = len[j];
+        a.n = len[j];
+        a.coef = d->coef.as<double>();
+        a.order = d->order.as<int>();
+        a.nfilt = 1;
+        a.dec_filter = 0;
+        a.state = d->state.as<double>() + (size_t)j * d->stage_state_elems();
+        a.chunk = (len[j] + 63) / 64 * 64;
+        a.nchunks = 1;
+        a.pass = 0;
+        a.band_index[0] = -1;
+        a.xnext = d->xbuf[j + 1].as<double>();
+        a.xnext_stride = len[j + 1];
+        if ((rc = launch_iir_stage(a, d->h_order.data(), 2, h->stream))) return rc;
+    }
+    hipLaunchKernelGGL(delay_ring_write_kernel, dim3((m + 255) / 256, 2), dim3(256), 0, h->stream, d->xbuf[h->n_stages].as<double>(), m,
+                       h->ring.as<double>(), h->ring_len, h->offset);
+    FRT_HIP_CHECK(hipGetLastError());
+    h->offset += m;
+    if (offset_out) *offset_out = h->offset;
+    return FRT_OK;
+}
+
+// Device pointers of the two windows of `length` samples ending at absolute index `end` (RingBuffer.data_indexed).
+extern "C" int frt_delay_window(frt_delay* h, int64_t end, int length, double** d0, double** d1) {
+    FRT_REQUIRE(h && d0 && d1 && length >= 1, "frt_delay_window: bad arguments");
+    FRT_REQUIRE(end >= 0 && end <= h->offset, "frt_delay_window: end index %lld outside [0, %lld]", (long long)end, (long long)h->offset);
+    int rc;
+    const long long need = length + h->offset - end;              // ringbuffer.py:96: grow_if_needed(length + offset - start)
+    FRT_REQUIRE(need < (1ll << 30), "frt_delay_window: window too far back");
+    if (need > h->ring_len && (rc = frt_delay_reserve(h, (int)need))) return rc;
+    const long long stop = end % h->ring_len + h->ring_len;       // ringbuffer.py:91-92
+    *d0 = h->ring.as<double>() + (stop - length);
+    *d1 = h->ring.as<double>() + 2 * h->ring_len + (stop - length);
+    return FRT_OK;
+}
+
+// numpy.std of both windows (the gate of delay_estimator.py:127); waits for everything enqueued before.
+extern "C" int frt_delay_window_std(frt_delay* h, const double* d0, const double* d1, int length, double* std_out) {
+    FRT_REQUIRE(h && d0 && d1 && std_out && length >= 1, "frt_delay_window_std: bad arguments");
+    hipLaunchKernelGGL(delay_window_std_kernel, dim3(2), dim3(1024), 0, h->stream, d0, d1, length, h->stats.as<double>());
+    FRT_HIP_CHECK(hipGetLastError());
+    FRT_HIP_CHECK(hipMemcpyAsync(std_out, h->stats.ptr, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    for (int s = 0; s < frt_delay::kSlots; ++s) h->pending[s] = false;
+    return FRT_OK;
+}
+
+// The in-place mean removal of generalized_cross_correlation (correlation.py:27-28) on the ring views.
+// `means`: two doubles in device memory (what frt_gcc_phat wrote); `stream`: the stream frt_gcc_phat ran on (the removal
+// must follow its reads of the windows), null = the object's own.
+extern "C" int frt_delay_demean(frt_delay* h, double* d0, double* d1, int length, const double* means, void* stream) {
+    FRT_REQUIRE(h && d0 && d1 && means && length >= 1, "frt_delay_demean: bad arguments");
+    hipLaunchKernelGGL(delay_demean_kernel, dim3((length + 255) / 256, 2), dim3(256), 0, stream ? (hipStream_t)stream : h->stream, d0, d1,
+                       length, means);
+    FRT_HIP_CHECK(hipGetLastError());
     return FRT_OK;
 }

@@ -82,11 +82,13 @@ class DelayEstimator:
 
 
 class DelayEstimatorStream(DelayEstimator):
-    """The same chain with its signals resident in HBM: the two-stage decimation runs on a two-channel bank object whose
-    filter states stay on the device, the 12 kHz rings are DeviceRingBuffers (same layout and growth as the host ring),
-    windows go to GCC-PHAT and the read-out as device slices, and the in-place mean removal the reference applies to its
-    ring views (correlation.py:27-28) is applied to the same slices.  Per chunk only the new samples go up; per window
-    two scalars (the std test of delay_estimator.py:127-129) and the read-out come down."""
+    """The same chain with its signals resident in HBM, on one C object (frt_delay_*, include/friture_hip.h): per chunk the
+    new samples go up through a pinned slot, the two decimation stages (filter states on the device) and one ring-write
+    launch are enqueued on the object's stream and the call returns — nothing comes back.  Once per `needed` decimated
+    samples a window of both rings (device pointers, same indices / mirror layout / growth as RingBuffer) goes to GCC-PHAT
+    and the read-out on the same stream; the in-place mean removal the reference applies to its ring views
+    (correlation.py:27-28) is applied to the same samples.  Per window two scalars (the std test of
+    delay_estimator.py:127-129) and the read-out come down."""
 
     def __init__(self, delayrange_s: float = DEFAULT_DELAYRANGE):
         super().__init__(delayrange_s)
@@ -95,45 +97,38 @@ class DelayEstimatorStream(DelayEstimator):
         import torch
 
         from . import _lib
-        from .ringbuffer import DeviceRingBuffer
         self._torch, self._ct, self._libmod = torch, ctypes, _lib
         self._lib = _lib.init()
-        self.ringbuffer0, self.ringbuffer1 = DeviceRingBuffer(), DeviceRingBuffer()
-        self._dec = ctypes.c_void_p()
+        self.ringbuffer0 = self.ringbuffer1 = None              # the rings live inside the C object
+        self._h = ctypes.c_void_p()
         DP = ctypes.POINTER(ctypes.c_double)
         b, a = np.ascontiguousarray(self.bdec, np.float64), np.ascontiguousarray(self.adec, np.float64)
-        _lib.check(self._lib.frt_octbank_create(ctypes.byref(self._dec), 0, 2, 0, None, None, b.ctypes.data_as(DP), a.ctypes.data_as(DP),
-                                                None, None))
+        _lib.check(self._lib.frt_delay_create(ctypes.byref(self._h), b.ctypes.data_as(DP), a.ctypes.data_as(DP), self.Ndec, 10000))
+        self._stream = ctypes.c_void_p(self._lib.frt_delay_stream(self._h))
         self._dev = torch.device("cuda", torch.cuda.current_device())
+        self._offset = ctypes.c_int64(0)
+        self._push = self._lib.frt_delay_push
+        self.offset = 0
 
     def __del__(self):
         try:
-            if self._dec.value:
-                self._lib.frt_octbank_destroy(self._dec)
+            if self._h.value:
+                self._lib.frt_delay_destroy(self._h)
         except Exception:
             pass
 
     def handle_new_data(self, floatdata):
-        torch, ct, check = self._torch, self._ct, self._libmod.check
         if floatdata.shape[0] == 1:
             self.two_channels = False
             return
         self.two_channels = True
-        x = torch.from_numpy(np.ascontiguousarray(floatdata[:2], np.float64)).to(self._dev)
-        n = x.shape[1]
-        n_out = ct.c_int(0)
-        dec = torch.empty((2, (n + 3) // 4 + 1), dtype=torch.float64, device=self._dev)
-        stream = ct.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(self._lib.frt_octbank_set_stream(self._dec, stream))
-        packed = torch.empty((2 * ((n + 3) // 4 + 1),), dtype=torch.float64, device=self._dev)
-        check(self._lib.frt_decimate_multiple(self._dec, self.Ndec, ct.c_void_p(x.data_ptr()), n, ct.c_void_p(packed.data_ptr()),
-                                              ct.byref(n_out)))
-        m = n_out.value
-        dec = packed[:2 * m].view(2, m)
-        self.ringbuffer0.push(dec[0:1], 0)
-        self.ringbuffer1.push(dec[1:2], 0)
-
-        index = self.ringbuffer0.offset
+        x = floatdata[:2]
+        if x.dtype != np.float64 or not x.flags.c_contiguous:
+            x = np.ascontiguousarray(x, np.float64)
+        rc = self._push(self._h, x.ctypes.data, x.shape[1], self._offset)
+        if rc:
+            self._libmod.check(rc)
+        index = self.offset = self._offset.value
         available = index - self.old_index
         if available < 0:
             available = 0
@@ -141,19 +136,24 @@ class DelayEstimatorStream(DelayEstimator):
         time = 2 * self.delayrange_s
         length = int(time * self.subsampled_sampling_rate)
         needed = int(0.5 * length)
-        for _ in range(int(available / needed)):
+        if available >= needed:
+            self._windows(int(available / needed), length, needed)
+
+    def _windows(self, count, length, needed):
+        torch, ct, check, lib = self._torch, self._ct, self._libmod.check, self._lib
+        for _ in range(count):
             self.old_index += needed
-            d0 = self.ringbuffer0.data_indexed(self.old_index, length)          # [1, length] device views into the rings
-            d1 = self.ringbuffer1.data_indexed(self.old_index, length)
-            stds = torch.stack([d0.std(unbiased=False), d1.std(unbiased=False)]).cpu()
+            p0, p1 = ct.c_void_p(), ct.c_void_p()
+            check(lib.frt_delay_window(self._h, self.old_index, length, ct.byref(p0), ct.byref(p1)))
+            stds = (ct.c_double * 2)()
+            check(lib.frt_delay_window_std(self._h, p0, p1, length, stds))
             if stds[0] > 0. and stds[1] > 0.:
                 if self._gcc is None or self._gcc.length != length:
                     self._gcc = GccPhat(length, 1)
-                Xcorr, _ = self._gcc.correlate(d0.contiguous(), d1.contiguous())
-                d0 -= self._gcc.means[0, 0]                                     # the reference de-means its views in place
-                d1 -= self._gcc.means[0, 1]
+                Xcorr = self._gcc.correlate_windows(p0, p1, self._dev, self._stream)
+                check(lib.frt_delay_demean(self._h, p0, p1, length, ct.c_void_p(self._gcc.means.data_ptr()), None))
                 old = self.old_Xcorr if self.old_Xcorr is not None and self.old_Xcorr.shape == Xcorr.shape else None
-                smoothed, ro = self._gcc.readout(Xcorr, old, self.subsampled_sampling_rate, self.delayrange_s, 0.3)
+                smoothed, ro = self._gcc.readout(Xcorr, old, self.subsampled_sampling_rate, self.delayrange_s, 0.3, stream=self._stream)
                 self.old_Xcorr = smoothed
                 self.Xcorr_extremum = ro[0].extremum
                 self.delay_ms = ro[0].delay_ms
@@ -164,3 +164,19 @@ class DelayEstimatorStream(DelayEstimator):
                 self.Xcorr_extremum = 0.
                 self.distance_m = 0.
                 self.correlation = 0
+
+    def window(self, end, length):
+        """Host copy [2, length] of the two windows that end at absolute index `end` (tests, inspection)."""
+        torch, ct, check = self._torch, self._ct, self._libmod.check
+        p0, p1 = ct.c_void_p(), ct.c_void_p()
+        check(self._lib.frt_delay_window(self._h, end, length, ct.byref(p0), ct.byref(p1)))
+        stds = (ct.c_double * 2)()
+        check(self._lib.frt_delay_window_std(self._h, p0, p1, length, stds))                 # waits for the pushes in flight
+        return np.stack([torch.as_tensor(_DeviceView(p.value, length), device=self._dev).cpu().numpy() for p in (p0, p1)])
+
+
+class _DeviceView:
+    """`length` float64 values at a device address, for torch.as_tensor (CUDA array interface)."""
+
+    def __init__(self, ptr, length):
+        self.__cuda_array_interface__ = {"shape": (length,), "typestr": "<f8", "data": (ptr, False), "version": 2}

@@ -79,7 +79,17 @@ class GccPhat:
         _lib.check(self._lib.frt_gcc_phat(self._h, d0.ctypes.data, d1.ctypes.data, out.ctypes.data, am.ctypes.data, None))
         return out, am
 
-    def readout(self, xcorr, old_smoothed, sample_rate, delayrange_s, alpha=0.3):
+    def correlate_windows(self, p0, p1, device, stream):
+        """The same for windows given as device POINTERS (ctypes.c_void_p; frt_delay_window), on HIP stream `stream`
+        (ctypes.c_void_p).  Returns the correlation as a torch tensor [n_pairs, length]; the means stay in self.means."""
+        import torch
+        out = torch.empty((self.n_pairs, self.length), dtype=torch.float64, device=device)
+        self.means = torch.empty((self.n_pairs, 2), dtype=torch.float64, device=device)
+        _lib.check(self._lib.frt_gcc_set_stream(self._h, stream))
+        _lib.check(self._lib.frt_gcc_phat(self._h, p0, p1, ctypes.c_void_p(out.data_ptr()), None, ctypes.c_void_p(self.means.data_ptr())))
+        return out
+
+    def readout(self, xcorr, old_smoothed, sample_rate, delayrange_s, alpha=0.3, stream=None):
         """Smoothing + peak pick + delay / confidence (delay_estimator.py:134-176).
         Returns (smoothed [n_pairs, length], list of DelayReadout)."""
         if type(xcorr).__module__.startswith("torch"):
@@ -87,7 +97,8 @@ class GccPhat:
             assert xcorr.is_cuda and xcorr.dtype == torch.float64 and xcorr.is_contiguous()
             sm = torch.empty_like(xcorr)
             ro = (_lib.DelayReadout * self.n_pairs)()
-            _lib.check(self._lib.frt_gcc_set_stream(self._h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            _lib.check(self._lib.frt_gcc_set_stream(self._h, stream if stream is not None
+                                                    else ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
             _lib.check(self._lib.frt_gcc_readout(self._h, ctypes.c_void_p(xcorr.data_ptr()),
                                                  None if old_smoothed is None else ctypes.c_void_p(old_smoothed.data_ptr()), alpha,
                                                  float(sample_rate), float(delayrange_s), ctypes.c_void_p(sm.data_ptr()), ctypes.byref(ro)))

@@ -152,6 +152,30 @@ int frt_decimate_multiple(frt_octbank* h, int n_stages, const double* x, int n, 
 int frt_lfilter_f64(const double* b, const double* a, int n_coef, const double* x, int n, const double* zi,
                     double* y, double* zf);
 
+/* ---- the delay estimator's per-chunk part, device resident (SURVEY.md §8 row 5 caller) -----------------------------
+ * Delay_Estimator_Widget.handle_new_data (friture/delay_estimator.py:87-131) without its GCC-PHAT call: per chunk of both
+ * channels, n_stages chained decimations by 2 with carried state (:97-98, decimate_multiple) and a push into two private
+ * mirror rings of the decimated signals (:99-100, friture/ringbuffer.py:39-63), all in HBM.  frt_delay_push is
+ * asynchronous (a pinned slot, the decimation stages and one ring-write launch on the object's stream; nothing comes back
+ * per chunk).  Windows are handed out as device pointers into the rings (RingBuffer.data_indexed, ringbuffer.py:87-99; the
+ * rings grow by the reference's rule, ringbuffer.py:102-130) and go to frt_gcc_phat / frt_gcc_readout as they are. */
+typedef struct frt_delay frt_delay;
+int frt_delay_create(frt_delay** out, const double* bdec, const double* adec, int n_stages, int ring_length /* 10000 */);
+void frt_delay_destroy(frt_delay* h);
+void* frt_delay_stream(frt_delay* h);                 /* the hipStream_t the pushes are enqueued on */
+/* x: float64 [2][n] in HOST memory; *offset_out = decimated samples pushed so far (RingBuffer.offset), may be NULL */
+int frt_delay_push(frt_delay* h, const double* x, int n, int64_t* offset_out);
+/* the rings hold at least `length` samples from now on (RingBuffer.grow_if_needed) */
+int frt_delay_reserve(frt_delay* h, int length);
+/* device pointers of the `length` samples of each ring that end at absolute index `end` (<= offset); valid until the
+ * rings grow.  Enqueued pushes may still be in flight: order consumers on frt_delay_stream or call frt_delay_window_std. */
+int frt_delay_window(frt_delay* h, int64_t end, int length, double** d0, double** d1);
+/* numpy.std of both windows (the gate of delay_estimator.py:127) -> std_out[2] on the host; waits for the object's stream */
+int frt_delay_window_std(frt_delay* h, const double* d0, const double* d1, int length, double* std_out);
+/* d0 -= means[0], d1 -= means[1] in place (generalized_cross_correlation does this to its views, correlation.py:27-28);
+ * means: two doubles in DEVICE memory (frt_gcc_phat's means_out); stream: the stream frt_gcc_phat ran on, NULL = the object's */
+int frt_delay_demean(frt_delay* h, double* d0, double* d1, int length, const double* means, void* stream);
+
 /* ---- device-resident streaming spectrogram ------------------------------------------------
  * One object does what Spectrogram_Widget.handle_new_data does per chunk (friture/spectrogram.py:131-177) and hands back
  * the block CanvasScaledSpectrogram.addData draws (friture/spectrogram_image.py:82-129): a mirror ring of the samples in

@@ -213,6 +213,44 @@ def test_delay_estimator_stream_equals_host_chain(hip):
         assert windows > 0 and abs(a.delay_ms - 1e3 * 31 / 12000.0) < 0.1
 
 
+def test_delay_object_rings_equal_host_rings(hip):
+    """frt_delay_* (decimation states and both 12 kHz mirror rings inside one C object, pushes asynchronous): the windows it
+    hands out hold the same bits as the host chain's RingBuffer views — before the rings have filled (zeros), across the
+    growth from 10000 samples, with ragged chunk lengths, and after the in-place mean removal of earlier windows."""
+    from friture_amd.delay_estimator import DelayEstimator, DelayEstimatorStream
+    a, b = DelayEstimator(0.4), DelayEstimatorStream(0.4)
+    rng = np.random.default_rng(5)
+    pos_total = 0
+    for i, n in enumerate([512, 512, 37, 1, 1024, 4096, 511] * 12):
+        x0 = 0.3 * rng.standard_normal(n) + 0.05
+        chunk = np.stack([x0, 0.5 * x0 + 0.01 * rng.standard_normal(n)])
+        a.handle_new_data(chunk)
+        b.handle_new_data(chunk)
+        assert a.ringbuffer0.offset == b.offset
+        if i % 5 == 0:
+            for end, length in ((b.offset, 300), (b.offset - b.offset // 3, 2000), (b.offset, 9000 + 700 * (i // 5))):
+                ref = np.concatenate([a.ringbuffer0.data_indexed(end, length), a.ringbuffer1.data_indexed(end, length)])
+                assert np.array_equal(b.window(end, length), ref), (i, end, length)
+    assert a.delay_ms == b.delay_ms and a.correlation == b.correlation and a.correlation > 0
+
+
+def test_delay_object_argument_checks(hip):
+    import ctypes
+
+    from friture_amd import _lib
+    from friture_amd.delay_estimator import DelayEstimatorStream
+    b = DelayEstimatorStream(0.4)
+    p0, p1 = ctypes.c_void_p(), ctypes.c_void_p()
+    with pytest.raises(_lib.FritureHipError):
+        _lib.check(hip.frt_delay_window(b._h, 10, 100, ctypes.byref(p0), ctypes.byref(p1)))      # nothing pushed yet
+    b.handle_new_data(np.zeros((2, 512)))
+    assert b.offset == 128
+    b.handle_new_data(np.zeros((1, 512)))            # mono: no push (delay_estimator.py:89-91)
+    assert b.offset == 128 and not b.two_channels
+    b.handle_new_data(np.zeros((2, 0)))
+    assert b.offset == 128
+
+
 def test_gcc_small_batch_path_equals_one_workgroup_path(hip, monkeypatch):
     """Batches that would leave most CUs idle run a pair's sub-transforms as workgroups of their own (five launches);
     the arithmetic is the one-workgroup kernel's: identical bits, for R = 1, 2 and 4."""
