@@ -1637,6 +1637,7 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
     FRT_REQUIRE(h && h->bpo >= 1, "frt_octbank_energies: needs a handle with bands");
     // mode 1, ONE block of any length up to 1024 = the octave-spectrum widget's chunk handler (octavespectrum.py:91-122)
     const bool chunk_call = h->mode == 1 && n == block && block >= 1 && block <= 1024;
+    const bool chunk_kernels = chunk_call && getenv("FRT_OLA_NO_CHUNK_KERNELS") == nullptr;      // A/B and tests: the transform path
     FRT_REQUIRE(chunk_call || (block >= 256 && (block & (block - 1)) == 0), "frt_octbank_energies: block %d must be a power of two >= 256", block);
     FRT_REQUIRE(h->mode == 0 || block <= 1024, "frt_octbank_energies: the FFT bank's cadence is blocks of at most 1024 samples");
     FRT_REQUIRE(n > 0 && n % block == 0 && n < (1ll << 31), "frt_octbank_energies: n must be a positive multiple of block");
@@ -1701,9 +1702,26 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
             }
             memcpy(h->pin_in, x, xbytes);
         }
-        FRT_HIP_CHECK(hipMemcpyAsync(h->xin.ptr, pinned ? (const void*)h->pin_in : (const void*)x, xbytes, hipMemcpyHostToDevice, h->stream));
-        d_x = h->xin.ptr;
-        d_out = h->eout.as<float>();
+        if (chunk_kernels && pinned) {
+            d_x = h->pin_in;                       // the two launches read the chunk and write the band vector in place
+            d_out = (float*)h->pin_out;
+        } else {
+            FRT_HIP_CHECK(hipMemcpyAsync(h->xin.ptr, pinned ? (const void*)h->pin_in : (const void*)x, xbytes, hipMemcpyHostToDevice, h->stream));
+            d_x = h->xin.ptr;
+            d_out = h->eout.as<float>();
+        }
+    }
+    if (chunk_kernels) {
+        // the widget's chunk: the running convolutions themselves, two launches (ola.hip, chunk path)
+        if ((rc = frt_ola_chunk_energies(h, d_x, 1, (int)n, alphas, h->decay_n.as<double>(), h->smooth.as<double>(),
+                                         weight_db ? h->weight.as<double>() : nullptr, as_db, d_out, 1)))
+            return rc;
+        if (!dx) {
+            if (!pinned) FRT_HIP_CHECK(hipMemcpyAsync(energy_out, d_out, obytes, hipMemcpyDeviceToHost, h->stream));
+            FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+            if (pinned) memcpy(energy_out, h->pin_out, obytes);
+        }
+        return FRT_OK;
     }
     if (h->mode == 1) rc = frt_ola_filter_batch(h, d_x, 1, n, nullptr, 0, h->eblock.as<double>(), block, nblocks, alphas);
     else rc = run_stages(h, d_x, 1, n, (int)n, nullptr, 0, h->eblock.as<double>(), block, nblocks);

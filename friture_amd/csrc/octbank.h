@@ -33,6 +33,9 @@ struct frt_ola_state {
     int ewt_block = 0;
     std::vector<double> ewt_alpha;
     std::vector<double> h_taps;         // [nfilt][512] kept for the lazily built tables
+    // chunk path (ola.hip, ola_chunk_*_kernel): the taps themselves and the per-band weight offsets on the device
+    frt::DeviceBuffer taps, ewt_off_dev, xs;
+    int ewt_n = -1;                     // chunk length the `whole` weights were built for
 };
 
 struct frt_octbank {
@@ -83,3 +86,8 @@ int frt_ola_filter(frt_octbank* h, const double* d_x, int n, double* d_y, int64_
 // zero-state block energies for blocks of eblock0 input samples to d_eblock [C][nblocks][nbands] (nullable)
 int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, double* d_y, int64_t y_cstride,
                          double* d_eblock, int eblock0, int nblocks, const double* alphas);
+// one chunk of 1..1024 samples = one energy block (the octave-spectrum widget's handler): the smoothed band energies of
+// x [C][n] (device-accessible memory: HBM or pinned host) straight to `out` [C][nbands] (float when out_f32; device-accessible),
+// two launches; decay_n / smooth / weight_db: the handle's device tables (weight_db nullable)
+int frt_ola_chunk_energies(frt_octbank* h, const void* x, int x_f32, int n, const double* alphas, const double* d_decay_n,
+                           double* d_smooth, const double* d_weight_db, int as_db, void* out, int out_f32);

@@ -200,6 +200,9 @@ void frt_ola_destroy(frt_octbank* h) {
     h->ola->btwl.release();
     h->ola->bH.release();
     h->ola->ewt.release();
+    h->ola->taps.release();
+    h->ola->ewt_off_dev.release();
+    h->ola->xs.release();
     delete h->ola;
     h->ola = nullptr;
 }
@@ -607,6 +610,32 @@ static int ola_batch_tables(frt_octbank* h) {
     return FRT_OK;
 }
 
+// smoothing weights per band: alpha (1 - alpha)^(m - 1 - i), m = the band's samples per energy block — eblock0 / dec, or
+// (whole) the band's stage length of an n-sample chunk (exp_smoothing.py:40-56 with the kernels of octavespectrum.py:77-81)
+static int ola_energy_weights(frt_octbank* h, int64_t n, int eblock0, bool whole, const double* alphas) {
+    frt_ola_state* o = h->ola;
+    bool same = o->ewt_block == eblock0 && (int)o->ewt_alpha.size() == h->nbands && (!whole || o->ewt_n == (int)n);
+    for (int k = 0; same && k < h->nbands; ++k) same = o->ewt_alpha[k] == alphas[k];
+    if (same) return FRT_OK;
+    o->ewt_off.assign(h->nbands, 0);
+    std::vector<double> wt;
+    long long slen[kNOctave];
+    slen[0] = n;
+    for (int j = 1; j < kNOctave; ++j) slen[j] = (slen[j - 1] + 1) / 2;
+    for (int k = 0; k < h->nbands; ++k) {
+        const int m = whole ? (int)slen[kNOctave - 1 - k / h->bpo] : eblock0 >> (kNOctave - 1 - k / h->bpo);
+        o->ewt_off[k] = (long long)wt.size();
+        for (int i = 0; i < m; ++i) wt.push_back(alphas[k] * std::pow(1.0 - alphas[k], (double)(m - 1 - i)));
+    }
+    FRT_HIP_CHECK(hipStreamSynchronize(h->stream));      // the old tables may still be read
+    int rc;
+    if ((rc = upload(o->ewt, wt)) || (rc = upload(o->ewt_off_dev, o->ewt_off))) return rc;
+    o->ewt_block = eblock0;
+    o->ewt_n = whole ? (int)n : -1;
+    o->ewt_alpha.assign(alphas, alphas + h->nbands);
+    return FRT_OK;
+}
+
 int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, double* d_y, int64_t y_cstride,
                          double* d_eblock, int eblock0, int nblocks, const double* alphas) {
     frt_ola_state* o = h->ola;
@@ -621,28 +650,7 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
         if ((rc = h->xbuf[j].reserve((size_t)h->n_channels * len[j] * sizeof(double)))) return rc;
     std::vector<long long> band_off(h->nbands + 1, 0);
     for (int k = 0; k < h->nbands; ++k) band_off[k + 1] = band_off[k] + len[kNOctave - 1 - k / h->bpo];
-    if (d_eblock) {
-        // smoothing weights per band: alpha (1 - alpha)^(m - 1 - i), m = eblock0 / dec (exp_smoothing.py:40-56 with the
-        // kernels of octavespectrum.py:77-81)
-        bool same = o->ewt_block == eblock0 && (int)o->ewt_alpha.size() == h->nbands;
-        for (int k = 0; same && k < h->nbands; ++k) same = o->ewt_alpha[k] == alphas[k];
-        if (!same) {
-            o->ewt_off.assign(h->nbands, 0);
-            std::vector<double> wt;
-            long long slen[kNOctave];
-            slen[0] = n;
-            for (int j = 1; j < kNOctave; ++j) slen[j] = (slen[j - 1] + 1) / 2;
-            for (int k = 0; k < h->nbands; ++k) {
-                const int m = whole ? (int)slen[kNOctave - 1 - k / h->bpo] : eblock0 >> (kNOctave - 1 - k / h->bpo);
-                o->ewt_off[k] = (long long)wt.size();
-                for (int i = 0; i < m; ++i) wt.push_back(alphas[k] * std::pow(1.0 - alphas[k], (double)(m - 1 - i)));
-            }
-            FRT_HIP_CHECK(hipStreamSynchronize(h->stream));      // the old table may still be read
-            if ((rc = upload(o->ewt, wt))) return rc;
-            o->ewt_block = eblock0;
-            o->ewt_alpha.assign(alphas, alphas + h->nbands);
-        }
-    }
+    if (d_eblock && (rc = ola_energy_weights(h, n, eblock0, whole, alphas))) return rc;
     const size_t stage_pend = (size_t)h->n_channels * h->nfilt * kTail;
     for (int j = 0; j < kNOctave; ++j) {
         OlaBatchArgs a{};
@@ -686,5 +694,279 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
         FRT_HIP_CHECK(hipGetLastError());
     }
     std::swap(o->pending.ptr, o->pending_next.ptr);             // equal sizes; the streaming path and the graphs follow `pending`
+    return FRT_OK;
+}
+
+
+// ---- chunk path: ONE block of 1..1024 samples, the octave-spectrum widget's handler (octavespectrum.py:91-122) ------------
+// The streaming object pushes one audio chunk (512 samples) at a time and wants 9 x bpo numbers back.  Through the
+// transform kernels above that is nine DEPENDENT launches (the stages chain through the decimated signal) of ~10 us each,
+// whatever the stage length — a 4096-point window to filter the two samples of stage 8.  At these sizes the running
+// convolution itself is cheaper than its FFT form: a stage's block contributes
+//     contrib[t] = sum_k h[k] x[t - k],   0 <= t < m + 511
+// to its own outputs (t < m, plus the carried tail pending[t]) and to the next tail (pending'[t'] = contrib[m + t'] +
+// pending[m + t']) — the same sums the overlap-add forms through X H (filter.py:213-245), in float64, to rounding.  Two launches:
+//   A  one workgroup per channel walks the DECIMATOR through stages 0..7: only the even outputs (the next stage's input,
+//      y_dec[:m:2]) and the new tail, 0.43 M multiply-adds for a 512-sample chunk;
+//   B  one workgroup per (stage, band filter, channel): outputs, tail, the block's smoothed energy
+//      sum_t alpha (1 - alpha)^(m-1-t) y[t]^2 + (1 - alpha)^m sp_prev (exp_smoothing.py:40-56) and the dB value.
+// A thread owns a PAIR of consecutive outputs (t even): per two taps it reads one aligned pair of input samples from LDS
+// (the previous pair stays in registers) for four multiply-adds; the taps are wave-uniform and come through the scalar
+// cache.  The stage input sits in LDS between zeros, so no tap needs a range test; a wavefront only walks the taps that
+// can meet a sample for one of its outputs.
+constexpr int kOcThreads = 1024;
+constexpr int kOcFront = kFirLength - 1;                 // zeros in front of the samples: t - k >= -511
+constexpr int kOcMaxN = 1024;
+constexpr int kOcPadLen = kOcFront + kOcMaxN + kFirLength + 1;      // ... and behind: t + 2 - k <= m + 511
+static_assert(kOcPadLen % 2 == 0 && kOcFront % 2 == 1, "pairs (x[t-k-1], x[t-k]) start at even LDS indices for even t, k");
+
+struct OlaChunkArgs {
+    const void* x;             // [C][x_stride] chunk: float (x_f32) or double; device-accessible (HBM or pinned host)
+    int x_f32;
+    long long x_stride;
+    int len[kNOctave];         // stage lengths
+    int xoff[kNOctave];        // stage inputs inside a channel's row of xs
+    double* xs;                // [C][xs_stride]
+    long long xs_stride;
+    const double* taps;        // [nfilt][512]
+    double* pending;           // [9][C][nfilt][511]
+    int nfilt, bpo, n_channels, nbands;
+    const double* ewt;         // alpha (1 - alpha)^(m - 1 - t) per band at ewt_off
+    const long long* ewt_off;
+    const double* decay_n;     // (1 - alpha)^m per band
+    double* smooth;            // [C][nbands] carried smoothed energies
+    const double* weight_db;   // [nbands] or null
+    int as_db;
+    void* out;                 // [C][nbands]
+    int out_f32;
+};
+
+typedef const double __attribute__((address_space(4))) * oc_ktable;
+
+// (y0, y1) = contrib[t], contrib[t + 1] for even t over the taps k0 .. k1 + 7 (k0, k1 multiples of 8, wave-uniform).
+// Eight taps per trip: four aligned sample pairs and the eight taps are fetched for the NEXT trip while this trip's sixteen
+// multiply-adds issue (one pair and two taps per trip left every load's latency in the open).
+template <bool BOTH>
+__device__ __forceinline__ void oc_fir_pair(const double* xpad, int t, oc_ktable h, int k0, int k1, double& y0, double& y1) {
+    const double2* p = (const double2*)(xpad + (kOcFront + t - k0 - 1));       // (x[t-k-1], x[t-k]) at k = k0
+    double2 hi = p[1];                                                           // (x[t-k+1], x[t-k+2])
+    double2 lo[4];
+    double hk[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lo[q] = p[-q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) hk[q] = h[k0 + q];
+    double a0 = 0.0, a1 = 0.0;
+    for (int k = k0; k <= k1; k += 8) {
+        double2 cur[4];
+        double hc[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = lo[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hc[q] = hk[q];
+        p -= 4;
+        if (k + 8 <= k1) {                                   // uniform
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lo[q] = p[-q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) hk[q] = h[k + 8 + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a0 = __builtin_fma(hc[2 * q], cur[q].y, a0);
+            a0 = __builtin_fma(hc[2 * q + 1], cur[q].x, a0);
+            if (BOTH) {
+                a1 = __builtin_fma(hc[2 * q], hi.x, a1);
+                a1 = __builtin_fma(hc[2 * q + 1], cur[q].y, a1);
+            }
+            hi = cur[q];
+        }
+    }
+    y0 = a0;
+    y1 = a1;
+}
+
+// tap range of a wavefront whose outputs span [t_lo, t_hi + 1] (even t_lo, t_hi): tap k meets a sample iff 0 <= t - k < m;
+// widened to whole groups of eight taps (the samples the extra taps meet are the zeros around the stage input)
+__device__ __forceinline__ void oc_tap_range(int t_lo, int t_hi, int m, int& k0, int& k1) {
+    k0 = t_lo + 1 - m;
+    k0 = k0 < 0 ? 0 : (k0 & ~7);
+    k1 = t_hi + 1 < kFirLength - 1 ? t_hi + 1 : kFirLength - 1;      // last tap that meets a sample
+    k1 &= ~7;                                                      // first tap of the last group
+    k0 = __builtin_amdgcn_readfirstlane(k0);
+    k1 = __builtin_amdgcn_readfirstlane(k1);
+}
+
+__device__ __forceinline__ void oc_stage_input(double* xpad, double* pend, const double* x, int m, const double* pend_g, int tid) {
+    for (int i = tid; i < kOcPadLen; i += kOcThreads) {
+        const int s = i - kOcFront;
+        xpad[i] = (s >= 0 && s < m) ? x[s] : 0.0;
+    }
+    for (int i = tid; i < kFirLength; i += kOcThreads) pend[i] = i < kTail ? pend_g[i] : 0.0;
+}
+
+// Launch A: the decimator's even outputs, stage after stage, nothing else — its new tails do not feed the chain and are
+// left to launch B.  The chain is a critical path (stage j + 1 waits for stage j), so a stage's outputs are spread over all
+// sixteen wavefronts: groups of 64 outputs x S parts of the group's tap range (a wavefront's taps stay uniform), the parts
+// summed in a fixed order afterwards.  The carried tails of all eight stages are fetched once, up front; the next stage's
+// input is written straight back into the LDS array (and to xs for launch B, not waited for).
+__global__ void __launch_bounds__(kOcThreads) ola_chunk_dec_kernel(const OlaChunkArgs a) {
+    __shared__ __attribute__((aligned(16))) double xpad[kOcPadLen];
+    __shared__ double pend[kNOctave - 1][kFirLength];
+    __shared__ double part[kOcThreads];
+    const int tid = threadIdx.x, c = blockIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int dec = a.bpo;
+    const oc_ktable h = (oc_ktable)(uintptr_t)(a.taps + (size_t)dec * kFirLength);
+    double* xs = a.xs + (size_t)c * a.xs_stride;
+    {
+        const int m = a.len[0];
+        for (int i = tid; i < kOcPadLen; i += kOcThreads) {
+            const int s = i - kOcFront;
+            double v = 0.0;
+            if (s >= 0 && s < m) {
+                const long long g = (long long)c * a.x_stride + s;
+                v = a.x_f32 ? (double)((const float*)a.x)[g] : ((const double*)a.x)[g];
+                xs[a.xoff[0] + s] = v;                    // the chunk as float64 for launch B
+            }
+            xpad[i] = v;
+        }
+        for (int i = tid; i < (kNOctave - 1) * kFirLength; i += kOcThreads) {
+            const int j = i / kFirLength, t = i - j * kFirLength;
+            pend[j][t] = t < kTail ? a.pending[(((size_t)j * a.n_channels + c) * a.nfilt + dec) * kTail + t] : 0.0;
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j + 1 < kNOctave; ++j) {
+        const int m = a.len[j], nh = (m + 1) / 2;
+        const int G = (nh + 63) / 64;                        // <= 8
+        const int S = G > 4 ? 2 : G > 2 ? 4 : G > 1 ? 8 : 16;
+        const int g = wave / S, sp = wave - g * S;
+        double y0 = 0.0, y1;
+        if (g < G) {
+            const int u0 = g * 64, u = u0 + lane;
+            const int ul = (u0 + 63 < nh ? u0 + 63 : nh - 1);
+            int k0, k1;
+            oc_tap_range(2 * u0, 2 * ul, m, k0, k1);
+            const int trips = (k1 - k0) / 8 + 1, per = (trips + S - 1) / S;
+            const int ka = k0 + 8 * per * sp;
+            int kb = ka + 8 * (per - 1);
+            kb = kb < k1 ? kb : k1;
+            if (ka <= kb) oc_fir_pair<false>(xpad, 2 * (u < nh ? u : nh - 1), h, ka, kb, y0, y1);
+        }
+        part[tid] = y0;
+        __syncthreads();                                     // every read of xpad is done
+        {
+            // thread u sums its output's parts; everybody clears what the shorter next stage no longer covers
+            const int u = tid;
+            if (u < nh) {
+                const int gg = u >> 6, l = u & 63, t = 2 * u;
+                double v = 0.0;
+                for (int q = 0; q < S; ++q) v += part[(gg * S + q) * 64 + l];
+                v += pend[j][t < kTail ? t : kTail];
+                xs[a.xoff[j + 1] + u] = v;
+                xpad[kOcFront + u] = v;
+            }
+            for (int i = nh + tid; i < m; i += kOcThreads) xpad[kOcFront + i] = 0.0;
+        }
+        __syncthreads();
+    }
+}
+
+// Launch B: one workgroup per (stage, band filter, channel) — outputs, new tail, smoothed energy, dB — plus eight per channel
+// for the decimator's new tails (stages 0..7).
+__global__ void __launch_bounds__(kOcThreads) ola_chunk_band_kernel(const OlaChunkArgs a) {
+    __shared__ __attribute__((aligned(16))) double xpad[kOcPadLen];
+    __shared__ double pend[kFirLength];
+    __shared__ double red[kOcThreads / 64];
+    const int tid = threadIdx.x, c = blockIdx.y, wave = tid >> 6, lane = tid & 63;
+    const int nb = kNOctave * a.bpo;
+    const bool is_dec = (int)blockIdx.x >= nb;
+    const int j = is_dec ? (int)blockIdx.x - nb : (int)blockIdx.x / a.bpo;
+    const int f = is_dec ? a.bpo : (int)blockIdx.x - j * a.bpo;
+    const int m = a.len[j];
+    const int band = is_dec ? 0 : (kNOctave - 1 - j) * a.bpo + f;
+    const oc_ktable h = (oc_ktable)(uintptr_t)(a.taps + (size_t)f * kFirLength);
+    double* pend_g = a.pending + (((size_t)j * a.n_channels + c) * a.nfilt + f) * kTail;
+    oc_stage_input(xpad, pend, a.xs + (size_t)c * a.xs_stride + a.xoff[j], m, pend_g, tid);
+    __syncthreads();
+    const int t_first = is_dec ? (m & ~1) : 0;             // the decimator's outputs below m were launch A's
+    const int np = (m + kTail - t_first + 1) / 2;          // pairs covering [t_first, m + 511)
+    double e = 0.0;
+    if (wave < (np + 63) / 64) {
+        const int v0 = wave * 64, v = v0 + lane;
+        const int vl = (v0 + 63 < np ? v0 + 63 : np - 1);
+        int k0, k1;
+        oc_tap_range(t_first + 2 * v0, t_first + 2 * vl, m, k0, k1);
+        const int t = t_first + 2 * (v < np ? v : np - 1);
+        double y[2];
+        oc_fir_pair<true>(xpad, t, h, k0, k1, y[0], y[1]);
+        if (v < np) {
+            const double* w = a.ewt + (is_dec ? 0 : a.ewt_off[band]);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int tt = t + r;
+                const double val = y[r] + pend[tt < kTail ? tt : kTail];
+                if (tt < m) {
+                    if (!is_dec) e = __builtin_fma(w[tt], val * val, e);
+                } else if (tt < m + kTail) pend_g[tt - m] = val;
+            }
+        }
+    }
+    if (is_dec) return;                                    // uniform
+    // the block's energy: lanes, then wavefronts, in a fixed order
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o, 64);
+    if (lane == 0) red[wave] = e;
+    __syncthreads();
+    if (tid == 0) {
+        double E = 0.0;
+        for (int w = 0; w < kOcThreads / 64; ++w) E += red[w];
+        double* sm = a.smooth + (size_t)c * a.nbands + band;
+        const double sp = E + *sm * a.decay_n[band];                 // exp_smoothing.py:52-54
+        *sm = sp;
+        double v = sp;
+        if (a.as_db) v = 10.0 * log10(sp + 1e-30) + (a.weight_db ? a.weight_db[band] : 0.0);
+        const size_t o = (size_t)c * a.nbands + band;
+        if (a.out_f32) ((float*)a.out)[o] = (float)v;
+        else ((double*)a.out)[o] = v;
+    }
+}
+
+int frt_ola_chunk_energies(frt_octbank* h, const void* x, int x_f32, int n, const double* alphas, const double* d_decay_n,
+                           double* d_smooth, const double* d_weight_db, int as_db, void* out, int out_f32) {
+    frt_ola_state* o = h->ola;
+    FRT_REQUIRE(n >= 1 && n <= kOcMaxN, "frt_ola_chunk_energies: n %d not in [1, %d]", n, kOcMaxN);
+    int rc;
+    if (!o->taps.ptr && (rc = upload(o->taps, o->h_taps))) return rc;
+    if ((rc = ola_energy_weights(h, n, n, true, alphas))) return rc;
+    OlaChunkArgs a{};
+    a.x = x;
+    a.x_f32 = x_f32;
+    a.x_stride = n;
+    int total = 0;
+    for (int j = 0, m = n; j < kNOctave; ++j, m = (m + 1) / 2) {
+        a.len[j] = m;
+        a.xoff[j] = total;
+        total += (m + 1) & ~1;
+    }
+    a.xs_stride = total;
+    if ((rc = o->xs.reserve((size_t)h->n_channels * total * sizeof(double)))) return rc;
+    a.xs = o->xs.as<double>();
+    a.taps = o->taps.as<double>();
+    a.pending = o->pending.as<double>();
+    a.nfilt = h->nfilt;
+    a.bpo = h->bpo;
+    a.n_channels = h->n_channels;
+    a.nbands = h->nbands;
+    a.ewt = o->ewt.as<double>();
+    a.ewt_off = o->ewt_off_dev.as<long long>();
+    a.decay_n = d_decay_n;
+    a.smooth = d_smooth;
+    a.weight_db = d_weight_db;
+    a.as_db = as_db;
+    a.out = out;
+    a.out_f32 = out_f32;
+    hipLaunchKernelGGL(ola_chunk_dec_kernel, dim3(h->n_channels), dim3(kOcThreads), 0, h->stream, a);
+    hipLaunchKernelGGL(ola_chunk_band_kernel, dim3(kNOctave * h->bpo + kNOctave - 1, h->n_channels), dim3(kOcThreads), 0, h->stream, a);
+    FRT_HIP_CHECK(hipGetLastError());
     return FRT_OK;
 }

@@ -158,3 +158,68 @@ def test_batched_bank_energies(hip, bpo, block):
             want = np.array(prev)
             # (a band that has not responded yet holds rounding noise of the transform, 1e-30 of the loudest band)
             assert np.all(np.abs(got[c, b] - want) <= 1e-5 * want + 1e-20 * want.max()), (c, b)
+
+
+@pytest.mark.parametrize("bpo", [1, 3, 24])
+def test_chunk_energies_against_oracle_and_transform_path(hip, bpo, monkeypatch):
+    """One chunk = one energy block (the octave-spectrum widget's handler): the two-launch running-convolution path of
+    frt_octbank_energies against the oracle's OlaBank + exp smoothing chunk by chunk (1e-5, the north star's band-energy
+    tolerance; float32 out), for the widget's 512, the extremes 1 and 1024, odd and ragged lengths, two channels; against
+    the transform path (FRT_OLA_NO_CHUNK_KERNELS) to float32 rounding; and interleaved with a batched call: both paths
+    carry the same tails."""
+    from friture_amd.filter import FirBank
+    C = 2
+    sizes = [512, 512, 1, 1024, 333, 7, 512, 2, 640, 1023, 512, 100, 512]
+    total = sum(sizes) + 4096
+    x = np.stack([synth("noise", total, 300 + c) for c in range(C)])
+    alphas, kernels = dsp.band_smoothing_setup(bpo, 0.125)
+    bank, other = FirBank(bpo, C), FirBank(bpo, C)
+    refs = [(dsp.OlaBank(bpo), [0.0] * (9 * bpo)) for _ in range(C)]
+    pos = 0
+
+    def oracle(c, chunk):
+        ref, prev = refs[c]
+        y, _ = ref.filter(chunk.astype(np.float64))
+        prev = dsp.band_energies(y, kernels, alphas, prev)
+        refs[c] = (ref, prev)
+        return np.array(prev)
+
+    for i, n in enumerate(sizes):
+        chunk = x[:, pos:pos + n]
+        pos += n
+        got = bank.energies(chunk, n, alphas)[:, 0]
+        monkeypatch.setenv("FRT_OLA_NO_CHUNK_KERNELS", "1")
+        via_fft = other.energies(chunk, n, alphas)[:, 0]
+        monkeypatch.delenv("FRT_OLA_NO_CHUNK_KERNELS")
+        for c in range(C):
+            want = oracle(c, chunk[c])
+            assert np.all(np.abs(got[c] - want) <= 1e-5 * want + 1e-20 * want.max()), (bpo, i, n, c)
+        assert np.all(np.abs(got - via_fft) <= 3e-7 * np.abs(via_fft) + 1e-25), (bpo, i, n)
+        if i == 6:
+            # a batched call in between (four blocks of 1024): the transform kernels read and leave the same tails
+            blk = x[:, pos:pos + 4096]
+            pos += 4096
+            gb = bank.energies(blk, 1024, alphas)
+            other.energies(blk, 1024, alphas)
+            for c in range(C):
+                for b in range(4):
+                    want = oracle(c, blk[c, b * 1024:(b + 1) * 1024])
+                assert np.all(np.abs(gb[c, 3] - want) <= 1e-5 * want + 1e-20 * want.max()), (bpo, c)
+
+
+def test_chunk_energies_device_pointers_and_db(hip):
+    """The same path on device pointers (a torch CUDA chunk in, a torch CUDA band vector out) with the dB + weighting
+    epilogue: equal to the host-buffer call."""
+    torch = pytest.importorskip("torch")
+    from friture_amd.filter import FirBank
+    bpo, C = 3, 3
+    x = np.stack([synth("noise", 4 * 512, 500 + c) for c in range(C)])
+    alphas, _ = dsp.band_smoothing_setup(bpo, 0.125)
+    w = np.linspace(-3.0, 1.0, 9 * bpo)
+    a, b = FirBank(bpo, C), FirBank(bpo, C)
+    for i in range(4):
+        chunk = np.ascontiguousarray(x[:, i * 512:(i + 1) * 512], np.float32)
+        host = a.energies(chunk, 512, alphas, weight_db=w, as_db=True)
+        dev = b.energies(torch.from_numpy(chunk).cuda(), 512, alphas, weight_db=w, as_db=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(host, dev.cpu().numpy())
