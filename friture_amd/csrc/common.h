@@ -83,6 +83,9 @@ int upload_if_changed(DeviceBuffer& buf, std::vector<T>& cache, const std::vecto
     return FRT_OK;
 }
 
+// calls whose host buffers total at most this are served in place from page-locked memory (kernels read / write it over
+// the bus) instead of by copies around the kernels
+constexpr size_t kZeroCopyMax = 256 * 1024;
 int device_cu_count();
 
 // ---- packed staging of host arrays for the stateless entry points ------------------------------------------------------

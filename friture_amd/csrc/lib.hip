@@ -50,7 +50,6 @@ StageArena& arena() {
     return *a;
 }
 constexpr size_t kStageAlign = 256;
-constexpr size_t kZeroCopyMax = 256 * 1024;
 size_t stage_round(size_t n) { return (n + kStageAlign - 1) / kStageAlign * kStageAlign; }
 }  // namespace
 

@@ -364,12 +364,20 @@ extern "C" int frt_specgram_push(frt_specgram* h, const double* chunk, int n, ui
             h->pin_in_bytes = (size_t)n * sizeof(double) * 2;
         }
         memcpy(h->pin_in, chunk, (size_t)n * sizeof(double));
-        FRT_HIP_CHECK(hipMemcpyAsync(h->chunk.ptr, h->pin_in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(ring_write_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->chunk.as<double>(), n, h->ring.as<double>(),
-                           h->ring_len, h->offset);
+        // a widget-sized chunk is read by the ring write where it lies (page-locked memory is device accessible): one launch
+        // instead of a copy and a launch; long chunks go up by the copy engine first
+        const double* src = (const double*)h->pin_in;
+        if ((size_t)n * sizeof(double) > kZeroCopyMax) {
+            FRT_HIP_CHECK(hipMemcpyAsync(h->chunk.ptr, h->pin_in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            src = h->chunk.as<double>();
+        }
+        hipLaunchKernelGGL(ring_write_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, src, n, h->ring.as<double>(), h->ring_len,
+                           h->offset);
         FRT_HIP_CHECK(hipGetLastError());
-        FRT_HIP_CHECK(hipEventRecord(h->in_done, h->stream));
-        h->in_pending = true;
+        if (realizable <= 0) {                     // a push that completes frames waits for the stream at its end anyway
+            FRT_HIP_CHECK(hipEventRecord(h->in_done, h->stream));
+            h->in_pending = true;
+        }
     }
     h->offset = new_offset;
     h->old_index = new_old_index;
@@ -404,10 +412,22 @@ extern "C" int frt_specgram_push(frt_specgram* h, const double* chunk, int n, ui
         FRT_HIP_CHECK(hipMemcpyAsync(h->src.ptr, h->h_src.data(), (size_t)n_out * sizeof(int), hipMemcpyHostToDevice, h->stream));
         FRT_HIP_CHECK(hipMemcpyAsync(h->a.ptr, h->h_a.data(), (size_t)n_out * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
+    // pixels for a host caller: a block of a few columns is written by the kernel straight into the page-locked block
+    const size_t pix_bytes = (size_t)n_out * h->height * 4;
+    const bool host_out = n_out > 0 && pixels_out && !is_device_pointer(pixels_out);
+    const bool direct_out = host_out && pix_bytes <= kZeroCopyMax;
+    if (host_out && pix_bytes > h->pin_bytes) {
+        FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (h->pin) (void)hipHostFree(h->pin);
+        h->pin = nullptr;
+        h->pin_bytes = 0;
+        FRT_HIP_CHECK(hipHostMalloc(&h->pin, pix_bytes * 2, hipHostMallocDefault));
+        h->pin_bytes = pix_bytes * 2;
+    }
     hipLaunchKernelGGL(screen_columns_kernel, dim3((cols_alloc + 63) / 64, h->height), dim3(64), 0, h->stream, h->norm.as<double>(), h->nb,
                        realizable, h->jidx.as<int>(), h->dx.as<double>(), h->den.as<double>(), h->height, old_in.as<double>(),
                        old_out.as<double>(), inline_cols ? nullptr : h->src.as<int>(), inline_cols ? nullptr : h->a.as<double>(), inl, n_out,
-                       h->lut.as<uint32_t>(), h->pixels.as<uint32_t>(), n_out > 0 ? n_out : 1, 1);
+                       h->lut.as<uint32_t>(), direct_out ? (uint32_t*)h->pin : h->pixels.as<uint32_t>(), n_out > 0 ? n_out : 1, 1);
     FRT_HIP_CHECK(hipGetLastError());
     h->old_is_a = !h->old_is_a;
     if (n_out > 0 && pixels_out) {
@@ -415,14 +435,7 @@ extern "C" int frt_specgram_push(frt_specgram* h, const double* chunk, int n, ui
             FRT_HIP_CHECK(hipMemcpy2DAsync(pixels_out, (size_t)max_cols * 4, h->pixels.ptr, (size_t)n_out * 4, (size_t)n_out * 4, h->height,
                                            hipMemcpyDeviceToDevice, h->stream));
         } else {
-            const size_t bytes = (size_t)n_out * h->height * 4;
-            if (bytes > h->pin_bytes) {
-                if (h->pin) (void)hipHostFree(h->pin);
-                h->pin = nullptr;
-                FRT_HIP_CHECK(hipHostMalloc(&h->pin, bytes * 2, hipHostMallocDefault));
-                h->pin_bytes = bytes * 2;
-            }
-            FRT_HIP_CHECK(hipMemcpyAsync(h->pin, h->pixels.ptr, bytes, hipMemcpyDeviceToHost, h->stream));
+            if (!direct_out) FRT_HIP_CHECK(hipMemcpyAsync(h->pin, h->pixels.ptr, pix_bytes, hipMemcpyDeviceToHost, h->stream));
             FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
             for (int r = 0; r < h->height; ++r)
                 memcpy(pixels_out + (size_t)r * max_cols, (const uint32_t*)h->pin + (size_t)r * n_out, (size_t)n_out * 4);

@@ -1017,7 +1017,7 @@ extern "C" int frt_stft_run(frt_stft* h, int kind, const void* x, int64_t T, int
         h->pin_bytes = 2 * (in_pad + out_bytes);
     }
     if (pinned) memcpy(h->pin, x, in_bytes);
-    if (pinned && in_pad + out_bytes <= 256 * 1024) {
+    if (pinned && in_pad + out_bytes <= kZeroCopyMax) {
         // one frame or a few (audioproc.analyzelive): the kernel reads the pinned block and writes the spectrum into it — no
         // copy engine on either side, one launch and one synchronisation per call
         if ((rc = stft_launch(h, kind, h->pin, x_stride, h->pin + in_pad, F, h->stream))) return rc;
