@@ -21,6 +21,7 @@
 #include "common.h"
 #include "fft_mixed.h"
 #include "fft_core.h"
+#include "fft_static.h"
 
 namespace frt {
 
@@ -38,10 +39,12 @@ struct GccArgs {
     const double* window;  // [L] numpy.hanning(L)
     const double* twm;     // [M] exp(-2 pi i t / M)
     const double* tw2;     // per-pass twiddle tables of the M2-point plan (fft_mixed.h, make_pass_twiddles)
+    const double* tws;     // tables of the compile-time plan (fft_static.h) when M2 = 6000
     const double* twl;     // [M+1] exp(-2 pi i k / L)
     double* scratch;       // [pairs][4 M + 2] complex
     MixedPlan plan;        // for M2
     int L, M, M2, R;
+    int vec;               // d0, d1 and xcorr are 16-byte aligned
 };
 
 template <typename T>
@@ -67,6 +70,127 @@ __device__ double block_max(double v, double* red) {
     return s;
 }
 
+// The sub-transform engine: the compile-time plan 6 x 10 x 10 x 10 (fft_static.h) for the default window's 6000 points,
+// the run-time mixed-radix plan for every other 5-smooth length.
+constexpr int kGccStaticM2 = 6000;
+template <bool ST>
+__device__ __forceinline__ void gcc_fft(cpx<double>* buf, const GccArgs& a, int tid) {
+    if constexpr (ST) static_fft_forward<double, kGccThreads, 6, 10, 10, 10>(buf, (const cpx<double>*)a.tws, tid);
+    else fft_mixed_forward<double, kGccMaxB>(buf, (const cpx<double>*)a.tw2, a.plan, tid, kGccThreads);
+}
+
+// Z_s[kk] = sum_r W_M^{r kk} S[s][r][kk mod M2], kk < M: the last (radix-R, decimation in time) step of the M-point transform
+template <int R>
+__device__ __forceinline__ cpx<double> gcc_zfull(const cpx<double>* S, const cpx<double>* twm, int s, int kk, int M, int M2) {
+    using C = cpx<double>;
+    int kp = kk;
+#pragma unroll
+    for (int q = 1; q < R; ++q) kp = kp >= M2 ? kp - M2 : kp;
+    C acc = S[((size_t)s * R) * M2 + kp];
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+        int idx = r * kk;                            // < R M
+#pragma unroll
+        for (int q = 1; q < r + 1; ++q) idx = idx >= M ? idx - M : idx;
+        acc = acc + cmul(twm[idx], S[((size_t)s * R + r) * M2 + kp]);
+    }
+    return acc;
+}
+
+// D[kk] of the real signal whose even / odd samples rode in Z: A = Z[kk], B = Z[M - kk] (both taken mod M), t = exp(-2 pi i kk / L)
+__device__ __forceinline__ cpx<double> gcc_unpack(cpx<double> A, cpx<double> Bz, cpx<double> t) {
+    using C = cpx<double>;
+    const C B = cconj(Bz);
+    const C Sm = A + B, D = A - B;
+    const C u = cmul(t, D);
+    return {0.5 * (Sm.x + u.y), 0.5 * (Sm.y - u.x)};
+}
+
+// Forward sub-transforms of ONE signal by one workgroup, R <= 2.  The signal is read once: thread t takes the sample pairs
+// p = R (t + 1024 i) + r for every r (R consecutive 16-byte words per slot), keeps them in registers while the block sum
+// gives the mean, turns them into (x - mean) w in place, and feeds sub-transform after sub-transform from registers — no
+// second pass over the window for the mean, no re-read per sub-transform.  Returns the mean.
+constexpr int kGccSlots = (kGccMaxM2 + kGccThreads - 1) / kGccThreads;      // 6
+template <int R, bool ST>
+__device__ __forceinline__ double gcc_forward_signal(const GccArgs& a, const double* sig, cpx<double>* Sdst, cpx<double>* buf,
+                                                    double* red, int tid) {
+    static_assert(R <= 2, "register budget");
+    const int M2 = a.M2;
+    double2 x[kGccSlots][R], w[kGccSlots][R];
+    const double2* wn = (const double2*)a.window;
+#pragma unroll
+    for (int i = 0; i < kGccSlots; ++i) {
+        const int m = tid + i * kGccThreads;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            x[i][r] = w[i][r] = double2{0.0, 0.0};
+            if (m < M2) {
+                const int p = R * m + r;
+                x[i][r] = a.vec ? ((const double2*)sig)[p] : double2{sig[2 * p], sig[2 * p + 1]};
+                w[i][r] = wn[p];
+            }
+        }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < kGccSlots; ++i)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc += x[i][r].x + x[i][r].y;
+    const double mean = block_sum(acc, red) / (double)a.L;
+#pragma unroll
+    for (int i = 0; i < kGccSlots; ++i)
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[i][r] = double2{(x[i][r].x - mean) * w[i][r].x, (x[i][r].y - mean) * w[i][r].y};
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int i = 0; i < kGccSlots; ++i) {
+            const int m = tid + i * kGccThreads;
+            if (m < M2) buf[m] = {x[i][r].x, x[i][r].y};
+        }
+        __syncthreads();
+        gcc_fft<ST>(buf, a, tid);
+        cpx<double>* dst = Sdst + (size_t)r * M2;
+        for (int k = tid; k < M2; k += kGccThreads) dst[k] = buf[k];
+        __syncthreads();
+    }
+    return mean;
+}
+
+// One window pair per workgroup, everything between the two signals and the correlation in this launch.  What passes
+// through the pair's scratch slab is only what cannot stay on the CU: of the 2 R sub-spectra (M2 complex each, one LDS
+// array's worth) all but the last, which the cross spectrum reads where the transform left it.  The cross spectrum itself
+// never leaves the registers: thread t owns the bin pairs (k, M - k), k = t + 1024 i — the real-transform unpack needs
+// exactly that pair of Z, and so does the Hermitian packing in front of the inverse transform — and only the block maximum
+// of |G| (the PHAT weight's regulariser) is exchanged in between.  For R <= 2 the packed inverse input goes from those
+// registers to the inverse sub-transforms through LDS: R = 1 writes it in place; R = 2 needs Zi[k] +- Zi[k + M2], and
+// Zi[k + M2] = Zi[M - (M2 - k)] sits with the owner of the mirrored pair, so the upper halves are exchanged through the
+// LDS array, the r = 0 input is formed in it and the r = 1 input waits in registers.
+// (R = 4, up to 13 bin pairs per thread, computes the cross spectrum twice — once for the maximum, once to pack — and
+// passes the packed input through the slab.)
+template <int R>
+struct GccSub {
+    const cpx<double>* p[2][R];             // sub-spectrum (s, r): the scratch slab, or LDS for the last one
+};
+
+template <int R>
+__device__ __forceinline__ cpx<double> gcc_zfull_at(const GccSub<R>& sub, const cpx<double>* twm, int s, int kk, int M, int M2) {
+    using C = cpx<double>;
+    int kp = kk;
+#pragma unroll
+    for (int q = 1; q < R; ++q) kp = kp >= M2 ? kp - M2 : kp;
+    C acc = sub.p[s][0][kp];
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+        int idx = r * kk;                            // < R M
+#pragma unroll
+        for (int q = 1; q < r + 1; ++q) idx = idx >= M ? idx - M : idx;
+        acc = acc + cmul(twm[idx], sub.p[s][r][kp]);
+    }
+    return acc;
+}
+
+template <int R, bool ST>
 __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) {
     using C = cpx<double>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,84 +200,173 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
 
     const int tid = threadIdx.x;
     const int pair = blockIdx.x;
-    const int L = a.L, M = a.M, M2 = a.M2, R = a.R;
+    const int L = a.L, M = a.M, M2 = a.M2;
     const double* sig[2] = {a.d0 + (size_t)pair * L, a.d1 + (size_t)pair * L};
-    C* S = (C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2);   // [2][M] sub-spectra
-    C* G = S + 2 * (size_t)M;                                    // [M+1] cross spectrum
-    C* Zi = G + (M + 1);                                         // [M] packed inverse input
+    C* S = (C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2);   // [2][R][M2] sub-spectra
+    C* Zi = S + 2 * (size_t)M + (M + 1);                         // [M] packed inverse input (R = 4 only)
     const C* twm = (const C*)a.twm;
     const C* twl = (const C*)a.twl;
 
-    // ---- means -----------------------------------------------------------------------------------
+    // ---- means (both signals in one pass) ---------------------------------------------------------------
     double mean[2];
-    for (int s = 0; s < 2; ++s) {
-        double acc = 0.0;
-        for (int t = tid; t < L; t += kGccThreads) acc += sig[s][t];
-        mean[s] = block_sum(acc, red) / (double)L;
+    {
+        double acc0 = 0.0, acc1 = 0.0;
+        for (int t = tid; t < L; t += kGccThreads) {
+            acc0 += sig[0][t];
+            acc1 += sig[1][t];
+        }
+        mean[0] = block_sum(acc0, red) / (double)L;
+        mean[1] = block_sum(acc1, red) / (double)L;
     }
     if (tid == 0 && a.means) {
         a.means[2 * pair] = mean[0];
         a.means[2 * pair + 1] = mean[1];
     }
 
-    // ---- forward sub-transforms: S[s][r][k'] = FFT_M2( z_s[R m + r] ) -------------------------------
+    // ---- forward sub-transforms: S[s][r][k'] = FFT_M2( z_s[R m + r] ); the last one stays in LDS ---------------
+    GccSub<R> sub;
     for (int s = 0; s < 2; ++s)
         for (int r = 0; r < R; ++r) {
-            for (int m = tid; m < M2; m += kGccThreads) {
-                const int t = 2 * (R * m + r);
-                buf[m] = {(sig[s][t] - mean[s]) * a.window[t], (sig[s][t + 1] - mean[s]) * a.window[t + 1]};
+            const double2* wn = (const double2*)a.window;
+            const double mu = mean[s];
+            if (a.vec) {                                     // 16-byte aligned windows (a ring view need not be)
+                const double2* sg = (const double2*)sig[s];
+                for (int m = tid; m < M2; m += kGccThreads) {
+                    const double2 x = sg[R * m + r], w = wn[R * m + r];
+                    buf[m] = {(x.x - mu) * w.x, (x.y - mu) * w.y};
+                }
+            } else {
+                for (int m = tid; m < M2; m += kGccThreads) {
+                    const int t = 2 * (R * m + r);
+                    const double2 w = wn[R * m + r];
+                    buf[m] = {(sig[s][t] - mu) * w.x, (sig[s][t + 1] - mu) * w.y};
+                }
             }
             __syncthreads();
-            fft_mixed_forward<double, kGccMaxB>(buf, (const C*)a.tw2, a.plan, tid, kGccThreads);
-            for (int k = tid; k < M2; k += kGccThreads) S[((size_t)s * R + r) * M2 + k] = buf[k];
-            __syncthreads();
+            gcc_fft<ST>(buf, a, tid);
+            const bool last = s == 1 && r == R - 1;
+            C* dst = S + ((size_t)s * R + r) * M2;
+            sub.p[s][r] = last ? (const C*)buf : (const C*)dst;
+            if (!last) {
+                for (int k = tid; k < M2; k += kGccThreads) dst[k] = buf[k];
+                __syncthreads();
+            }
         }
     __threadfence_block();
     __syncthreads();
 
-    // Z_s[k] = sum_r W_M^{r k} S[s][r][k mod M2]
-    auto zfull = [&](int s, int k) -> C {
-        const int kp = k % M2;
-        C acc = S[((size_t)s * R) * M2 + kp];
-        for (int r = 1; r < R; ++r) acc = acc + cmul(twm[(int)(((long long)r * k) % M)], S[((size_t)s * R + r) * M2 + kp]);
-        return acc;
+    // ---- cross spectrum of the bin pairs (k, M - k) and its maximum magnitude -----------------------------------
+    constexpr bool KEEP = R <= 2;                        // M <= 12288: at most 7 pairs per thread stay in registers
+    constexpr int NP = KEEP ? (2 * kGccMaxM2 / 2 + 1 + kGccThreads - 1) / kGccThreads : 1;
+    C g_lo[NP], g_hi[NP];
+    auto cross = [&](int k, C& glo, C& ghi) {
+        const int km = k == 0 ? 0 : M - k;                  // Z index of the partner bin
+        const C tk = twl[k], tm = twl[M - k];
+        C d_lo[2], d_hi[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const C Za = gcc_zfull_at<R>(sub, twm, s, k, M, M2), Zb = gcc_zfull_at<R>(sub, twm, s, km, M, M2);
+            d_lo[s] = gcc_unpack(Za, Zb, tk);               // D_s[k]
+            d_hi[s] = gcc_unpack(Zb, Za, tm);               // D_s[M - k]
+        }
+        glo = cmul(cconj(d_lo[0]), d_lo[1]);
+        ghi = cmul(cconj(d_hi[0]), d_hi[1]);
     };
-    auto unpack = [&](int s, int k) -> C {          // D_s[k], k = 0..M
-        const C A = zfull(s, k == M ? 0 : k);
-        const C B = cconj(zfull(s, k == 0 ? 0 : M - k));
-        const C Sm = A + B, D = A - B;
-        const C t = cmul(twl[k], D);
-        return {0.5 * (Sm.x + t.y), 0.5 * (Sm.y - t.x)};
-    };
-
-    // ---- cross spectrum and its maximum magnitude ------------------------------------------------------
     double gmax = 0.0;
-    for (int k = tid; k <= M; k += kGccThreads) {
-        const C g = cmul(cconj(unpack(0, k)), unpack(1, k));
-        G[k] = g;
-        gmax = fmax(gmax, sqrt(g.x * g.x + g.y * g.y));
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int k = tid + i * kGccThreads;
+            g_lo[i] = g_hi[i] = {0.0, 0.0};
+            if (2 * k <= M) cross(k, g_lo[i], g_hi[i]);
+            gmax = fmax(gmax, fmax(sqrt(g_lo[i].x * g_lo[i].x + g_lo[i].y * g_lo[i].y), sqrt(g_hi[i].x * g_hi[i].x + g_hi[i].y * g_hi[i].y)));
+            asm volatile("" ::: "memory");                   // one pair's loads in flight at a time (register budget)
+        }
+    } else {
+        for (int k = tid; 2 * k <= M; k += kGccThreads) {
+            C glo, ghi;
+            cross(k, glo, ghi);
+            gmax = fmax(gmax, fmax(sqrt(glo.x * glo.x + glo.y * glo.y), sqrt(ghi.x * ghi.x + ghi.y * ghi.y)));
+        }
     }
-    gmax = block_max(gmax, red);
-    __threadfence_block();
-    __syncthreads();
+    gmax = block_max(gmax, red);                             // (its barriers: every read of the LDS sub-spectrum is done)
 
     // ---- PHAT weighting and packing for the inverse real transform ---------------------------------------
-    auto weighted = [&](int k) -> C {
-        C g = G[k];
-        const double w = 1.0 / (1e-10 * gmax + sqrt(g.x * g.x + g.y * g.y));
-        g = {g.x * w, g.y * w};
-        if (k == 0 || k == M) g.y = 0.0;            // irfft ignores the imaginary part of the edge bins
-        return g;
+    // (zk, zm) = Zi[k], Zi[M - k] from the pair's cross-spectrum values
+    auto pack = [&](int k, C A, C B, C& zk, C& zm) {
+        const double wa = 1.0 / (1e-10 * gmax + sqrt(A.x * A.x + A.y * A.y));
+        const double wb = 1.0 / (1e-10 * gmax + sqrt(B.x * B.x + B.y * B.y));
+        A = {A.x * wa, A.y * wa};
+        B = {B.x * wb, B.y * wb};
+        if (k == 0) A.y = B.y = 0.0;                        // irfft ignores the imaginary part of the edge bins 0 and M
+        const C tk = cconj(twl[k]), tm = cconj(twl[M - k]);
+        {
+            const C Bc = cconj(B), Sm = A + Bc, D = A - Bc, u = cmul(tk, D);
+            zk = {0.5 * (Sm.x - u.y), 0.5 * (Sm.y + u.x)};
+        }
+        {
+            const C Ac = cconj(A), Sm = B + Ac, D = B - Ac, u = cmul(tm, D);
+            zm = {0.5 * (Sm.x - u.y), 0.5 * (Sm.y + u.x)};
+        }
     };
-    for (int k = tid; k < M; k += kGccThreads) {
-        const C A = weighted(k);
-        const C B = cconj(weighted(M - k));
-        const C Sm = A + B, D = A - B;
-        const C t = cmul(cconj(twl[k]), D);
-        Zi[k] = {0.5 * (Sm.x - t.y), 0.5 * (Sm.y + t.x)};
+    C x1[KEEP && R == 2 ? NP : 1];                            // R = 2: the r = 1 input of the thread's slots, conjugated
+    if constexpr (R == 1) {
+        // the one inverse transform's input, conj(Zi[k]), straight into the LDS array
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int k = tid + i * kGccThreads;
+            if (2 * k <= M) {
+                C zk, zm;
+                pack(k, g_lo[i], g_hi[i], zk, zm);
+                buf[k] = cconj(zk);
+                if (k > 0) buf[M - k] = cconj(zm);
+            }
+        }
+        __syncthreads();
+    } else if constexpr (R == 2) {
+        // Zi[k] (k < M2) stays with its owner, Zi[M - k] = upper half element M2 - k goes through LDS to the owner of that slot
+        C zlo[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int k = tid + i * kGccThreads;
+            zlo[i] = {0.0, 0.0};
+            if (2 * k <= M) {
+                C zk, zm;
+                pack(k, g_lo[i], g_hi[i], zk, zm);
+                if (k < M2) zlo[i] = zk;
+                if (k > 0) buf[M2 - k] = zm;                 // k = M2: zm = zk = Zi[M2], upper element 0
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int k = tid + i * kGccThreads;
+            x1[i] = {0.0, 0.0};
+            if (k < M2) {
+                const C hi = buf[k];                         // Zi[k + M2]
+                const C s0 = zlo[i] + hi, s1 = cmul(cconj(twm[k]), zlo[i] - hi);
+                zlo[i] = cconj(s0);
+                x1[i] = cconj(s1);
+            }
+        }
+        __syncthreads();                                     // every upper-half element has been read
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int k = tid + i * kGccThreads;
+            if (k < M2) buf[k] = zlo[i];
+        }
+        __syncthreads();
+    } else {
+        for (int k = tid; 2 * k <= M; k += kGccThreads) {
+            C glo, ghi, zk, zm;
+            cross(k, glo, ghi);
+            pack(k, glo, ghi, zk, zm);
+            Zi[k] = zk;
+            if (k > 0) Zi[M - k] = zm;
+        }
+        __threadfence_block();
+        __syncthreads();
     }
-    __threadfence_block();
-    __syncthreads();
 
     // ---- inverse sub-transforms: z[R m + r] = (1/M) IFFT_M2( W_M^{-r k'} sum_q W_R^{-r q} Zi[k' + q M2] ) ---
     double* out = a.xcorr + (size_t)pair * L;
@@ -161,23 +374,39 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
     double best = -1.0;
     int besti = 0;
     for (int r = 0; r < R; ++r) {
-        for (int k = tid; k < M2; k += kGccThreads) {
-            C acc = Zi[k];
-            for (int q = 1; q < R; ++q) {
-                // W_R^{-r q} = conj(W_M^{(r q mod R) M2})
-                const C wq = cconj(twm[(int)(((long long)((r * q) % R) * M2) % M)]);
-                acc = acc + cmul(wq, Zi[k + q * M2]);
+        if constexpr (R == 2) {
+            if (r == 1) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const int k = tid + i * kGccThreads;
+                    if (k < M2) buf[k] = x1[i];
+                }
+                __syncthreads();
             }
-            acc = cmul(cconj(twm[(int)(((long long)r * k) % M)]), acc);
-            buf[k] = cconj(acc);                   // conj trick: ifft(u) = conj(fft(conj u)) / n
+        } else if constexpr (R > 2) {
+            for (int k = tid; k < M2; k += kGccThreads) {
+                C acc = Zi[k];
+#pragma unroll
+                for (int q = 1; q < R; ++q) {
+                    // W_R^{-r q} = conj(W_M^{(r q mod R) M2})
+                    const C wq = cconj(twm[((r * q) % R) * M2]);
+                    acc = acc + cmul(wq, Zi[k + q * M2]);
+                }
+                acc = cmul(cconj(twm[r * k]), acc);                  // r k < M
+                buf[k] = cconj(acc);                   // conj trick: ifft(u) = conj(fft(conj u)) / n
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        fft_mixed_forward<double, kGccMaxB>(buf, (const C*)a.tw2, a.plan, tid, kGccThreads);
+        gcc_fft<ST>(buf, a, tid);
         for (int m = tid; m < M2; m += kGccThreads) {
             const int t = 2 * (R * m + r);
             const double re = buf[m].x * inv, im = -buf[m].y * inv;
-            out[t] = re;
-            out[t + 1] = im;
+            if (a.vec) {
+                *(double2*)(out + t) = double2{re, im};
+            } else {
+                out[t] = re;
+                out[t + 1] = im;
+            }
             if (fabs(re) > best || (fabs(re) == best && t < besti)) { best = fabs(re); besti = t; }
             if (fabs(im) > best || (fabs(im) == best && t + 1 < besti)) { best = fabs(im); besti = t + 1; }
         }
@@ -251,59 +480,69 @@ __global__ void __launch_bounds__(kGccThreads) gcc_readout_kernel(const double* 
 // occupies 100 of the 256 CUs.  For batches that do not fill the chip the work of a pair is dealt to more workgroups —
 // 2 R forward sub-transforms, the cross spectrum in slices, R inverse sub-transforms — at the price of four kernel
 // boundaries; every phase reads what the previous one left in the pair's scratch slab (same layout as above).
+template <int R, bool ST>
 __global__ void __launch_bounds__(kGccThreads) gcc_fwd_kernel(const GccArgs a, unsigned long long* __restrict__ gmax) {
     using C = cpx<double>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     C* buf = (C*)smem;
     double* red = (double*)(buf + a.M2);
     const int tid = threadIdx.x, pair = blockIdx.y;
-    const int s = blockIdx.x / a.R, r = blockIdx.x - s * a.R;
-    const int L = a.L, M = a.M, M2 = a.M2, R = a.R;
-    const double* sig = (s ? a.d1 : a.d0) + (size_t)pair * L;
+    const int L = a.L, M = a.M, M2 = a.M2;
     C* S = (C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2);
-    double acc = 0.0;
-    for (int t = tid; t < L; t += kGccThreads) acc += sig[t];
-    const double mean = block_sum(acc, red) / (double)L;
-    if (tid == 0 && r == 0) {
-        if (a.means) a.means[2 * pair + s] = mean;
-        if (s == 0) gmax[pair] = 0ull;
+    if constexpr (R <= 2) {
+        // one workgroup per signal: the signal is read once and feeds all its sub-transforms from registers
+        const int s = blockIdx.x;
+        const double* sig = (s ? a.d1 : a.d0) + (size_t)pair * L;
+        const double mean = gcc_forward_signal<R, ST>(a, sig, S + (size_t)s * R * M2, buf, red, tid);
+        if (tid == 0) {
+            if (a.means) a.means[2 * pair + s] = mean;
+            if (s == 0) gmax[pair] = 0ull;
+        }
+    } else {
+        const int s = blockIdx.x / R, r = blockIdx.x - s * R;
+        const double* sig = (s ? a.d1 : a.d0) + (size_t)pair * L;
+        double acc = 0.0;
+        for (int t = tid; t < L; t += kGccThreads) acc += sig[t];
+        const double mean = block_sum(acc, red) / (double)L;
+        if (tid == 0 && r == 0) {
+            if (a.means) a.means[2 * pair + s] = mean;
+            if (s == 0) gmax[pair] = 0ull;
+        }
+        for (int m = tid; m < M2; m += kGccThreads) {
+            const int t = 2 * (R * m + r);
+            buf[m] = {(sig[t] - mean) * a.window[t], (sig[t + 1] - mean) * a.window[t + 1]};
+        }
+        __syncthreads();
+        gcc_fft<ST>(buf, a, tid);
+        for (int k = tid; k < M2; k += kGccThreads) S[((size_t)s * R + r) * M2 + k] = buf[k];
     }
-    for (int m = tid; m < M2; m += kGccThreads) {
-        const int t = 2 * (R * m + r);
-        buf[m] = {(sig[t] - mean) * a.window[t], (sig[t + 1] - mean) * a.window[t + 1]};
-    }
-    __syncthreads();
-    fft_mixed_forward<double, kGccMaxB>(buf, (const C*)a.tw2, a.plan, tid, kGccThreads);
-    for (int k = tid; k < M2; k += kGccThreads) S[((size_t)s * R + r) * M2 + k] = buf[k];
 }
 
+template <int R>
 __global__ void __launch_bounds__(256) gcc_cross_kernel(const GccArgs a, unsigned long long* __restrict__ gmax) {
     using C = cpx<double>;
     __shared__ double red[4];
     const int pair = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
-    const int M = a.M, M2 = a.M2, R = a.R;
+    const int M = a.M, M2 = a.M2;
     const C* S = (const C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2);
     C* G = (C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2) + 2 * (size_t)M;
     const C* twm = (const C*)a.twm;
     const C* twl = (const C*)a.twl;
-    auto zfull = [&](int sg, int kk) -> C {
-        const int kp = kk % M2;
-        C acc = S[((size_t)sg * R) * M2 + kp];
-        for (int r = 1; r < R; ++r) acc = acc + cmul(twm[(int)(((long long)r * kk) % M)], S[((size_t)sg * R + r) * M2 + kp]);
-        return acc;
-    };
-    auto unpack = [&](int sg, int kk) -> C {
-        const C A = zfull(sg, kk == M ? 0 : kk);
-        const C B = cconj(zfull(sg, kk == 0 ? 0 : M - kk));
-        const C Sm = A + B, D = A - B;
-        const C t = cmul(twl[kk], D);
-        return {0.5 * (Sm.x + t.y), 0.5 * (Sm.y - t.x)};
-    };
     double mag = 0.0;
-    if (k <= M) {
-        const C g = cmul(cconj(unpack(0, k)), unpack(1, k));
-        G[k] = g;
-        mag = sqrt(g.x * g.x + g.y * g.y);
+    if (2 * k <= M) {                                    // the bin pair (k, M - k): both need Z[k] and Z[M - k]
+        const int km = k == 0 ? 0 : M - k;
+        const C tk = twl[k], tm = twl[M - k];
+        C d_lo[2], d_hi[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const C Za = gcc_zfull<R>(S, twm, s, k, M, M2), Zb = gcc_zfull<R>(S, twm, s, km, M, M2);
+            d_lo[s] = gcc_unpack(Za, Zb, tk);
+            d_hi[s] = gcc_unpack(Zb, Za, tm);
+        }
+        const C glo = cmul(cconj(d_lo[0]), d_lo[1]), ghi = cmul(cconj(d_hi[0]), d_hi[1]);
+        G[k] = glo;
+        G[M - k] = ghi;
+        mag = fmax(sqrt(glo.x * glo.x + glo.y * glo.y), sqrt(ghi.x * ghi.x + ghi.y * ghi.y));
     }
     for (int o = 32; o > 0; o >>= 1) mag = fmax(mag, __shfl_down(mag, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mag;
@@ -312,33 +551,44 @@ __global__ void __launch_bounds__(256) gcc_cross_kernel(const GccArgs a, unsigne
         atomicMax(gmax + pair, (unsigned long long)__double_as_longlong(fmax(fmax(red[0], red[1]), fmax(red[2], red[3]))));
 }
 
+// PHAT weighting + Hermitian packing for the inverse real transform, one thread per bin pair (k, M - k): two weights, two
+// packed values (each weight serves both).
 __global__ void __launch_bounds__(256) gcc_pack_kernel(const GccArgs a, const unsigned long long* __restrict__ gmax) {
     using C = cpx<double>;
     const int pair = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
     const int M = a.M;
-    if (k >= M) return;
+    if (2 * k > M) return;
     const C* G = (const C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2) + 2 * (size_t)M;
     C* Zi = (C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2) + 2 * (size_t)M + (M + 1);
     const C* twl = (const C*)a.twl;
     const double gm = __longlong_as_double((long long)gmax[pair]);
-    auto weighted = [&](int kk) -> C {
-        C g = G[kk];
-        const double w = 1.0 / (1e-10 * gm + sqrt(g.x * g.x + g.y * g.y));
-        g = {g.x * w, g.y * w};
-        if (kk == 0 || kk == M) g.y = 0.0;
-        return g;
-    };
-    const C A = weighted(k);
-    const C B = cconj(weighted(M - k));
-    const C Sm = A + B, D = A - B;
-    const C t = cmul(cconj(twl[k]), D);
-    Zi[k] = {0.5 * (Sm.x - t.y), 0.5 * (Sm.y + t.x)};
+    C A = G[k], B = G[M - k];
+    const double wa = 1.0 / (1e-10 * gm + sqrt(A.x * A.x + A.y * A.y));
+    const double wb = 1.0 / (1e-10 * gm + sqrt(B.x * B.x + B.y * B.y));
+    A = {A.x * wa, A.y * wa};
+    B = {B.x * wb, B.y * wb};
+    if (k == 0) A.y = B.y = 0.0;                        // irfft ignores the imaginary part of the edge bins 0 and M
+    const C tk = cconj(twl[k]), tm = cconj(twl[M - k]);
+    {
+        const C Bc = cconj(B), Sm = A + Bc, D = A - Bc, u = cmul(tk, D);
+        Zi[k] = {0.5 * (Sm.x - u.y), 0.5 * (Sm.y + u.x)};
+    }
+    if (k > 0) {
+        const C Ac = cconj(A), Sm = B + Ac, D = B - Ac, u = cmul(tm, D);
+        Zi[M - k] = {0.5 * (Sm.x - u.y), 0.5 * (Sm.y + u.x)};
+    }
 }
 
-__global__ void __launch_bounds__(kGccThreads) gcc_inv_kernel(const GccArgs a) {
+// Inverse sub-transform r of a pair; the workgroup leaves the (|value|, first index) of its slice's extremum for
+// gcc_argmax_combine_kernel.  (Folding the R slices in the pair's last workgroup to finish was measured: the device-scope
+// fences that hand-over needs on a multi-XCD part cost 10 us per launch, twice the tiny launch below.)
+template <bool ST>
+__global__ void __launch_bounds__(kGccThreads) gcc_inv_kernel(const GccArgs a, double* __restrict__ part_val, int* __restrict__ part_idx) {
     using C = cpx<double>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     C* buf = (C*)smem;
+    double* red = (double*)(buf + a.M2);
+    int* redi = (int*)(red + 16);
     const int tid = threadIdx.x, pair = blockIdx.y, r = blockIdx.x;
     const int L = a.L, M = a.M, M2 = a.M2, R = a.R;
     const C* Zi = (const C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2) + 2 * (size_t)M + (M + 1);
@@ -346,21 +596,59 @@ __global__ void __launch_bounds__(kGccThreads) gcc_inv_kernel(const GccArgs a) {
     for (int k = tid; k < M2; k += kGccThreads) {
         C acc = Zi[k];
         for (int q = 1; q < R; ++q) {
-            const C wq = cconj(twm[(int)(((long long)((r * q) % R) * M2) % M)]);
+            const C wq = cconj(twm[((r * q) % R) * M2]);
             acc = acc + cmul(wq, Zi[k + q * M2]);
         }
-        acc = cmul(cconj(twm[(int)(((long long)r * k) % M)]), acc);
+        acc = cmul(cconj(twm[r * k]), acc);                  // r k < M
         buf[k] = cconj(acc);
     }
     __syncthreads();
-    fft_mixed_forward<double, kGccMaxB>(buf, (const C*)a.tw2, a.plan, tid, kGccThreads);
+    gcc_fft<ST>(buf, a, tid);
     double* out = a.xcorr + (size_t)pair * L;
     const double inv = 1.0 / (double)M;
+    double best = -1.0;
+    int besti = 0;
     for (int m = tid; m < M2; m += kGccThreads) {
         const int t = 2 * (R * m + r);
-        out[t] = buf[m].x * inv;
-        out[t + 1] = -buf[m].y * inv;
+        const double re = buf[m].x * inv, im = -buf[m].y * inv;
+        if (a.vec) {
+            *(double2*)(out + t) = double2{re, im};
+        } else {
+            out[t] = re;
+            out[t + 1] = im;
+        }
+        if (fabs(re) > best || (fabs(re) == best && t < besti)) { best = fabs(re); besti = t; }
+        if (fabs(im) > best || (fabs(im) == best && t + 1 < besti)) { best = fabs(im); besti = t + 1; }
     }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_down(best, o, 64);
+        const int oi = __shfl_down(besti, o, 64);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = best; redi[tid >> 6] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kGccThreads / 64; ++w)
+            if (red[w] > best || (red[w] == best && redi[w] < besti)) { best = red[w]; besti = redi[w]; }
+        part_val[(size_t)pair * R + r] = best;
+        part_idx[(size_t)pair * R + r] = besti;
+    }
+}
+
+
+// argmax |xcorr| of a pair from its R slices' extrema (first index on ties, as numpy.argmax)
+__global__ void __launch_bounds__(256) gcc_argmax_combine_kernel(const double* __restrict__ part_val, const int* __restrict__ part_idx, int R,
+                                                                 int n_pairs, int* __restrict__ argmax) {
+    const int pair = blockIdx.x * 256 + threadIdx.x;
+    if (pair >= n_pairs) return;
+    double best = part_val[(size_t)pair * R];
+    int besti = part_idx[(size_t)pair * R];
+    for (int r = 1; r < R; ++r) {
+        const double v = part_val[(size_t)pair * R + r];
+        const int i = part_idx[(size_t)pair * R + r];
+        if (v > best || (v == best && i < besti)) { best = v; besti = i; }
+    }
+    argmax[pair] = besti;
 }
 
 
@@ -672,20 +960,21 @@ struct frt_gcc {
     int L = 0, M = 0, M2 = 0, R = 1, n_pairs = 0;
     MixedPlan plan{};
     hipStream_t stream = nullptr;
-    DeviceBuffer window, twm, tw2, twl, scratch;
+    DeviceBuffer window, twm, tw2, tws, twl, scratch;
+    bool static_plan = false;            // M2 = 6000: the compile-time plan of fft_static.h
     DeviceBuffer in0, in1, out, argmax, means, old, sm, stats;
     size_t lds_bytes = 0;
     // any-length path (chirp-z): lengths the one-workgroup kernel does not take
     bool any = false;
     int log2r = 0, log2c = 0;
-    DeviceBuffer chirp, bhat, work, spec, twr, twc, gmax;
+    DeviceBuffer chirp, bhat, work, spec, twr, twc, gmax, part_val, part_idx;
 };
 
 extern "C" void frt_gcc_destroy(frt_gcc* h) {
     if (!h) return;
-    DeviceBuffer* bufs[] = {&h->window, &h->twm, &h->tw2, &h->twl, &h->scratch, &h->in0, &h->in1,
+    DeviceBuffer* bufs[] = {&h->window, &h->twm, &h->tw2, &h->tws, &h->twl, &h->scratch, &h->in0, &h->in1,
                             &h->out, &h->argmax, &h->means, &h->old, &h->sm, &h->stats,
-                            &h->chirp, &h->bhat, &h->work, &h->spec, &h->twr, &h->twc, &h->gmax};
+                            &h->chirp, &h->bhat, &h->work, &h->spec, &h->twr, &h->twc, &h->gmax, &h->part_val, &h->part_idx};
     for (auto* b : bufs) b->release();
     delete h;
 }
@@ -757,13 +1046,21 @@ extern "C" int frt_gcc_create(frt_gcc** out, int length, int n_pairs) {
         return rc;
     }
     h->lds_bytes = (size_t)h->M2 * 16 + 16 * sizeof(double) + 16 * sizeof(int);
-    if (hipFuncSetAttribute((const void*)gcc_phat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gcc_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gcc_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
-        set_last_error("frt_gcc_create: cannot reserve %zu bytes of LDS", h->lds_bytes);
+    h->static_plan = h->M2 == kGccStaticM2 && getenv("FRT_GCC_NO_STATIC_PLAN") == nullptr;
+    if (h->static_plan && (rc = upload(h->tws, make_static_twiddles<double>({6, 10, 10, 10})))) {
         frt_gcc_destroy(h);
-        return FRT_ERR_HIP;
+        return rc;
     }
+    const void* big[] = {(const void*)gcc_phat_kernel<1, false>, (const void*)gcc_phat_kernel<2, false>, (const void*)gcc_phat_kernel<4, false>,
+                         (const void*)gcc_phat_kernel<2, true>,  (const void*)gcc_fwd_kernel<1, false>,  (const void*)gcc_fwd_kernel<2, false>,
+                         (const void*)gcc_fwd_kernel<4, false>,  (const void*)gcc_fwd_kernel<2, true>,   (const void*)gcc_inv_kernel<false>,
+                         (const void*)gcc_inv_kernel<true>};
+    for (const void* f : big)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
+            set_last_error("frt_gcc_create: cannot reserve %zu bytes of LDS", h->lds_bytes);
+            frt_gcc_destroy(h);
+            return FRT_ERR_HIP;
+        }
     *out = h;
     return FRT_OK;
 }
@@ -839,17 +1136,37 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
     a.M = h->M;
     a.M2 = h->M2;
     a.R = h->R;
-    if ((long long)h->n_pairs * 2 <= device_cu_count() && !getenv("FRT_GCC_ONE_WORKGROUP")) {
-        // a batch that leaves more than half of the CUs idle: the pair's sub-transforms as workgroups of their own
+    a.tws = h->tws.as<double>();
+    a.vec = ((uintptr_t)a.d0 % 16 == 0) && ((uintptr_t)a.d1 % 16 == 0) && ((uintptr_t)a.xcorr % 16 == 0);
+    const bool st = h->static_plan;
+    const char* force = getenv("FRT_GCC_ONE_WORKGROUP");
+    const bool split = force ? force[0] == '0' : (long long)h->n_pairs * 8 <= 5ll * device_cu_count();
+    if (split) {
+        // up to 5/8 of a workgroup per CU (160 pairs on 256 CUs; measured crossover between 100 and 256): a pair as launches of its own phases
         if ((rc = h->gmax.reserve((size_t)h->n_pairs * 8))) return rc;
         unsigned long long* gm = h->gmax.as<unsigned long long>();
-        hipLaunchKernelGGL(gcc_fwd_kernel, dim3(2 * h->R, h->n_pairs), dim3(kGccThreads), h->lds_bytes, h->stream, a, gm);
-        hipLaunchKernelGGL(gcc_cross_kernel, dim3((h->M + 1 + 255) / 256, h->n_pairs), dim3(256), 0, h->stream, a, gm);
-        hipLaunchKernelGGL(gcc_pack_kernel, dim3((h->M + 255) / 256, h->n_pairs), dim3(256), 0, h->stream, a, gm);
-        hipLaunchKernelGGL(gcc_inv_kernel, dim3(h->R, h->n_pairs), dim3(kGccThreads), h->lds_bytes, h->stream, a);
-        hipLaunchKernelGGL(any_argmax_kernel, dim3(h->n_pairs), dim3(kGccThreads), 0, h->stream, a.xcorr, h->L, h->argmax.as<int>());
+        if ((rc = h->part_val.reserve((size_t)h->n_pairs * h->R * sizeof(double))) || (rc = h->part_idx.reserve((size_t)h->n_pairs * h->R * sizeof(int))))
+            return rc;
+        const dim3 fgrid(h->R <= 2 ? 2 : 2 * h->R, h->n_pairs), igrid(h->R, h->n_pairs), cgrid((h->M / 2 + 1 + 255) / 256, h->n_pairs);
+        const dim3 block(kGccThreads);
+        if (st) hipLaunchKernelGGL((gcc_fwd_kernel<2, true>), fgrid, block, h->lds_bytes, h->stream, a, gm);
+        else if (h->R == 1) hipLaunchKernelGGL((gcc_fwd_kernel<1, false>), fgrid, block, h->lds_bytes, h->stream, a, gm);
+        else if (h->R == 2) hipLaunchKernelGGL((gcc_fwd_kernel<2, false>), fgrid, block, h->lds_bytes, h->stream, a, gm);
+        else hipLaunchKernelGGL((gcc_fwd_kernel<4, false>), fgrid, block, h->lds_bytes, h->stream, a, gm);
+        if (h->R == 1) hipLaunchKernelGGL(gcc_cross_kernel<1>, cgrid, dim3(256), 0, h->stream, a, gm);
+        else if (h->R == 2) hipLaunchKernelGGL(gcc_cross_kernel<2>, cgrid, dim3(256), 0, h->stream, a, gm);
+        else hipLaunchKernelGGL(gcc_cross_kernel<4>, cgrid, dim3(256), 0, h->stream, a, gm);
+        hipLaunchKernelGGL(gcc_pack_kernel, cgrid, dim3(256), 0, h->stream, a, gm);
+        if (st) hipLaunchKernelGGL(gcc_inv_kernel<true>, igrid, block, h->lds_bytes, h->stream, a, h->part_val.as<double>(), h->part_idx.as<int>());
+        else hipLaunchKernelGGL(gcc_inv_kernel<false>, igrid, block, h->lds_bytes, h->stream, a, h->part_val.as<double>(), h->part_idx.as<int>());
+        hipLaunchKernelGGL(gcc_argmax_combine_kernel, dim3((h->n_pairs + 255) / 256), dim3(256), 0, h->stream, h->part_val.as<double>(),
+                           h->part_idx.as<int>(), h->R, h->n_pairs, h->argmax.as<int>());
     } else {
-        hipLaunchKernelGGL(gcc_phat_kernel, dim3(h->n_pairs), dim3(kGccThreads), h->lds_bytes, h->stream, a);
+        const dim3 grid(h->n_pairs), block(kGccThreads);
+        if (st) hipLaunchKernelGGL((gcc_phat_kernel<2, true>), grid, block, h->lds_bytes, h->stream, a);
+        else if (h->R == 1) hipLaunchKernelGGL((gcc_phat_kernel<1, false>), grid, block, h->lds_bytes, h->stream, a);
+        else if (h->R == 2) hipLaunchKernelGGL((gcc_phat_kernel<2, false>), grid, block, h->lds_bytes, h->stream, a);
+        else hipLaunchKernelGGL((gcc_phat_kernel<4, false>), grid, block, h->lds_bytes, h->stream, a);
     }
     FRT_HIP_CHECK(hipGetLastError());
     }
