@@ -36,16 +36,33 @@ void set_last_error(const char* fmt, ...);
 // true when `p` points to device (or managed) memory usable by kernels directly.
 bool is_device_pointer(const void* p);
 
+// Allocations a growing DeviceBuffer has replaced.  Freeing synchronises the device (hipFree does, and kernels enqueued
+// on a caller's non-blocking stream may still use the old block), which is neither legal while a stream of this thread
+// is capturing nor wanted then: inside a capture region (CaptureScope) the old block is parked here and freed by the next
+// growth outside of one, or when a handle is destroyed.
+void retire_allocation(void* p);
+void free_retired_allocations();
+struct CaptureScope {                       // marks the calling thread as capturing a stream for its lifetime
+    CaptureScope();
+    ~CaptureScope();
+    static bool active();
+};
+
 // A grow-only device buffer used for staging host-pointer calls and for plan-owned scratch.
 struct DeviceBuffer {
     void* ptr = nullptr;
     size_t bytes = 0;
     int reserve(size_t n) {
         if (n <= bytes) return FRT_OK;
-        // growing: kernels enqueued on a caller's (non-blocking) stream may still use the old allocation
         if (ptr) {
-            (void)hipDeviceSynchronize();
-            (void)hipFree(ptr);
+            if (CaptureScope::active()) {
+                retire_allocation(ptr);
+            } else {
+                // growing: kernels enqueued on a caller's (non-blocking) stream may still use the old allocation
+                (void)hipDeviceSynchronize();
+                (void)hipFree(ptr);
+                free_retired_allocations();
+            }
         }
         ptr = nullptr;
         bytes = 0;

@@ -1581,8 +1581,12 @@ static int filter_host(frt_octbank* h, const double* x, int n, double* y_packed,
     } else {
         hipGraph_t graph = nullptr;
         FRT_HIP_CHECK(hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal));
-        rc = enqueue_filter(h, n, plen, h->gstream);
-        hipError_t e = hipStreamEndCapture(h->gstream, &graph);
+        hipError_t e;
+        {
+            CaptureScope capturing;              // a buffer that grows in here parks its old block instead of freeing it
+            rc = enqueue_filter(h, n, plen, h->gstream);
+            e = hipStreamEndCapture(h->gstream, &graph);
+        }
         if (rc) {
             if (graph) (void)hipGraphDestroy(graph);
             return rc;

@@ -1,5 +1,6 @@
 // lib.hip — library-level entry points of libfriture_hip.so (init, errors, pointer queries).
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -14,6 +15,30 @@ void set_last_error(const char* fmt, ...) {
     vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
     va_end(ap);
 }
+
+namespace {
+std::mutex g_retired_mutex;
+std::vector<void*> g_retired;
+thread_local int g_capture_depth = 0;
+}  // namespace
+
+void retire_allocation(void* p) {
+    std::lock_guard<std::mutex> lock(g_retired_mutex);
+    g_retired.push_back(p);
+}
+
+void free_retired_allocations() {
+    std::vector<void*> mine;
+    {
+        std::lock_guard<std::mutex> lock(g_retired_mutex);
+        mine.swap(g_retired);
+    }
+    for (void* p : mine) (void)hipFree(p);
+}
+
+CaptureScope::CaptureScope() { ++g_capture_depth; }
+CaptureScope::~CaptureScope() { --g_capture_depth; }
+bool CaptureScope::active() { return g_capture_depth > 0; }
 
 bool is_device_pointer(const void* p) {
     if (!p) return false;
