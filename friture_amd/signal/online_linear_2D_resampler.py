@@ -8,6 +8,8 @@ to one launch of time_resample_kernel (frt_time_resample); a height change Fouri
 device (frt_fourier_resample)."""
 from __future__ import annotations
 
+import math
+
 import numpy as np
 
 from .. import _lib
@@ -47,20 +49,27 @@ class Online_Linear_2D_resampler:
 
     def advance(self, n_cols):
         """The scalar index bookkeeping of a push of n_cols columns, as in the reference (online_linear_2D_resampler.py:61-97):
-        returns (columns the reference allocates, source column per emitted pixel column, its weight)."""
-        total = self.processable(n_cols)
+        returns (columns the reference allocates, source column per emitted pixel column, its weight).  Same float64
+        operations in the same order as the reference's numpy expressions (resampled_index + ratio * k, k = 1..n), on
+        Python floats: a chunk advances by one or two columns, where array temporaries cost more than the arithmetic."""
+        ceil = math.ceil
+        ratio = self.resampling_ratio
+        total = int(ceil((self.orig_index + n_cols - (self.resampled_index + ratio)) / ratio))
         src, weights = [], []
+        orig, res = self.orig_index, self.resampled_index
         for j in range(n_cols):
-            self.orig_index += 1.
-            n = self.processable(0)
+            orig += 1.
+            n = int(ceil((orig - (res + ratio)) / ratio))
             if n <= 0:
                 continue
-            new_indices = self.resampled_index + self.resampling_ratio * np.arange(1, n + 1, dtype=np.float64)
-            weights.append(self.orig_index - new_indices)
-            src += [j] * n
-            self.resampled_index = float(new_indices[-1])
-        a = np.ascontiguousarray(np.concatenate(weights)) if weights else np.zeros(0)
-        return total, np.ascontiguousarray(src, np.int32), a
+            last = res
+            for k in range(1, n + 1):
+                last = res + ratio * float(k)
+                weights.append(orig - last)
+                src.append(j)
+            res = last
+        self.orig_index, self.resampled_index = orig, res
+        return total, np.array(src, np.int32), np.array(weights, np.float64)
 
     def push(self, data):
         data = np.ascontiguousarray(data, np.float64)

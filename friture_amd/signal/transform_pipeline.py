@@ -16,14 +16,32 @@ import numpy as np
 class Transform_Pipeline:
     def __init__(self, blocks):
         self.blocks = blocks
+        self._fused_for = None          # ids of the blocks the fused path was last validated for
+        self._tables = None             # (freq, targets, lut) as float64 / uint32 arrays + their addresses, keyed by identity
 
     def _fusable(self):
+        b = self.blocks
+        key = tuple(map(id, b))
+        if self._fused_for is not None and self._fused_for[0] == key:
+            return self._fused_for[1]
         from .color_tranform import Color_Transform
         from .frequency_resampler import Frequency_Resampler
         from .online_linear_2D_resampler import Online_Linear_2D_resampler
-        b = self.blocks
-        return (len(b) == 3 and type(b[0]) is Frequency_Resampler and type(b[1]) is Online_Linear_2D_resampler
-                and type(b[2]) is Color_Transform)
+        ok = (len(b) == 3 and type(b[0]) is Frequency_Resampler and type(b[1]) is Online_Linear_2D_resampler
+              and type(b[2]) is Color_Transform)
+        self._fused_for = (key, ok)
+        return ok
+
+    def _constant_tables(self, fr, ct):
+        """The frequency table, the screen rows' frequencies and the LUT change only when the widget is reconfigured: their
+        contiguous copies and addresses are kept until one of the source arrays is replaced."""
+        t = self._tables
+        if t is None or t[0] is not fr.freq or t[1] is not fr.xscaled or t[2] is not ct.colors:
+            freq = np.ascontiguousarray(fr.freq, np.float64)
+            targets = np.ascontiguousarray(fr.xscaled, np.float64)
+            lut = np.ascontiguousarray(ct.colors, np.uint32)
+            t = self._tables = (fr.freq, fr.xscaled, ct.colors, freq, targets, lut, freq.ctypes.data, targets.ctypes.data, lut.ctypes.data)
+        return t[3:]
 
     def push(self, data):
         if not self._fusable():
@@ -32,24 +50,30 @@ class Transform_Pipeline:
         data = np.asarray(data, np.float64)
         if data.ndim != 2 or data.shape[1] == 0:
             return reduce(lambda columns, stage: stage.push(columns), self.blocks, data)
-        freq = np.ascontiguousarray(fr.freq, np.float64)
-        targets = np.ascontiguousarray(fr.xscaled, np.float64)
+        freq, targets, lut, p_freq, p_targets, p_lut = self._constant_tables(fr, ct)
         if data.shape[0] != freq.size:
             raise ValueError("fp and xp are not of the same length.")          # numpy.interp's complaint
         height, n_cols = targets.size, data.shape[1]
         tr.set_height(height)                                  # Fourier-resamples the carried column on a resize
         total, src, a = tr.advance(n_cols)                     # the scalar index recurrence of Online_Linear_2D_resampler.push
-        old_in = np.ascontiguousarray(tr.old_data, np.float64)
-        norm = np.ascontiguousarray(data.T)                    # frame-major: a column of the block is a row here
-        lut = np.ascontiguousarray(ct.colors, np.uint32)
+        old_in = tr.old_data
+        if old_in.dtype != np.float64 or not old_in.flags.c_contiguous:
+            old_in = np.ascontiguousarray(old_in, np.float64)
+        norm = data.T                                          # frame-major: a column of the block is a row here
+        if not norm.flags.c_contiguous:
+            norm = np.ascontiguousarray(norm)
         n_out = len(src)
         pix = np.empty((height, max(n_out, 1)), np.uint32)
         old_out = np.empty(height)
-        from .. import _lib
-        _lib.check(fr._lib.frt_screen_columns(norm.ctypes.data, freq.size, n_cols, freq.ctypes.data, targets.ctypes.data, height,
-                                              old_in.ctypes.data, src.ctypes.data if n_out else None, a.ctypes.data if n_out else None,
-                                              n_out, lut.ctypes.data, pix.ctypes.data if n_out else None, old_out.ctypes.data))
+        rc = fr._lib.frt_screen_columns(norm.ctypes.data, freq.size, n_cols, p_freq, p_targets, height, old_in.ctypes.data,
+                                        src.ctypes.data if n_out else None, a.ctypes.data if n_out else None, n_out, p_lut,
+                                        pix.ctypes.data if n_out else None, old_out.ctypes.data)
+        if rc:
+            from .. import _lib
+            _lib.check(rc)
         tr.old_data = old_out
+        if n_out and total == n_out:
+            return pix
         out = np.full((height, max(total, 0)), lut[0], np.uint32)              # columns the resampler left at zero map to lut[0]
         if n_out:
             out[:, :n_out] = pix[:, :n_out]

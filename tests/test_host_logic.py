@@ -54,3 +54,32 @@ def test_tables_match_reference(golden):
         assert np.array_equal(fi, o[f"bands{bpo}_fi"]) and np.array_equal(flo, o[f"bands{bpo}_flow"])
         assert np.array_equal(fhi, o[f"bands{bpo}_fhigh"])
         assert np.array_equal(tables.weighting_db(fi)[0], o[f"bands{bpo}_A"])
+
+
+def test_time_resampler_bookkeeping_matches_oracle():
+    """Online_Linear_2D_resampler.advance (plain Python floats) against the oracle's numpy restatement of the reference's index
+    recurrence (online_linear_2D_resampler.py:61-97): the same pixel columns, the same float64 weights bit for bit, the same
+    carried indices — for up- and down-sampling ratios and ragged pushes (no device call involved)."""
+    from friture_amd.signal.online_linear_2D_resampler import Online_Linear_2D_resampler
+    rng = np.random.default_rng(3)
+    for L, M in ((25, 16), (1, 3), (7, 5), (375, 32), (2, 2), (1000, 3)):
+        mine = object.__new__(Online_Linear_2D_resampler)               # the constructor binds the device library
+        mine.resampling_ratio, mine.orig_index, mine.resampled_index = float(L) / M, 0., 0.
+        ref = dsp.TimeResampler(L, M, 4)
+        for _ in range(40):
+            n_cols = int(rng.integers(0, 6))
+            total, src, a = mine.advance(n_cols)
+            # the oracle's loop, bookkeeping only
+            want_total = ref._processable(n_cols)
+            want_src, want_a = [], []
+            for j in range(n_cols):
+                ref.orig_index += 1.0
+                n = ref._processable(0)
+                if n > 0:
+                    idx = ref.resampled_index + ref.ratio * np.arange(1, n + 1, dtype=np.float64)
+                    want_a += list(ref.orig_index - idx)
+                    want_src += [j] * n
+                    ref.resampled_index = float(idx[-1])
+            assert total == want_total and list(src) == want_src
+            assert np.array_equal(a, np.array(want_a, np.float64))
+            assert mine.orig_index == ref.orig_index and mine.resampled_index == ref.resampled_index
