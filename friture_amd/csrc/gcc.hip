@@ -45,7 +45,12 @@ struct GccArgs {
     MixedPlan plan;        // for M2
     int L, M, M2, R;
     int vec;               // d0, d1 and xcorr are 16-byte aligned
+    long long* prof;       // FRT_GCC_PROFILE: phase time stamps of workgroup 0 (100 MHz counter), else null
 };
+#define GCC_STAMP(i)                                                           \
+    do {                                                                       \
+        if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.prof[i] = wall_clock64(); \
+    } while (0)
 
 template <typename T>
 __device__ T block_sum(T v, T* red) {
@@ -73,6 +78,7 @@ __device__ double block_max(double v, double* red) {
 // The sub-transform engine: the compile-time plan 6 x 10 x 10 x 10 (fft_static.h) for the default window's 6000 points,
 // the run-time mixed-radix plan for every other 5-smooth length.
 constexpr int kGccStaticM2 = 6000;
+constexpr int kGccSlotsMax = (kGccMaxM2 + kGccThreads - 1) / kGccThreads;      // points of a sub-transform per thread: 6
 template <bool ST>
 __device__ __forceinline__ void gcc_fft(cpx<double>* buf, const GccArgs& a, int tid) {
     if constexpr (ST) static_fft_forward<double, kGccThreads, 6, 10, 10, 10>(buf, (const cpx<double>*)a.tws, tid);
@@ -104,6 +110,85 @@ __device__ __forceinline__ cpx<double> gcc_unpack(cpx<double> A, cpx<double> Bz,
     const C Sm = A + B, D = A - B;
     const C u = cmul(t, D);
     return {0.5 * (Sm.x + u.y), 0.5 * (Sm.y - u.x)};
+}
+
+// Sample pair p of a window (16-byte load when the window is aligned; a view into a ring need not be)
+__device__ __forceinline__ double2 gcc_pair_at(const double* sig, int p, int vec) {
+    return vec ? ((const double2*)sig)[p] : double2{sig[2 * p], sig[2 * p + 1]};
+}
+
+// Sum of a window's L samples over the workgroup's threads, eight independent loads per thread in flight at a time (a
+// loop of one load per trip pays the memory latency L / 2048 times over: 12 round trips for the default window).
+__device__ __forceinline__ double gcc_thread_sum(const double* sig, int L, int vec, int tid) {
+    double acc = 0.0;
+    const int np = L / 2;
+    for (int base = 0; base < np; base += 8 * kGccThreads) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = base + u * kGccThreads + tid;
+            v[u] = p < np ? gcc_pair_at(sig, p, vec) : double2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u].x + v[u].y;
+    }
+    return acc;
+}
+
+// (x - mean) w of sub-transform r into the LDS array, every thread's (at most six) loads in flight together
+template <int R>
+__device__ __forceinline__ void gcc_load_sub(const GccArgs& a, const double* sig, double mean, int r, cpx<double>* buf, int tid) {
+    const double2* wn = (const double2*)a.window;
+    const int M2 = a.M2;
+    double2 x[kGccSlotsMax], w[kGccSlotsMax];
+#pragma unroll
+    for (int i = 0; i < kGccSlotsMax; ++i) {
+        const int m = tid + i * kGccThreads;
+        x[i] = w[i] = double2{0.0, 0.0};
+        if (m < M2) {
+            x[i] = gcc_pair_at(sig, R * m + r, a.vec);
+            w[i] = wn[R * m + r];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kGccSlotsMax; ++i) {
+        const int m = tid + i * kGccThreads;
+        if (m < M2) buf[m] = {(x[i].x - mean) * w[i].x, (x[i].y - mean) * w[i].y};
+    }
+}
+
+// Input of inverse sub-transform r into the LDS array: conj( W_M^{-r k} sum_q W_R^{-r q} Zi[k + q M2] ) (the conjugate turns
+// the forward engine into the inverse: ifft(u) = conj(fft(conj u)) / n), a thread's loads in flight together
+template <int R>
+__device__ __forceinline__ void gcc_load_inverse(const cpx<double>* Zi, const cpx<double>* twm, int r, int M2, cpx<double>* buf, int tid) {
+    using C = cpx<double>;
+    constexpr int G = R <= 2 ? kGccSlotsMax : 2;           // slots per group: G R + G loads in flight
+#pragma unroll
+    for (int i0 = 0; i0 < kGccSlotsMax; i0 += G) {
+        C z[G][R], tw[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int k = tid + (i0 + g) * kGccThreads;
+            tw[g] = {1.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < R; ++q) z[g][q] = {0.0, 0.0};
+            if (k < M2) {
+#pragma unroll
+                for (int q = 0; q < R; ++q) z[g][q] = Zi[k + q * M2];
+                tw[g] = twm[r * k];                          // r k < M
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int k = tid + (i0 + g) * kGccThreads;
+            if (k < M2) {
+                C acc = z[g][0];
+#pragma unroll
+                for (int q = 1; q < R; ++q) acc = acc + cmul(cconj(twm[((r * q) % R) * M2]), z[g][q]);      // W_R^{-r q} = conj(W_M^{(r q mod R) M2})
+                buf[k] = cconj(cmul(cconj(tw[g]), acc));
+            }
+        }
+    }
 }
 
 // Forward sub-transforms of ONE signal by one workgroup, R <= 2.  The signal is read once: thread t takes the sample pairs
@@ -207,9 +292,12 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
     const C* twm = (const C*)a.twm;
     const C* twl = (const C*)a.twl;
 
-    // ---- means (both signals in one pass) ---------------------------------------------------------------
+    GCC_STAMP(0);
+    // ---- means -----------------------------------------------------------------------------------------------
     double mean[2];
     {
+        // (one load per trip and signal: eight in flight per thread — gcc_thread_sum — measured 5 % SLOWER for the kernel as a
+        // whole at 1 and at 1024 pairs; this kernel's workgroups are alone on their CUs and meet HBM in bursts either way)
         double acc0 = 0.0, acc1 = 0.0;
         for (int t = tid; t < L; t += kGccThreads) {
             acc0 += sig[0][t];
@@ -223,27 +311,23 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
         a.means[2 * pair + 1] = mean[1];
     }
 
+    GCC_STAMP(1);
     // ---- forward sub-transforms: S[s][r][k'] = FFT_M2( z_s[R m + r] ); the last one stays in LDS ---------------
     GccSub<R> sub;
     for (int s = 0; s < 2; ++s)
         for (int r = 0; r < R; ++r) {
-            const double2* wn = (const double2*)a.window;
-            const double mu = mean[s];
-            if (a.vec) {                                     // 16-byte aligned windows (a ring view need not be)
-                const double2* sg = (const double2*)sig[s];
+            {
+                const double2* wn = (const double2*)a.window;
+                const double mu = mean[s];
                 for (int m = tid; m < M2; m += kGccThreads) {
-                    const double2 x = sg[R * m + r], w = wn[R * m + r];
+                    const double2 x = gcc_pair_at(sig[s], R * m + r, a.vec), w = wn[R * m + r];
                     buf[m] = {(x.x - mu) * w.x, (x.y - mu) * w.y};
-                }
-            } else {
-                for (int m = tid; m < M2; m += kGccThreads) {
-                    const int t = 2 * (R * m + r);
-                    const double2 w = wn[R * m + r];
-                    buf[m] = {(sig[s][t] - mu) * w.x, (sig[s][t + 1] - mu) * w.y};
                 }
             }
             __syncthreads();
+            if (s == 0 && r == 0) GCC_STAMP(2);
             gcc_fft<ST>(buf, a, tid);
+            if (s == 0 && r == 0) GCC_STAMP(3);
             const bool last = s == 1 && r == R - 1;
             C* dst = S + ((size_t)s * R + r) * M2;
             sub.p[s][r] = last ? (const C*)buf : (const C*)dst;
@@ -254,6 +338,7 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
         }
     __threadfence_block();
     __syncthreads();
+    GCC_STAMP(4);
 
     // ---- cross spectrum of the bin pairs (k, M - k) and its maximum magnitude -----------------------------------
     constexpr bool KEEP = R <= 2;                        // M <= 12288: at most 7 pairs per thread stay in registers
@@ -280,7 +365,8 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
             g_lo[i] = g_hi[i] = {0.0, 0.0};
             if (2 * k <= M) cross(k, g_lo[i], g_hi[i]);
             gmax = fmax(gmax, fmax(sqrt(g_lo[i].x * g_lo[i].x + g_lo[i].y * g_lo[i].y), sqrt(g_hi[i].x * g_hi[i].x + g_hi[i].y * g_hi[i].y)));
-            asm volatile("" ::: "memory");                   // one pair's loads in flight at a time (register budget)
+            asm volatile("" ::: "memory");                   // one pair's loads in flight at a time (register budget; the phase is
+                                                             // bound by its float64 arithmetic — two in flight measured equal)
         }
     } else {
         for (int k = tid; 2 * k <= M; k += kGccThreads) {
@@ -290,6 +376,7 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
         }
     }
     gmax = block_max(gmax, red);                             // (its barriers: every read of the LDS sub-spectrum is done)
+    GCC_STAMP(5);
 
     // ---- PHAT weighting and packing for the inverse real transform ---------------------------------------
     // (zk, zm) = Zi[k], Zi[M - k] from the pair's cross-spectrum values
@@ -368,6 +455,7 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
         __syncthreads();
     }
 
+    GCC_STAMP(6);
     // ---- inverse sub-transforms: z[R m + r] = (1/M) IFFT_M2( W_M^{-r k'} sum_q W_R^{-r q} Zi[k' + q M2] ) ---
     double* out = a.xcorr + (size_t)pair * L;
     const double inv = 1.0 / (double)M;
@@ -384,17 +472,7 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
                 __syncthreads();
             }
         } else if constexpr (R > 2) {
-            for (int k = tid; k < M2; k += kGccThreads) {
-                C acc = Zi[k];
-#pragma unroll
-                for (int q = 1; q < R; ++q) {
-                    // W_R^{-r q} = conj(W_M^{(r q mod R) M2})
-                    const C wq = cconj(twm[((r * q) % R) * M2]);
-                    acc = acc + cmul(wq, Zi[k + q * M2]);
-                }
-                acc = cmul(cconj(twm[r * k]), acc);                  // r k < M
-                buf[k] = cconj(acc);                   // conj trick: ifft(u) = conj(fft(conj u)) / n
-            }
+            gcc_load_inverse<R>(Zi, twm, r, M2, buf, tid);
             __syncthreads();
         }
         gcc_fft<ST>(buf, a, tid);
@@ -413,6 +491,7 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
         __syncthreads();
     }
 
+    GCC_STAMP(7);
     // ---- argmax |xcorr| (first index on ties, as numpy.argmax) ---------------------------------------------
     if (a.argmax) {
         for (int o = 32; o > 0; o >>= 1) {
@@ -429,6 +508,7 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
             a.argmax[pair] = besti;
         }
     }
+    GCC_STAMP(8);
 }
 
 // Smoothing + statistics of the read-out: sm = alpha x + (1 - alpha) old (or x when old is null);
@@ -501,17 +581,12 @@ __global__ void __launch_bounds__(kGccThreads) gcc_fwd_kernel(const GccArgs a, u
     } else {
         const int s = blockIdx.x / R, r = blockIdx.x - s * R;
         const double* sig = (s ? a.d1 : a.d0) + (size_t)pair * L;
-        double acc = 0.0;
-        for (int t = tid; t < L; t += kGccThreads) acc += sig[t];
-        const double mean = block_sum(acc, red) / (double)L;
+        const double mean = block_sum(gcc_thread_sum(sig, L, a.vec, tid), red) / (double)L;
         if (tid == 0 && r == 0) {
             if (a.means) a.means[2 * pair + s] = mean;
             if (s == 0) gmax[pair] = 0ull;
         }
-        for (int m = tid; m < M2; m += kGccThreads) {
-            const int t = 2 * (R * m + r);
-            buf[m] = {(sig[t] - mean) * a.window[t], (sig[t + 1] - mean) * a.window[t + 1]};
-        }
+        gcc_load_sub<R>(a, sig, mean, r, buf, tid);
         __syncthreads();
         gcc_fft<ST>(buf, a, tid);
         for (int k = tid; k < M2; k += kGccThreads) S[((size_t)s * R + r) * M2 + k] = buf[k];
@@ -582,7 +657,7 @@ __global__ void __launch_bounds__(256) gcc_pack_kernel(const GccArgs a, const un
 // Inverse sub-transform r of a pair; the workgroup leaves the (|value|, first index) of its slice's extremum for
 // gcc_argmax_combine_kernel.  (Folding the R slices in the pair's last workgroup to finish was measured: the device-scope
 // fences that hand-over needs on a multi-XCD part cost 10 us per launch, twice the tiny launch below.)
-template <bool ST>
+template <int R, bool ST>
 __global__ void __launch_bounds__(kGccThreads) gcc_inv_kernel(const GccArgs a, double* __restrict__ part_val, int* __restrict__ part_idx) {
     using C = cpx<double>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -590,18 +665,10 @@ __global__ void __launch_bounds__(kGccThreads) gcc_inv_kernel(const GccArgs a, d
     double* red = (double*)(buf + a.M2);
     int* redi = (int*)(red + 16);
     const int tid = threadIdx.x, pair = blockIdx.y, r = blockIdx.x;
-    const int L = a.L, M = a.M, M2 = a.M2, R = a.R;
+    const int L = a.L, M = a.M, M2 = a.M2;
     const C* Zi = (const C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2) + 2 * (size_t)M + (M + 1);
     const C* twm = (const C*)a.twm;
-    for (int k = tid; k < M2; k += kGccThreads) {
-        C acc = Zi[k];
-        for (int q = 1; q < R; ++q) {
-            const C wq = cconj(twm[((r * q) % R) * M2]);
-            acc = acc + cmul(wq, Zi[k + q * M2]);
-        }
-        acc = cmul(cconj(twm[r * k]), acc);                  // r k < M
-        buf[k] = cconj(acc);
-    }
+    gcc_load_inverse<R>(Zi, twm, r, M2, buf, tid);
     __syncthreads();
     gcc_fft<ST>(buf, a, tid);
     double* out = a.xcorr + (size_t)pair * L;
@@ -967,14 +1034,14 @@ struct frt_gcc {
     // any-length path (chirp-z): lengths the one-workgroup kernel does not take
     bool any = false;
     int log2r = 0, log2c = 0;
-    DeviceBuffer chirp, bhat, work, spec, twr, twc, gmax, part_val, part_idx;
+    DeviceBuffer chirp, bhat, work, spec, twr, twc, gmax, part_val, part_idx, prof;
 };
 
 extern "C" void frt_gcc_destroy(frt_gcc* h) {
     if (!h) return;
     DeviceBuffer* bufs[] = {&h->window, &h->twm, &h->tw2, &h->tws, &h->twl, &h->scratch, &h->in0, &h->in1,
                             &h->out, &h->argmax, &h->means, &h->old, &h->sm, &h->stats,
-                            &h->chirp, &h->bhat, &h->work, &h->spec, &h->twr, &h->twc, &h->gmax, &h->part_val, &h->part_idx};
+                            &h->chirp, &h->bhat, &h->work, &h->spec, &h->twr, &h->twc, &h->gmax, &h->part_val, &h->part_idx, &h->prof};
     for (auto* b : bufs) b->release();
     delete h;
 }
@@ -1053,8 +1120,8 @@ extern "C" int frt_gcc_create(frt_gcc** out, int length, int n_pairs) {
     }
     const void* big[] = {(const void*)gcc_phat_kernel<1, false>, (const void*)gcc_phat_kernel<2, false>, (const void*)gcc_phat_kernel<4, false>,
                          (const void*)gcc_phat_kernel<2, true>,  (const void*)gcc_fwd_kernel<1, false>,  (const void*)gcc_fwd_kernel<2, false>,
-                         (const void*)gcc_fwd_kernel<4, false>,  (const void*)gcc_fwd_kernel<2, true>,   (const void*)gcc_inv_kernel<false>,
-                         (const void*)gcc_inv_kernel<true>};
+                         (const void*)gcc_fwd_kernel<4, false>,  (const void*)gcc_fwd_kernel<2, true>,   (const void*)gcc_inv_kernel<1, false>,
+                         (const void*)gcc_inv_kernel<2, false>,  (const void*)gcc_inv_kernel<4, false>,  (const void*)gcc_inv_kernel<2, true>};
     for (const void* f : big)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
             set_last_error("frt_gcc_create: cannot reserve %zu bytes of LDS", h->lds_bytes);
@@ -1137,6 +1204,11 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
     a.M2 = h->M2;
     a.R = h->R;
     a.tws = h->tws.as<double>();
+    static const bool profile = getenv("FRT_GCC_PROFILE") != nullptr;
+    if (profile) {
+        if ((rc = h->prof.reserve(16 * sizeof(long long)))) return rc;
+        a.prof = h->prof.as<long long>();
+    }
     a.vec = ((uintptr_t)a.d0 % 16 == 0) && ((uintptr_t)a.d1 % 16 == 0) && ((uintptr_t)a.xcorr % 16 == 0);
     const bool st = h->static_plan;
     const char* force = getenv("FRT_GCC_ONE_WORKGROUP");
@@ -1157,8 +1229,12 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
         else if (h->R == 2) hipLaunchKernelGGL(gcc_cross_kernel<2>, cgrid, dim3(256), 0, h->stream, a, gm);
         else hipLaunchKernelGGL(gcc_cross_kernel<4>, cgrid, dim3(256), 0, h->stream, a, gm);
         hipLaunchKernelGGL(gcc_pack_kernel, cgrid, dim3(256), 0, h->stream, a, gm);
-        if (st) hipLaunchKernelGGL(gcc_inv_kernel<true>, igrid, block, h->lds_bytes, h->stream, a, h->part_val.as<double>(), h->part_idx.as<int>());
-        else hipLaunchKernelGGL(gcc_inv_kernel<false>, igrid, block, h->lds_bytes, h->stream, a, h->part_val.as<double>(), h->part_idx.as<int>());
+        double* pv = h->part_val.as<double>();
+        int* pi = h->part_idx.as<int>();
+        if (st) hipLaunchKernelGGL((gcc_inv_kernel<2, true>), igrid, block, h->lds_bytes, h->stream, a, pv, pi);
+        else if (h->R == 1) hipLaunchKernelGGL((gcc_inv_kernel<1, false>), igrid, block, h->lds_bytes, h->stream, a, pv, pi);
+        else if (h->R == 2) hipLaunchKernelGGL((gcc_inv_kernel<2, false>), igrid, block, h->lds_bytes, h->stream, a, pv, pi);
+        else hipLaunchKernelGGL((gcc_inv_kernel<4, false>), igrid, block, h->lds_bytes, h->stream, a, pv, pi);
         hipLaunchKernelGGL(gcc_argmax_combine_kernel, dim3((h->n_pairs + 255) / 256), dim3(256), 0, h->stream, h->part_val.as<double>(),
                            h->part_idx.as<int>(), h->R, h->n_pairs, h->argmax.as<int>());
     } else {
@@ -1169,6 +1245,14 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
         else hipLaunchKernelGGL((gcc_phat_kernel<4, false>), grid, block, h->lds_bytes, h->stream, a);
     }
     FRT_HIP_CHECK(hipGetLastError());
+    if (profile && !split) {
+        long long t[9];
+        FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+        FRT_HIP_CHECK(hipMemcpy(t, h->prof.ptr, sizeof(t), hipMemcpyDeviceToHost));
+        fprintf(stderr, "gcc_phat_kernel phases (us): means %.1f | load0 %.1f | fft0 %.1f | rest of forward %.1f | cross %.1f | pack %.1f | inverse %.1f | argmax %.1f | total %.1f\n",
+                (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01,
+                (t[7] - t[6]) * 0.01, (t[8] - t[7]) * 0.01, (t[8] - t[0]) * 0.01);
+    }
     }
     if (!dev) FRT_HIP_CHECK(hipMemcpyAsync(xcorr_out, h->out.ptr, bytes, hipMemcpyDeviceToHost, h->stream));
     if (argmax_out) {
