@@ -337,26 +337,34 @@ def stft1024_f64_leg(dev, world, rank, consts):
 
 
 def gcc_leg(dev, world, rank):
-    """configs[4], first half: GCC-PHAT of 100 window pairs of L = 24000 samples (float64) per GPU."""
+    """configs[4], first half: GCC-PHAT of 100 window pairs of L = 24000 samples (float64) per GPU — and of 1024 pairs, the
+    batch at which every CU holds a pair."""
     import torch
 
     from friture_amd import distributed
     from friture_amd.signal.correlation import GccPhat
-    L, pairs = 24000, 100
-    rng = np.random.default_rng(4242 + rank)
-    d0 = 0.25 * rng.standard_normal((pairs, L))
-    d1 = np.roll(d0, 37, axis=1) + 0.025 * rng.standard_normal((pairs, L))
-    g = GccPhat(L, pairs)
-    a0, a1 = torch.from_numpy(d0).to(dev), torch.from_numpy(d1).to(dev)
-    dt, ev_ms = leg(lambda k: g.correlate(a0, a1), 10, dev, distributed, torch)
-    _, am = g.correlate(a0, a1)
-    nbytes = pairs * 24 * L
-    return {"configs4_gcc_phat": {"value": world * pairs / dt, "unit": "windows/s", "ms_per_step": dt * 1e3,
-                                  "config": f"{pairs} window pairs/GPU, L = {L}, float64, device resident; delay 37 samples found: "
-                                            f"{bool(int(am[0]) == 37)}",
-                                  "roofline": {"bound": "hbm", "kernel": "gcc_phat_kernel", "unit": "GB/s", "achieved": nbytes / dt / 1e9,
-                                               "peak": HBM_PEAK_GBS, "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS,
-                                               "algorithmic_bytes_per_step": nbytes}}}
+    L = 24000
+    out = {}
+    for pairs, name in ((100, "configs4_gcc_phat"), (1024, "configs4_gcc_phat_1024_pairs")):
+        rng = np.random.default_rng(4242 + rank)
+        d0 = 0.25 * rng.standard_normal((pairs, L))
+        d1 = np.roll(d0, 37, axis=1) + 0.025 * rng.standard_normal((pairs, L))
+        g = GccPhat(L, pairs)
+        a0, a1 = torch.from_numpy(d0).to(dev), torch.from_numpy(d1).to(dev)
+        dt, ev_ms = leg(lambda k: g.correlate(a0, a1), 10, dev, distributed, torch)
+        _, am = g.correlate(a0, a1)
+        nbytes = pairs * 24 * L
+        # real transforms of 24000 samples as complex transforms of 12000: 3 per pair (two forward, one inverse), 5 n log2 n
+        flops = pairs * 3 * 5.0 * 12000 * np.log2(12000.0)
+        out[name] = {"value": world * pairs / dt, "unit": "windows/s", "ms_per_step": dt * 1e3,
+                     "config": f"{pairs} window pairs/GPU, L = {L}, float64, device resident; delay 37 samples found: "
+                               f"{bool(int(am[0]) == 37)}",
+                     "roofline": {"bound": "hbm", "kernel": "gcc_fwd/cross/pack/inv kernels" if pairs <= 160 else "gcc_phat_kernel",
+                                  "unit": "GB/s", "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBS, "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS,
+                                  "algorithmic_bytes_per_step": nbytes, "algorithmic_flops_per_step": flops,
+                                  "f64_tflops": flops / dt / 1e12, "f64_frac": flops / dt / 1e12 / F64_VECTOR_PEAK_TFLOPS}}
+        del a0, a1, g
+    return out
 
 
 class StubEngine:
