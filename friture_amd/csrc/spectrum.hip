@@ -97,10 +97,12 @@ extern "C" int frt_spectrum_post(const void* psd, int psd_is_f32, int n_frames, 
         decay = std::pow(1.0 - alpha, (double)n);
     }
     const bool dev = is_device_pointer(smoothed_out);
-    FRT_REQUIRE(dev == is_device_pointer(db_out) && dev == is_device_pointer(previous) &&
-                    (n_frames == 0 || dev == is_device_pointer(psd)) && (!weight_db || dev == is_device_pointer(weight_db)) &&
-                    (!ref_smoothed || dev == is_device_pointer(ref_smoothed)),
-                "frt_spectrum_post: buffers must all be host or all be device memory");
+    // the smoothed spectra and what they are formed from live together (all host or all device); the dB vector may come
+    // back to a host array while the state stays on the device (the spectrum widget's object)
+    FRT_REQUIRE(dev == is_device_pointer(previous) && (n_frames == 0 || dev == is_device_pointer(psd)) &&
+                    (!weight_db || dev == is_device_pointer(weight_db)) && (!ref_smoothed || dev == is_device_pointer(ref_smoothed)) &&
+                    (dev || !is_device_pointer(db_out)),
+                "frt_spectrum_post: spectra, state and weights must all be host or all be device memory");
     const size_t esz = psd_is_f32 ? 4 : 8;
     // all host arguments in one pinned block, one upload, one download (StageCall, common.h): seven blocking copies and a
     // thread-local set of device buffers until round 3

@@ -713,6 +713,8 @@ struct frt_stft {
     DeviceBuffer stage_in, stage_out;
     char* pin = nullptr;          // pinned staging of the host-buffer path: [input][output]
     size_t pin_bytes = 0;
+    hipEvent_t pin_done = nullptr;     // host samples -> device spectra returns without waiting: guards the pinned block
+    bool pin_pending = false;
 };
 
 template <typename T>
@@ -785,6 +787,8 @@ extern "C" void frt_stft_destroy(frt_stft* h) {
     h->lut.release();
     h->stage_in.release();
     h->stage_out.release();
+    if (h->pin_pending) (void)hipEventSynchronize(h->pin_done);
+    if (h->pin_done) (void)hipEventDestroy(h->pin_done);
     if (h->pin) (void)hipHostFree(h->pin);
     delete h;
 }
@@ -992,11 +996,42 @@ extern "C" int frt_stft_run(frt_stft* h, int kind, const void* x, int64_t T, int
     if (F == 0) return FRT_OK;
     FRT_REQUIRE(x && out, "frt_stft_run: null buffer");
     const bool dx = is_device_pointer(x), dout = is_device_pointer(out);
-    FRT_REQUIRE(dx == dout, "frt_stft_run: input and output must both be host or both be device memory");
+    FRT_REQUIRE(dx == dout || dout, "frt_stft_run: device samples need a device output");
     const int nb = h->fft_size / 2 + 1;
     const size_t in_esz = h->precision == 32 ? 4 : 8;
     const size_t out_esz = (kind == FRT_STFT_IMAGE) ? 4 : in_esz;
     if (dx) return stft_launch(h, kind, x, x_stride, out, F, h->stream);
+    if (h->pin_pending) {                        // an earlier host -> device call may still be reading the pinned block
+        FRT_HIP_CHECK(hipEventSynchronize(h->pin_done));
+        h->pin_pending = false;
+    }
+    if (dout) {
+        // host samples, spectra that stay on the device (a widget's ring on the host, its read-out chain on the device):
+        // the samples go through the pinned block — read in place by the kernel when small — and the call returns without
+        // waiting; consumers order themselves on the handle's stream
+        const size_t in_bytes = (size_t)h->n_channels * x_stride * in_esz;
+        int rc;
+        if (in_bytes > h->pin_bytes) {
+            FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+            if (h->pin) (void)hipHostFree(h->pin);
+            h->pin = nullptr;
+            h->pin_bytes = 0;
+            FRT_HIP_CHECK(hipHostMalloc((void**)&h->pin, 2 * in_bytes, hipHostMallocDefault));
+            h->pin_bytes = 2 * in_bytes;
+        }
+        memcpy(h->pin, x, in_bytes);
+        const void* src = h->pin;
+        if (in_bytes > kZeroCopyMax) {
+            if ((rc = h->stage_in.reserve(in_bytes))) return rc;
+            FRT_HIP_CHECK(hipMemcpyAsync(h->stage_in.ptr, h->pin, in_bytes, hipMemcpyHostToDevice, h->stream));
+            src = h->stage_in.ptr;
+        }
+        if ((rc = stft_launch(h, kind, src, x_stride, out, F, h->stream))) return rc;
+        if (!h->pin_done) FRT_HIP_CHECK(hipEventCreateWithFlags(&h->pin_done, hipEventDisableTiming));
+        FRT_HIP_CHECK(hipEventRecord(h->pin_done, h->stream));
+        h->pin_pending = true;
+        return FRT_OK;
+    }
 
     // host buffers: stage through device memory, return when the result is back.  Small calls (the widgets' one frame at a
     // time: audioproc.analyzelive) go through the handle's pinned block — from pageable memory the runtime stages every

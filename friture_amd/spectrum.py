@@ -107,18 +107,18 @@ class SpectrumAnalyzer:
 
 
 class SpectrumAnalyzerStream(SpectrumAnalyzer):
-    """The same slot with its signals resident in HBM: the ring is a DeviceRingBuffer, the realizable frames go through the
-    float64 STFT in place, and smoothing, dB + weighting, peak and harmonic-product pitch (frt_spectrum_post) read and
-    write device buffers — the smoothed spectra never leave the device; per chunk the new samples go up and the dB
-    spectrum and two indices come down."""
+    """The same slot with its spectra resident in HBM.  The samples' ring stays on the host (a push is a numpy copy: the
+    widget completes a frame only every few chunks, and a device call per chunk would cost more than the ring is worth);
+    when frames complete, their window goes up once through page-locked memory (frt_stft_run, host samples -> device
+    spectra, no wait), and smoothing, dB + weighting, peak and harmonic-product pitch (frt_spectrum_post) read and write
+    device buffers — the PSD frames and the smoothed spectra never leave the device; per completed frame one window goes
+    up, the dB spectrum and two indices come down, one synchronisation."""
 
     def __init__(self, *args, **kw):
         import torch
         self._torch = torch
         self._dev = torch.device("cuda", torch.cuda.current_device())
         super().__init__(*args, **kw)
-        from .ringbuffer import DeviceRingBuffer
-        self.ringbuffer = DeviceRingBuffer()
 
     def setfftsize(self, fft_size):
         super().setfftsize(fft_size)
@@ -127,15 +127,15 @@ class SpectrumAnalyzerStream(SpectrumAnalyzer):
         self._d_disp1 = torch.zeros(nb, dtype=torch.float64, device=self._dev)
         self._d_disp2 = torch.zeros(nb, dtype=torch.float64, device=self._dev)
         self._d_next = torch.zeros(nb, dtype=torch.float64, device=self._dev)       # the smoothed spectrum being written
-        self._d_db = torch.empty(nb, dtype=torch.float64, device=self._dev)
+        self._d_psd = None                                                           # [frames, bins] of the last call
+        self._db = np.empty(nb)
 
     def update_weighting(self):
         super().update_weighting()
         self._d_w = self._torch.from_numpy(np.ascontiguousarray(self.w, np.float64)).to(self._dev)
 
     def handle_new_data(self, floatdata):
-        torch = self._torch
-        self.ringbuffer.push(torch.from_numpy(np.ascontiguousarray(floatdata, np.float64)).to(self._dev), 0.)
+        self.ringbuffer.push(floatdata, 0.)
         index = self.ringbuffer.offset
         available = index - self.old_index
         if available < 0:
@@ -149,18 +149,30 @@ class SpectrumAnalyzerStream(SpectrumAnalyzer):
         last = self.old_index + (realizable - 1) * self.hop
         window = self.ringbuffer.data_indexed(last, span)
         self.old_index += realizable * self.hop
-        psd1 = self._engine.psd(window[0:1, :])[0]
-        peak, pitch = self._post_dev(psd1, self._d_disp1, self._d_w, None)
+        peak, pitch = self._post_dev(self._psd_dev(window[0], realizable), self._d_disp1, self._d_w, None)
         self._d_disp1, self._d_next = self._d_next, self._d_disp1
         if self.dual_channels and window.shape[0] > 1:
-            psd2 = self._engine.psd(window[1:2, :].contiguous())[0]
-            peak, _ = self._post_dev(psd2, self._d_disp2, None, self._d_disp1)
+            peak, _ = self._post_dev(self._psd_dev(window[1], realizable), self._d_disp2, None, self._d_disp1)
             self._d_disp2, self._d_next = self._d_next, self._d_disp2
-        db = self._d_db.cpu().numpy()
+        db = self._db.copy()
         self.dB_spectrogram = db
         self.fmax = self.freq[peak]
         self.fpitch = max(self.freq[pitch], 1e-20)
         return self.freq, db, self.fmax, self.fpitch
+
+    def _psd_dev(self, samples, n_frames):
+        """PSD frames [n_frames, bins] of a host window, left on the device (enqueued on the engine's stream, not waited for)."""
+        torch = self._torch
+        x = np.ascontiguousarray(samples, np.float64)
+        nb = len(self.freq)
+        if self._d_psd is None or self._d_psd.shape[0] < n_frames:
+            self._d_psd = torch.empty((n_frames, nb), dtype=torch.float64, device=self._dev)
+        nf = ctypes.c_int64(0)
+        e = self._engine
+        _lib.check(e._lib.frt_stft_run(e._h, 0, x.ctypes.data, x.shape[0], x.shape[0], ctypes.c_void_p(self._d_psd.data_ptr()),
+                                       ctypes.byref(nf)))
+        assert nf.value == n_frames
+        return self._d_psd[:n_frames]
 
     def _post_dev(self, psd, disp, weight, ref):
         nf, nb = psd.shape
@@ -169,5 +181,5 @@ class SpectrumAnalyzerStream(SpectrumAnalyzer):
         _lib.check(self._lib.frt_spectrum_post(
             vp(psd.data_ptr()), 0, nf, nb, nb, self.kernel.ctypes.data, len(self.kernel), float(self.alpha), vp(disp.data_ptr()),
             None if weight is None else vp(weight.data_ptr()), None if ref is None else vp(ref.data_ptr()), vp(self._d_next.data_ptr()),
-            vp(self._d_db.data_ptr()), ctypes.byref(peak), ctypes.byref(pitch)))
+            self._db.ctypes.data, ctypes.byref(peak), ctypes.byref(pitch)))
         return peak.value, pitch.value

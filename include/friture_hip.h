@@ -76,7 +76,9 @@ int frt_stft_set_epilogue(frt_stft* h, const double* weight_db, double spec_min,
                           const uint32_t* lut256);
 /* x: [n_channels][x_stride] samples (float for precision 32, double for 64), T valid per channel.
  * out: [n_channels][n_frames][fft_size/2+1] elements of the output kind (4 bytes each at
- * precision 32; at precision 64 PSD/DB/NORM are doubles and IMAGE stays uint32). */
+ * precision 32; at precision 64 PSD/DB/NORM are doubles and IMAGE stays uint32).
+ * x and out: both host (returns with the result), both device (enqueued on the handle's stream), or x host and out
+ * device (the samples go up through page-locked memory, the call returns without waiting: order consumers on the stream). */
 int frt_stft_run(frt_stft* h, int kind, const void* x, int64_t T, int64_t x_stride, void* out,
                  int64_t* n_frames_out);
 /* survey-named conveniences (precision-32 handles): */
@@ -271,7 +273,8 @@ int frt_exp_smooth_2d(const double* kernel, int nk, double alpha, const double* 
  * frame-major slab frt_stft_run writes).  smoothed = exp_smoothed_value_2d(kernel, alpha, psd^T, previous);
  * db = 10 log10(smoothed + 1e-30) + weight_db (or - 10 log10(ref_smoothed + 1e-30) in dual-channel mode);
  * *peak_index_out = argmax(db); *pitch_index_out = argmax of the harmonic product spectrum
- * s[:K] s[::2][:K] s[::3][:K], K = n_bins / 3, of smoothed (of ref_smoothed in dual-channel mode). */
+ * s[:K] s[::2][:K] s[::3][:K], K = n_bins / 3, of smoothed (of ref_smoothed in dual-channel mode).
+ * psd / previous / weight_db / ref_smoothed / smoothed_out: all host or all device; db_out may be a host array either way. */
 int frt_spectrum_post(const void* psd, int psd_is_f32, int n_frames, int n_bins, int64_t frame_stride,
                       const double* kernel, int nk, double alpha, const double* previous, const double* weight_db,
                       const double* ref_smoothed, double* smoothed_out, double* db_out, int* peak_index_out,
