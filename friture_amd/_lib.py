@@ -60,6 +60,7 @@ SIGNATURES = {
     "frt_octbank_energies": (c_int, [c_void_p, c_void_p, c_int64, c_int, POINTER(c_double), POINTER(c_double), c_int,
                                      c_void_p]),
     "frt_decimate_multiple": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, POINTER(c_int)]),
+    "frt_decimate_multiple_state": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_int), c_void_p]),
     "frt_gcc_create": (c_int, [POINTER(c_void_p), c_int, c_int]),
     "frt_gcc_destroy": (None, [c_void_p]),
     "frt_gcc_set_stream": (c_int, [c_void_p, c_void_p]),

@@ -1800,6 +1800,80 @@ extern "C" int frt_decimate_multiple(frt_octbank* h, int n_stages, const double*
     return FRT_OK;
 }
 
+// decimate_multiple with the reference's functional interface (decimate.py:45-71: the filter states are arguments and
+// results) as ONE call on host arrays: samples and states are read, and the decimated signal and the new states written,
+// in place in page-locked memory by the stage kernels — a call that went through frt_octbank_set_state,
+// frt_decimate_multiple and frt_octbank_get_state made three round trips.  One channel; zi / zf: [n_stages][12] or NULL
+// (zero state / states not wanted).  The handle's own carried state is not touched.
+extern "C" int frt_decimate_multiple_state(frt_octbank* h, int n_stages, const double* x, int n, const double* zi, double* out, int* n_out,
+                                           double* zf) {
+    FRT_REQUIRE(h && h->bpo == 0 && h->n_channels == 1, "frt_decimate_multiple_state: needs a one-channel handle created with bands_per_octave = 0");
+    FRT_REQUIRE(n_stages >= 1 && n_stages < kNOctave, "frt_decimate_multiple_state: n_stages %d not in [1, 8]", n_stages);
+    FRT_REQUIRE(n >= 0, "frt_decimate_multiple_state: n < 0");
+    int len[kNOctave];
+    stage_lengths(n, len);
+    if (n_out) *n_out = len[n_stages];
+    if (n == 0) return FRT_OK;
+    FRT_REQUIRE(x && out && !is_device_pointer(x) && !is_device_pointer(out), "frt_decimate_multiple_state: host arrays");
+    const int ord = h->h_order[0];
+    const size_t xbytes = (size_t)n * sizeof(double), sbytes = (size_t)n_stages * kStates * sizeof(double);
+    const size_t obytes = (size_t)len[n_stages] * sizeof(double);
+    const size_t in_need = (xbytes + 255) / 256 * 256 + sbytes;
+    FRT_REQUIRE(in_need <= kZeroCopyMax && obytes <= kZeroCopyMax, "frt_decimate_multiple_state: %d samples exceed the in-place call", n);
+    int rc;
+    if (in_need > h->pin_in_bytes || obytes > h->pin_out_bytes) {
+        FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+        for (auto& e : h->graphs)                              // captured graphs carry the pinned addresses
+            if (e.exec) (void)hipGraphExecDestroy(e.exec);
+        h->graphs.clear();
+        if (in_need > h->pin_in_bytes) {
+            if (h->pin_in) (void)hipHostFree(h->pin_in);
+            h->pin_in = nullptr;
+            h->pin_in_bytes = 0;
+            FRT_HIP_CHECK(hipHostMalloc(&h->pin_in, 2 * in_need, hipHostMallocDefault));
+            h->pin_in_bytes = 2 * in_need;
+        }
+        if (obytes > h->pin_out_bytes) {
+            if (h->pin_out) (void)hipHostFree(h->pin_out);
+            h->pin_out = nullptr;
+            h->pin_out_bytes = 0;
+            FRT_HIP_CHECK(hipHostMalloc(&h->pin_out, 2 * obytes, hipHostMallocDefault));
+            h->pin_out_bytes = 2 * obytes;
+        }
+    }
+    double* px = (double*)h->pin_in;
+    double* ps = (double*)((char*)h->pin_in + (xbytes + 255) / 256 * 256);
+    memcpy(px, x, xbytes);
+    for (int j = 0; j < n_stages; ++j)
+        for (int s = 0; s < kStates; ++s) ps[j * kStates + s] = (zi && s < ord) ? zi[j * ord + s] : 0.0;
+    for (int j = 1; j < n_stages; ++j)
+        if ((rc = h->xbuf[j].reserve((size_t)len[j] * sizeof(double)))) return rc;
+    for (int j = 0; j < n_stages; ++j) {
+        IirStageArgs a{};
+        a.x = j == 0 ? (const void*)px : h->xbuf[j].ptr;
+        a.x_stride = len[j];
+        a.n = len[j];
+        a.coef = h->coef.as<double>();
+        a.order = h->order.as<int>();
+        a.nfilt = 1;
+        a.dec_filter = 0;
+        a.state = ps + (size_t)j * kStates;
+        a.chunk = (len[j] + 63) / 64 * 64;
+        a.nchunks = 1;
+        a.pass = 0;
+        a.band_index[0] = -1;
+        a.xnext = j + 1 == n_stages ? (double*)h->pin_out : h->xbuf[j + 1].as<double>();
+        a.xnext_stride = len[j + 1];
+        if ((rc = launch_iir_stage(a, h->h_order.data(), 1, h->stream))) return rc;
+    }
+    FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    memcpy(out, h->pin_out, obytes);
+    if (zf)
+        for (int j = 0; j < n_stages; ++j)
+            for (int s = 0; s < ord; ++s) zf[j * ord + s] = ps[j * kStates + s];
+    return FRT_OK;
+}
+
 // ---- lfilter_float64_1D (friture/signal/lfilter.py:85-147): one filter, explicit state in / out ----
 extern "C" int frt_lfilter_f64(const double* b, const double* a, int n_coef, const double* x, int n, const double* zi,
                                double* y, double* zf) {

@@ -15,6 +15,7 @@ from .lfilter import lfilter_float64_1D
 
 _DP = ctypes.POINTER(ctypes.c_double)
 _handles: dict = {}
+_IN_PLACE_MAX = 30000         # samples per call that frt_decimate_multiple_state takes (256 KB in place)
 
 
 def _chain_handle(bdec, adec):
@@ -55,14 +56,22 @@ def decimate_multiple(Ndec, bdec, adec, x, zis):
         return out, (None if zis is None else zfs)
     lib = _lib.init()
     h = _chain_handle(bdec, adec)
+    n_out = ctypes.c_int(0)
+    out = np.empty((len(x) + 1) // 2, np.float64)      # upper bound
+    if len(x) <= _IN_PLACE_MAX:
+        # samples and states in, decimated samples and states out: one call, one synchronisation
+        zi = None if zis is None else np.ascontiguousarray(np.stack([np.asarray(z, np.float64) for z in zis[:Ndec]]))
+        zf = None if zis is None else np.empty((Ndec, 12), np.float64)
+        _lib.check(lib.frt_decimate_multiple_state(h, int(Ndec), x.ctypes.data, len(x), None if zi is None else zi.ctypes.data,
+                                                   out.ctypes.data, ctypes.byref(n_out), None if zf is None else zf.ctypes.data))
+        out = out[:n_out.value]
+        return out, (None if zis is None else [zf[j].copy() for j in range(Ndec)])
     slen = lib.frt_octbank_state_length(h)
     state = np.zeros(slen, np.float64)
     if zis is not None:
         for j, z in zip(range(Ndec), zis):
             state[12 * j:12 * (j + 1)] = z
     _lib.check(lib.frt_octbank_set_state(h, state.ctypes.data_as(_DP)))
-    n_out = ctypes.c_int(0)
-    out = np.empty(len(x), np.float64)      # upper bound
     _lib.check(lib.frt_decimate_multiple(h, int(Ndec), x.ctypes.data, len(x), out.ctypes.data, ctypes.byref(n_out)))
     out = out[:n_out.value].copy()
     if zis is None:

@@ -149,6 +149,11 @@ int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, int block, c
 /* decimate_multiple (friture/signal/decimate.py:45-71) with carried state: n_stages chained
  * decimations by 2 of x [n_channels][n] -> out [n_channels][*n_out].  Needs a bands_per_octave = 0 handle. */
 int frt_decimate_multiple(frt_octbank* h, int n_stages, const double* x, int n, double* out, int* n_out);
+/* the same with the reference's functional interface (the states are arguments and results, decimate.py:45-71) as ONE call
+ * on HOST arrays of one channel: zi / zf [n_stages][12] or NULL (zero state / not wanted); the handle's carried state is
+ * not touched; n up to 32 Ki samples (read and written in place in page-locked memory). */
+int frt_decimate_multiple_state(frt_octbank* h, int n_stages, const double* x, int n, const double* zi, double* out, int* n_out,
+                                double* zf);
 /* lfilter_float64_1D (friture/signal/lfilter.py:85-147): direct form II transposed IIR of one host
  * signal with explicit state; len(b) = len(a) = n_coef <= 16, zi/zf hold n_coef-1 doubles. */
 int frt_lfilter_f64(const double* b, const double* a, int n_coef, const double* x, int n, const double* zi,

@@ -61,6 +61,34 @@ def test_decimate_multiple_against_golden(golden, tabs):
     assert e.size == 0 and z is None
 
 
+def test_decimate_multiple_in_place_call_equals_the_staged_one(tabs):
+    """decimate_multiple with explicit states: the one-call in-place path (frt_decimate_multiple_state, up to 30000 samples)
+    and the staged path (set_state / frt_decimate_multiple / get_state, longer inputs) are the same sequential recurrence:
+    a long signal through the staged path equals its ragged pieces through the in-place one, samples and final states bit
+    for bit, for 1..4 chained stages, with and without states, and against the oracle."""
+    from friture_amd.signal import decimate as D
+    rng = np.random.default_rng(11)
+    x = 0.3 * rng.standard_normal(70001)
+    for ndec in (1, 2, 4):
+        whole, zw = D.decimate_multiple(ndec, tabs["bdec"], tabs["adec"], x, D.decimate_multiple_filtic(ndec, tabs["bdec"], tabs["adec"]))
+        ref, zr = dsp.decimate_multiple(ndec, tabs["bdec"], tabs["adec"], x, dsp.decimate_multiple_filtic(ndec, tabs["bdec"], tabs["adec"]))
+        assert np.array_equal(whole, ref) and all(np.array_equal(a, b) for a, b in zip(zw, zr))
+        # pieces whose lengths keep every stage's take-every-other phase aligned (multiples of 2^ndec), then a ragged tail
+        zs = D.decimate_multiple_filtic(ndec, tabs["bdec"], tabs["adec"])
+        parts, pos = [], 0
+        for n in (512, 16 * 1024, 30000 - 30000 % 16, 48, 16):
+            y, zs = D.decimate_multiple(ndec, tabs["bdec"], tabs["adec"], x[pos:pos + n], zs)
+            parts.append(y)
+            pos += n
+        y, zs = D.decimate_multiple(ndec, tabs["bdec"], tabs["adec"], x[pos:], zs)      # 22000-odd samples, odd length
+        parts.append(y)
+        assert np.array_equal(np.concatenate(parts), whole)
+        assert all(np.array_equal(a, b) for a, b in zip(zs, zw))
+    y0, z0 = D.decimate_multiple(2, tabs["bdec"], tabs["adec"], x[:777], None)           # zero state, none returned
+    r0, _ = dsp.decimate_multiple(2, tabs["bdec"], tabs["adec"], x[:777], dsp.decimate_multiple_filtic(2, tabs["bdec"], tabs["adec"]))
+    assert z0 is None and np.array_equal(y0, r0)
+
+
 @pytest.mark.parametrize("bpo", [1, 3, 6, 12, 24])
 def test_iir_bank_against_golden(golden, tabs, bpo):
     from friture_amd import filter as F
