@@ -1057,6 +1057,10 @@ extern "C" int frt_gcc_create(frt_gcc** out, int length, int n_pairs) {
     h->n_pairs = n_pairs;
     int R = 1;
     while (h->M / R > kGccMaxM2 && R < kGccMaxR && h->M % (2 * R) == 0) R *= 2;
+    if (const char* fr = getenv("FRT_GCC_FORCE_R")) {           // experiments: a deeper split than LDS requires
+        const int want = atoi(fr);
+        while (R < want && R < kGccMaxR && h->M % (2 * R) == 0) R *= 2;
+    }
     h->R = R;
     h->M2 = h->M / R;
     // numpy.hanning(L) = 0.5 - 0.5 cos(2 pi n / (L - 1))
