@@ -1557,6 +1557,15 @@ static int filter_host(frt_octbank* h, const double* x, int n, double* y_packed,
     if (!h->gstream) FRT_HIP_CHECK(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
     FRT_HIP_CHECK(hipStreamSynchronize(h->stream));        // order after earlier work on the caller's stream
     memcpy(h->pin_in, x, in_bytes);
+    const bool no_chunk = getenv("FRT_OLA_NO_CHUNK_KERNELS") != nullptr;       // A/B and tests: the transform path
+    if (h->mode == 1 && n <= 1024 && in_bytes <= kZeroCopyMax && out_bytes <= kZeroCopyMax && !no_chunk) {
+        // the production bank's block (Octave_Filters.filter): running convolutions, two launches, samples read and band
+        // signals written in place in the page-locked blocks (ola.hip, chunk path) instead of nine transform launches
+        if ((rc = frt_ola_chunk_filter(h, (const double*)h->pin_in, n, (double*)h->pin_out, plen))) return rc;
+        FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
+        memcpy(y_packed, h->pin_out, out_bytes);
+        return FRT_OK;
+    }
 
     frt_octbank::StreamGraph* g = nullptr;
     for (auto& e : h->graphs)

@@ -89,5 +89,7 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
 // one chunk of 1..1024 samples = one energy block (the octave-spectrum widget's handler): the smoothed band energies of
 // x [C][n] (device-accessible memory: HBM or pinned host) straight to `out` [C][nbands] (float when out_f32; device-accessible),
 // two launches; decay_n / smooth / weight_db: the handle's device tables (weight_db nullable)
+// ... and the band signals of such a block: x [C][n] float64, y packed [C][y_cstride], both device accessible
+int frt_ola_chunk_filter(frt_octbank* h, const double* x, int n, double* y, int64_t y_cstride);
 int frt_ola_chunk_energies(frt_octbank* h, const void* x, int x_f32, int n, const double* alphas, const double* d_decay_n,
                            double* d_smooth, const double* d_weight_db, int as_db, void* out, int out_f32);

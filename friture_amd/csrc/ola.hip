@@ -739,6 +739,8 @@ struct OlaChunkArgs {
     int as_db;
     void* out;                 // [C][nbands]
     int out_f32;
+    double* y;                 // band signals, packed per channel (band k after band k - 1), or null
+    long long y_cstride;
 };
 
 typedef const double __attribute__((address_space(4))) * oc_ktable;
@@ -901,18 +903,27 @@ __global__ void __launch_bounds__(kOcThreads) ola_chunk_band_kernel(const OlaChu
         double y[2];
         oc_fir_pair<true>(xpad, t, h, k0, k1, y[0], y[1]);
         if (v < np) {
-            const double* w = a.ewt + (is_dec ? 0 : a.ewt_off[band]);
+            const bool energy = !is_dec && a.ewt != nullptr;
+            const double* w = energy ? a.ewt + a.ewt_off[band] : nullptr;
+            // a channel's packed row holds band k after band k - 1, bands of the lowest-rate stage first (filter.py:239-245)
+            double* yrow = nullptr;
+            if (a.y && !is_dec) {
+                long long off = (long long)f * m;
+                for (int jj = j + 1; jj < kNOctave; ++jj) off += (long long)a.bpo * a.len[jj];
+                yrow = a.y + (long long)c * a.y_cstride + off;
+            }
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int tt = t + r;
                 const double val = y[r] + pend[tt < kTail ? tt : kTail];
                 if (tt < m) {
-                    if (!is_dec) e = __builtin_fma(w[tt], val * val, e);
+                    if (energy) e = __builtin_fma(w[tt], val * val, e);
+                    if (yrow) yrow[tt] = val;
                 } else if (tt < m + kTail) pend_g[tt - m] = val;
             }
         }
     }
-    if (is_dec) return;                                    // uniform
+    if (is_dec || a.ewt == nullptr) return;                // uniform
     // the block's energy: lanes, then wavefronts, in a fixed order
     for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o, 64);
     if (lane == 0) red[wave] = e;
@@ -965,6 +976,40 @@ int frt_ola_chunk_energies(frt_octbank* h, const void* x, int x_f32, int n, cons
     a.as_db = as_db;
     a.out = out;
     a.out_f32 = out_f32;
+    hipLaunchKernelGGL(ola_chunk_dec_kernel, dim3(h->n_channels), dim3(kOcThreads), 0, h->stream, a);
+    hipLaunchKernelGGL(ola_chunk_band_kernel, dim3(kNOctave * h->bpo + kNOctave - 1, h->n_channels), dim3(kOcThreads), 0, h->stream, a);
+    FRT_HIP_CHECK(hipGetLastError());
+    return FRT_OK;
+}
+
+// The same two launches for a call that wants the band SIGNALS of one block of 1..1024 samples (Octave_Filters.filter,
+// octavefilters.py:49-58): x [C][n] float64 and y packed [C][y_cstride], both device accessible.
+int frt_ola_chunk_filter(frt_octbank* h, const double* x, int n, double* y, int64_t y_cstride) {
+    frt_ola_state* o = h->ola;
+    FRT_REQUIRE(n >= 1 && n <= kOcMaxN, "frt_ola_chunk_filter: n %d not in [1, %d]", n, kOcMaxN);
+    int rc;
+    if (!o->taps.ptr && (rc = upload(o->taps, o->h_taps))) return rc;
+    OlaChunkArgs a{};
+    a.x = x;
+    a.x_f32 = 0;
+    a.x_stride = n;
+    int total = 0;
+    for (int j = 0, m = n; j < kNOctave; ++j, m = (m + 1) / 2) {
+        a.len[j] = m;
+        a.xoff[j] = total;
+        total += (m + 1) & ~1;
+    }
+    a.xs_stride = total;
+    if ((rc = o->xs.reserve((size_t)h->n_channels * total * sizeof(double)))) return rc;
+    a.xs = o->xs.as<double>();
+    a.taps = o->taps.as<double>();
+    a.pending = o->pending.as<double>();
+    a.nfilt = h->nfilt;
+    a.bpo = h->bpo;
+    a.n_channels = h->n_channels;
+    a.nbands = h->nbands;
+    a.y = y;
+    a.y_cstride = y_cstride;
     hipLaunchKernelGGL(ola_chunk_dec_kernel, dim3(h->n_channels), dim3(kOcThreads), 0, h->stream, a);
     hipLaunchKernelGGL(ola_chunk_band_kernel, dim3(kNOctave * h->bpo + kNOctave - 1, h->n_channels), dim3(kOcThreads), 0, h->stream, a);
     FRT_HIP_CHECK(hipGetLastError());

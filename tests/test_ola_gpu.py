@@ -223,3 +223,31 @@ def test_chunk_energies_device_pointers_and_db(hip):
         dev = b.energies(torch.from_numpy(chunk).cuda(), 512, alphas, weight_db=w, as_db=True)
         torch.cuda.synchronize()
         assert np.array_equal(host, dev.cpu().numpy())
+
+
+@pytest.mark.parametrize("bpo", [3, 24])
+def test_chunk_filter_equals_transform_path(hip, bpo, monkeypatch):
+    """Octave_Filters.filter on one block: the running-convolution launches (default for blocks of up to 1024 samples) against
+    the per-stage transform launches (FRT_OLA_NO_CHUNK_KERNELS) — the same sums in another order: 1e-12 of each band's scale,
+    equal shapes and decimation factors, tails shared when the two alternate, two channels' worth of state kept apart."""
+    from friture_amd.octavefilters import Octave_Filters
+    a, b, mixed = Octave_Filters(bpo), Octave_Filters(bpo), Octave_Filters(bpo)
+    x = synth("noise", 9000, 21).astype(np.float64)
+    pos = 0
+    for i, n in enumerate((512, 512, 1, 1024, 333, 7, 512, 1023, 640, 2, 512)):
+        chunk = x[pos:pos + n]
+        pos += n
+        ya, da = a.filter(chunk)
+        monkeypatch.setenv("FRT_OLA_NO_CHUNK_KERNELS", "1")
+        yb, db = b.filter(chunk)
+        if i % 2:
+            ym, _ = mixed.filter(chunk)
+        monkeypatch.delenv("FRT_OLA_NO_CHUNK_KERNELS")
+        if not i % 2:
+            ym, _ = mixed.filter(chunk)
+        assert da == db and len(ya) == len(yb) == 9 * bpo
+        for k in range(9 * bpo):
+            assert ya[k].shape == yb[k].shape
+            scale = max(np.max(np.abs(yb[k])), 1e-3)
+            assert np.max(np.abs(ya[k] - yb[k])) <= 1e-12 * scale, (bpo, n, k)
+            assert np.max(np.abs(ym[k] - yb[k])) <= 1e-12 * scale, (bpo, n, k)
