@@ -15,11 +15,15 @@ __global__ void __launch_bounds__(NT) k(const double* in, double* out, const dou
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cpx<double>* buf = (cpx<double>*)smem;
     const int tid = threadIdx.x;
+    cpx<double>* twl = buf + N;                        // MODE 2: the plan's tables copied to LDS
+    if (MODE == 2)
+        for (int i = tid; i < 666; i += NT) twl[i] = ((const cpx<double>*)tw)[i];
     for (int i = tid; i < N; i += NT) buf[i] = {in[2 * i], in[2 * i + 1]};
     __syncthreads();
     for (int it = 0; it < iters; ++it) {
         if (MODE == 0) fft_mixed_forward<double, 3>(buf, (const cpx<double>*)tw, plan, tid, NT);
-        else static_fft_forward<double, NT, 6, 10, 10, 10>(buf, (const cpx<double>*)tw, tid);
+        else if (MODE == 1) static_fft_forward<double, NT, 6, 10, 10, 10>(buf, (const cpx<double>*)tw, tid);
+        else static_fft_forward<double, NT, 6, 10, 10, 10>(buf, twl, tid);
         if (it + 1 < iters) {
             for (int i = tid; i < N; i += NT) buf[i] = {buf[i].x * (1.0 / 77.0), buf[i].y * (1.0 / 77.0)};
             __syncthreads();
@@ -42,9 +46,10 @@ int main() {
     CK(hipMemcpy(din, h.data(), h.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dtwm, twm.data(), twm.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dtws, tws.data(), tws.size() * 8, hipMemcpyHostToDevice));
-    const size_t lds = (size_t)N * 16;
+    const size_t lds = (size_t)(N + 672) * 16;
     CK(hipFuncSetAttribute((const void*)k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipFuncSetAttribute((const void*)k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void*)k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     std::vector<double> r0(2 * N), r1(2 * N);
     hipLaunchKernelGGL(k<0>, dim3(1), dim3(NT), lds, 0, din, dout, dtwm, plan, 1);
     CK(hipMemcpy(r0.data(), dout, r0.size() * 8, hipMemcpyDeviceToHost));
@@ -65,16 +70,17 @@ int main() {
     printf("max |X| %.3e   mixed vs static %.3e   static vs direct DFT (7 bins) %.3e\n", maxref, e01, eref);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int grid : {1, 256}) {
-        for (int mode = 0; mode < 2; ++mode) {
+        for (int mode = 0; mode < 3; ++mode) {
             const int iters = 200;
             for (int rep = 0; rep < 2; ++rep) {
                 CK(hipEventRecord(e0, 0));
                 if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(NT), lds, 0, din, dout, dtwm, plan, iters);
-                else hipLaunchKernelGGL(k<1>, dim3(grid), dim3(NT), lds, 0, din, dout, dtws, plan, iters);
+                else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(NT), lds, 0, din, dout, dtws, plan, iters);
+                else hipLaunchKernelGGL(k<2>, dim3(grid), dim3(NT), lds, 0, din, dout, dtws, plan, iters);
                 CK(hipEventRecord(e1, 0));
                 CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-                if (rep) printf("grid %3d  %s  %.2f us per transform\n", grid, mode ? "static 6x10x10x10" : "mixed  4,4,5,5,5,3 ", ms * 1e3 / iters);
+                if (rep) printf("grid %3d  %s  %.2f us per transform\n", grid, mode == 2 ? "static, tables in LDS" : mode ? "static 6x10x10x10   " : "mixed  4,4,5,5,5,3  ", ms * 1e3 / iters);
             }
         }
     }
