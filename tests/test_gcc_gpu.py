@@ -191,6 +191,44 @@ def test_configs4_full_size_properties(hip):
         assert np.max(np.abs(x01n[w] - ref)) <= 1e-9 * np.max(np.abs(ref))
 
 
+def test_gcc_large_batch_one_workgroup_per_pair(hip):
+    """300 window pairs of L = 24000: above 160 pairs the default dispatch is the one-workgroup kernel (compile-time
+    6000-point plan, cross spectrum in registers, last sub-spectrum and packed inverse input in LDS).  Every window finds the
+    delay, the means it reports are the windows' means, sampled windows (first, one inside, last — the last workgroup of the
+    grid) equal the oracle to 1e-9, a window with a large DC offset included, and unaligned windows (views at an odd sample
+    offset, as a ring hands them out) give the same correlation as their aligned copies."""
+    import torch
+    from friture_amd.signal.correlation import GccPhat
+    L, pairs, lag = 24000, 300, 23
+    rng = np.random.default_rng(77)
+    d0 = 0.25 * rng.standard_normal((pairs, L))
+    d1 = np.roll(d0, lag, axis=1) + 0.02 * rng.standard_normal((pairs, L))
+    d0[150] += 3.0                                              # DC offsets: the means matter
+    d1[150] -= 1.5
+    g = GccPhat(L, pairs)
+    a0, a1 = torch.from_numpy(d0).cuda(), torch.from_numpy(d1).cuda()
+    x, am = g.correlate(a0, a1)
+    torch.cuda.synchronize()
+    assert bool((am == lag).all())
+    means = g.means.cpu().numpy()
+    assert np.max(np.abs(means[:, 0] - d0.mean(axis=1))) <= 1e-14 and np.max(np.abs(means[:, 1] - d1.mean(axis=1))) <= 1e-14
+    xn = x.cpu().numpy()
+    for w in (0, 150, 299):
+        ref, _, _ = dsp.gcc_phat(d0[w].copy(), d1[w].copy())
+        assert np.max(np.abs(xn[w] - ref)) <= 1e-9 * np.max(np.abs(ref)), w
+    # the same windows at an 8-byte (not 16-byte) aligned address: one pair, views into a longer buffer
+    g1 = GccPhat(L, 1)
+    buf0 = torch.zeros(L + 1, dtype=torch.float64, device="cuda")
+    buf1 = torch.zeros(L + 1, dtype=torch.float64, device="cuda")
+    buf0[1:] = a0[7]
+    buf1[1:] = a1[7]
+    xu, amu = g1.correlate(buf0[1:][None, :], buf1[1:][None, :])
+    xa, ama = g1.correlate(a0[7:8].clone(), a1[7:8].clone())
+    torch.cuda.synchronize()
+    assert int(amu[0]) == int(ama[0]) == lag
+    assert np.max(np.abs(xu.cpu().numpy() - xa.cpu().numpy())) <= 1e-12 * np.max(np.abs(xn[7]))
+
+
 def test_delay_estimator_stream_equals_host_chain(hip):
     """DelayEstimatorStream (decimator states, 12 kHz rings, windows, correlation and read-out resident in HBM) against
     DelayEstimator (host rings, every stage a host-staged call): the same read-out chunk after chunk — including the ring
