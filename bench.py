@@ -63,11 +63,13 @@ def synth_channel(channel: int, n: int) -> np.ndarray:
 
 
 def kernel_source_digest() -> str:
-    """Digest of the K1 kernel sources — their code, i.e. with comments and blank lines removed: a PMC traffic figure is
-    only quoted for the code it was measured on (rewording a comment does not un-measure it)."""
+    """Digest of the sources of the headline kernel (stft_kernel, N <= 1024: stft.hip + fft_core.h; stft_big.h only defines the
+    N >= 2048 instances) — their code, i.e. with comments and blank lines removed: a PMC traffic figure is only quoted for the
+    code it was measured on (rewording a comment does not un-measure it).  tests/test_evidence_fresh.py fails while
+    profiles/pmc_traffic.json carries another digest."""
     import re
     h = hashlib.sha256()
-    for name in ("stft.hip", "stft_big.h", "fft_core.h"):
+    for name in ("stft.hip", "fft_core.h"):
         text = (ROOT / "friture_amd" / "csrc" / name).read_text()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         lines = [re.sub(r"//[^\n]*", "", ln).rstrip() for ln in text.splitlines()]
@@ -75,7 +77,7 @@ def kernel_source_digest() -> str:
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(x: np.ndarray, n_fft: int, hop: int, weight, lut, budget_s: float):
+def cpu_baseline(x: np.ndarray, n_fft: int, hop: int, weight, lut, budget_s: float, with_legs: bool = True):
     """Oracle timed on the host over a bounded sample of the same channel: on one core (about 60 % of
     budget_s seconds of CPU work: a prefix of the channel, repeated when the whole channel is shorter),
     then on every core at once (a pool of spawned workers, each running the same prefix)."""
@@ -102,7 +104,27 @@ def cpu_baseline(x: np.ndarray, n_fft: int, hop: int, weight, lut, budget_s: flo
                         f"present on this box, hence kind = port; the restatement is the faster of the two (no per-frame Python "
                         f"object overhead), so this baseline is conservative",
               "host_cpus": os.cpu_count()}
-    # every core: one spawned worker per core (workers import numpy + the oracle only, never the GPU runtime)
+    # every core: one spawned worker per core (workers import numpy + the oracle only, never the GPU runtime); the same pool
+    # then times the other halves of the metric — the octave banks (both variants, bpo 3 and 24) and GCC-PHAT — whose
+    # one-core figures are taken here in the parent first
+    side = {}
+    sc = min(1.0, budget_s / 12.0)                         # about 4.5 s of one-core work at the default budget
+    nb3, nb24, nwin = max(16, int(1200 * sc)), max(16, int(256 * sc)), max(8, int(256 * sc))
+    side_jobs = {"octave_iir_bpo3": (cpu_bench.octave_blocks, (0, 3, nb3, "iir"), "octave-bands/s"),
+                 "octave_ola_bpo3": (cpu_bench.octave_blocks, (0, 3, nb3, "ola"), "octave-bands/s"),
+                 "octave_iir_bpo24": (cpu_bench.octave_blocks, (0, 24, nb24, "iir"), "octave-bands/s"),
+                 "octave_ola_bpo24": (cpu_bench.octave_blocks, (0, 24, nb24, "ola"), "octave-bands/s"),
+                 "gcc_phat": (cpu_bench.gcc_windows, (4242, 24000, nwin), "windows/s")} if with_legs else {}
+    what = {"iir": "exact IIR bank (friture/filter.py:86-118) through oracle/iir_ref.c", "ola": "FFT overlap-add bank "
+            "(friture/octavefilters.py:49-58) in numpy"}
+    for name, (fn, job, unit) in side_jobs.items():
+        t0 = time.perf_counter()
+        units, _ = fn(job)
+        dt1 = time.perf_counter() - t0
+        sample = (f"{job[2]} blocks of 1024 samples of one channel, bpo {job[1]}: {what[job[3]]} + smoothed band energies + dB per block, {dt1:.2f} s"
+                  if fn is cpu_bench.octave_blocks else
+                  f"{job[2]} window pairs of L = {job[1]} (numpy rfft/irfft float64, friture/signal/correlation.py:24-43) + arg-max, {dt1:.2f} s")
+        side[name] = {"value": units / dt1, "unit": unit, "cores": 1, "kind": "port", "sample": sample}
     try:
         import multiprocessing as mp
         from concurrent.futures import ProcessPoolExecutor
@@ -116,10 +138,18 @@ def cpu_baseline(x: np.ndarray, n_fft: int, hop: int, weight, lut, budget_s: flo
             t0 = time.perf_counter()
             done = list(pool.map(cpu_bench.spectrogram_passes, [job] * cores))
             wall = time.perf_counter() - t0
-        result["all_cores"] = {"value": sum(d[0] for d in done) / wall, "unit": "spectra/s", "cores": cores,
-                               "sample": f"{cores} worker processes x {wframes} spectra of the same prefix, {wall:.1f} s"}
+            result["all_cores"] = {"value": sum(d[0] for d in done) / wall, "unit": "spectra/s", "cores": cores,
+                                   "sample": f"{cores} worker processes x {wframes} spectra of the same prefix, {wall:.1f} s"}
+            for name, (fn, sjob, unit) in side_jobs.items():
+                sjob = (sjob[0], sjob[1], max(8, sjob[2] // 4), *sjob[3:])
+                t0 = time.perf_counter()
+                done = list(pool.map(fn, [sjob] * cores))
+                wall = time.perf_counter() - t0
+                side[name]["all_cores"] = {"value": sum(d[0] for d in done) / wall, "unit": unit, "cores": cores,
+                                           "sample": f"{cores} worker processes x {sjob[2]} of the same units each, {wall:.2f} s"}
     except Exception as exc:                                                     # a reported extra, never fatal
-        result["all_cores"] = {"error": repr(exc)}
+        result.setdefault("all_cores", {"error": repr(exc)})
+    result["_side"] = side
     return result
 
 
@@ -604,8 +634,19 @@ def main():
         if legs:
             result["legs"] = legs
             result["octave_bands"] = legs.get("configs2_bank_iir_time_parallel")      # the metric's second half, as in round 1
-        if world == 1 and args.cpu_budget > 0 and not stub:
-            result["cpu_baseline"] = cpu_baseline(host_x[0], n_fft, hop, consts["weight"], consts["lut"], args.cpu_budget)
+        if args.cpu_budget > 0:
+            # rank 0 only, whatever the world size (after the timed region; the other ranks wait at the final barrier)
+            base = cpu_baseline(host_x[0], n_fft, hop, consts["weight"], consts["lut"], args.cpu_budget, with_legs=bool(legs) or stub)
+            side = base.pop("_side")
+            result["cpu_baseline"] = base
+            for leg_name, side_name in (("configs2_bank_iir_time_parallel", "octave_iir_bpo3"), ("configs2_bank_iir_sequential", "octave_iir_bpo3"),
+                                        ("configs2_bank_fir_overlap_add", "octave_ola_bpo3"), ("configs4_bank_iir_time_parallel", "octave_iir_bpo24"),
+                                        ("configs4_bank_fir_overlap_add", "octave_ola_bpo24"), ("configs4_gcc_phat", "gcc_phat"),
+                                        ("configs4_gcc_phat_1024_pairs", "gcc_phat")):
+                if leg_name in legs and side_name in side:
+                    legs[leg_name]["cpu_baseline"] = side[side_name]
+            if stub:
+                result["cpu_baseline_legs"] = side
         print(json.dumps(result), flush=True)
         gates = [result.get("parity", {}).get("gate", {}).get("pass", True)]
         gates += [lg.get("parity", {}).get("gate", {}).get("pass", True) for lg in legs.values() if isinstance(lg, dict)]

@@ -66,4 +66,10 @@ class Octave:
         return 2 ** logs
 
 
-ALL = [Linear, Logarithmic, Mel, Erb, Octave]
+class OctaveC(Octave):
+    """The log2 axis whose major ticks sit on the C of every octave (friture/plotting/frequency_scales.py:225-237): same
+    transform pair as `Octave`, its own scale name."""
+    NAME = 'OctaveC'
+
+
+ALL = [Linear, Logarithmic, Mel, Erb, Octave, OctaveC]

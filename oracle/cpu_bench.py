@@ -39,3 +39,46 @@ def wait_ready(_):
     do not include interpreter start-up of late workers)."""
     _barrier.wait(timeout=120)
     return True
+
+
+def octave_blocks(args):
+    """One channel of bench.py's bank legs through the oracle, block by block as the widget feeds it
+    (friture/octavespectrum.py:91-122): `blocks` blocks of 1024 samples -> bank -> smoothed band energies -> dB.
+    mode "iir": the exact bank (friture/filter.py:86-118) through oracle/iir_ref.c; "ola": the production FFT
+    overlap-add bank (friture/octavefilters.py:49-58).  Returns (octave-band units, digest)."""
+    channel, bpo, blocks, mode = args
+    from oracle import dsp
+    t = dsp.load_filter_tables()
+    x = synth_prefix(1000 + channel, 1024 * blocks).astype(np.float64)
+    alphas, kernels = dsp.band_smoothing_setup(bpo, 1.0)
+    prev = [0.0] * (9 * bpo)
+    if mode == "iir":
+        boct, aoct = list(t[f"boct_{bpo}"]), list(t[f"aoct_{bpo}"])
+        zis = dsp.iir_bank_filtic(t["bdec"], t["adec"], boct, aoct)
+    else:
+        bank = dsp.OlaBank(bpo, t)
+    digest = 0.0
+    for b in range(blocks):
+        blk = x[1024 * b: 1024 * (b + 1)]
+        if mode == "iir":
+            y, _dec, zis = dsp.iir_bank(t["bdec"], t["adec"], boct, aoct, blk, zis)
+        else:
+            y, _dec = bank.filter(blk)
+        prev = dsp.band_energies(y, kernels, alphas, prev)
+        digest += float(dsp.band_db(prev).sum())
+    return blocks * 9 * bpo, digest
+
+
+def gcc_windows(args):
+    """`windows` GCC-PHAT window pairs of L samples (friture/signal/correlation.py:24-43) + arg-max, as bench.py's
+    gcc_leg synthesises them (delay 37).  Returns (windows, number of windows whose arg-max is 37)."""
+    seed, L, windows = args
+    from oracle import dsp
+    rng = np.random.default_rng(seed)
+    hits = 0
+    for _ in range(windows):
+        d0 = 0.25 * rng.standard_normal(L)
+        d1 = np.roll(d0, 37) + 0.025 * rng.standard_normal(L)
+        xc, _, _ = dsp.gcc_phat(d0, d1)
+        hits += int(np.argmax(np.abs(xc)) == 37)
+    return windows, hits

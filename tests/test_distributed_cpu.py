@@ -76,7 +76,7 @@ def test_bench_rank_logic_two_ranks_gloo():
     root = Path(__file__).resolve().parents[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--stub-engine", "--log2-samples", "14", "--batches", "2"]
+           "--stub-engine", "--log2-samples", "14", "--batches", "2", "--cpu-budget", "1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(root))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -93,6 +93,14 @@ def test_bench_rank_logic_two_ranks_gloo():
     want = sum(float(np.int32(1000 * (0.25 * np.random.default_rng(42 + c).standard_normal(2 ** 14, dtype=np.float32))[0]))
                for c in range(2))
     assert abs(rec["digest"] - want) < 1e-6
+    # the CPU baseline is emitted by rank 0 at every world size: spectrogram, both banks, GCC-PHAT —
+    # one core and every core, each naming its sample
+    cb = rec["cpu_baseline"]
+    assert cb["cores"] == 1 and cb["kind"] == "port" and cb["value"] > 0 and cb["all_cores"]["cores"] >= 1 and cb["all_cores"]["value"] > 0
+    side = rec["cpu_baseline_legs"]
+    assert set(side) == {"octave_iir_bpo3", "octave_ola_bpo3", "octave_iir_bpo24", "octave_ola_bpo24", "gcc_phat"}
+    for v in side.values():
+        assert v["value"] > 0 and v["cores"] == 1 and v["all_cores"]["value"] > 0 and v["sample"]
 
 
 def test_bench_two_ranks_gloo_with_slab_gather():
@@ -106,7 +114,7 @@ def test_bench_two_ranks_gloo_with_slab_gather():
     root = Path(__file__).resolve().parents[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-           "--stub-engine", "--log2-samples", "14", "--batches", "2", "--gather-slabs"]
+           "--stub-engine", "--log2-samples", "14", "--batches", "2", "--gather-slabs", "--cpu-budget", "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(root))
     assert r.returncode == 0, r.stderr[-2000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
@@ -161,7 +169,7 @@ def test_bench_stub_single_process():
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
-    r = subprocess.run([sys.executable, str(root / "bench.py"), "--stub-engine", "--log2-samples", "13", "--steps", "2", "--warmup", "1"],
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--stub-engine", "--log2-samples", "13", "--steps", "2", "--warmup", "1", "--cpu-budget", "0"],
                        capture_output=True, text=True, timeout=300, cwd=str(root))
     assert r.returncode == 0, r.stderr[-2000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])

@@ -83,3 +83,15 @@ def test_time_resampler_bookkeeping_matches_oracle():
             assert total == want_total and list(src) == want_src
             assert np.array_equal(a, np.array(want_a, np.float64))
             assert mine.orig_index == ref.orig_index and mine.resampled_index == ref.resampled_index
+
+
+def test_frequency_scale_names_cover_the_reference_list():
+    """friture/plotting/frequency_scales.py:65-293 defines Linear, Logarithmic, Mel, ERB, Octave and OctaveC; OctaveC is the
+    Octave transform pair under its own name (:225-237)."""
+    from friture_amd.plotting import frequency_scales as fs
+    from oracle import dsp
+    assert [s.NAME for s in fs.ALL] == ["Linear", "Logarithmic", "Mel", "ERB", "Octave", "OctaveC"]
+    f = np.array([0.0, 20.0, 440.0, 20000.0])
+    assert np.array_equal(fs.OctaveC.transform(f), fs.Octave.transform(f)) and np.array_equal(fs.OctaveC.inverse(f[1:] / 1e3), fs.Octave.inverse(f[1:] / 1e3))
+    want = dsp.frequency_targets("octave", 20.0, 20000.0, 37)
+    assert np.array_equal(fs.OctaveC.inverse(np.linspace(fs.OctaveC.transform(20.0), fs.OctaveC.transform(20000.0), 37)), want)
