@@ -36,12 +36,15 @@ void set_last_error(const char* fmt, ...);
 // true when `p` points to device (or managed) memory usable by kernels directly.
 bool is_device_pointer(const void* p);
 
-// Allocations a growing DeviceBuffer has replaced.  Freeing synchronises the device (hipFree does, and kernels enqueued
-// on a caller's non-blocking stream may still use the old block), which is neither legal while a stream of this thread
-// is capturing nor wanted then: inside a capture region (CaptureScope) the old block is parked here and freed by the next
-// growth outside of one, or when a handle is destroyed.
-void retire_allocation(void* p);
-void free_retired_allocations();
+// Allocations a growing DeviceBuffer has replaced.  Kernels enqueued on a caller's non-blocking stream may still use the old
+// block, and hipFree synchronises the whole device (not legal at all while a stream of this thread is capturing): the old
+// block is PARKED here instead — no synchronisation on growth.  Parked blocks are released together, behind one device
+// synchronisation, once more than kRetiredLimit bytes (or 64 blocks) are parked and the calling thread is not capturing,
+// and by frt_release_retired() (handle destruction calls it).  Buffers grow geometrically, so the parked total stays
+// below twice the live total.
+void retire_allocation(void* p, size_t bytes);
+void free_retired_allocations(bool force);
+constexpr size_t kRetiredLimit = (size_t)1 << 30;
 struct CaptureScope {                       // marks the calling thread as capturing a stream for its lifetime
     CaptureScope();
     ~CaptureScope();
@@ -55,14 +58,9 @@ struct DeviceBuffer {
     int reserve(size_t n) {
         if (n <= bytes) return FRT_OK;
         if (ptr) {
-            if (CaptureScope::active()) {
-                retire_allocation(ptr);
-            } else {
-                // growing: kernels enqueued on a caller's (non-blocking) stream may still use the old allocation
-                (void)hipDeviceSynchronize();
-                (void)hipFree(ptr);
-                free_retired_allocations();
-            }
+            retire_allocation(ptr, bytes);
+            if (n < bytes + bytes / 2) n = bytes + bytes / 2;      // geometric growth bounds what gets parked
+            if (!CaptureScope::active()) free_retired_allocations(false);
         }
         ptr = nullptr;
         bytes = 0;

@@ -1039,6 +1039,7 @@ struct frt_gcc {
 
 extern "C" void frt_gcc_destroy(frt_gcc* h) {
     if (!h) return;
+    free_retired_allocations(true);      // blocks parked by growing buffers (common.h); synchronises the device like the releases below
     DeviceBuffer* bufs[] = {&h->window, &h->twm, &h->tw2, &h->tws, &h->twl, &h->scratch, &h->in0, &h->in1,
                             &h->out, &h->argmax, &h->means, &h->old, &h->sm, &h->stats,
                             &h->chirp, &h->bhat, &h->work, &h->spec, &h->twr, &h->twc, &h->gmax, &h->part_val, &h->part_idx, &h->prof};

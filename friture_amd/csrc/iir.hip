@@ -1174,6 +1174,7 @@ extern "C" int frt_octbank_create(frt_octbank** out, int bands_per_octave, int n
 
 extern "C" void frt_octbank_destroy(frt_octbank* h) {
     if (!h) return;
+    free_retired_allocations(true);      // blocks parked by growing buffers (common.h); synchronises the device like the releases below
     for (auto& e : h->graphs)
         if (e.exec) (void)hipGraphExecDestroy(e.exec);
     if (h->gstream) (void)hipStreamDestroy(h->gstream);
@@ -1905,45 +1906,38 @@ extern "C" int frt_lfilter_f64(const double* b, const double* a, int n_coef, con
         coef[kMaxOrder + 1 + t] = a[t];
     }
     for (int s = 0; s < order; ++s) st[s] = zi[s];
-    // device scratch of this entry point: grow-only, kept per calling thread (the call is synchronous and stateless; the
-    // five buffers used to be allocated and freed on every call — two hipMalloc round trips per 512-sample chunk)
-    struct Scratch {
-        DeviceBuffer coef, order, state, x, y;
-        ~Scratch() { coef.release(); order.release(); state.release(); x.release(); y.release(); }
-    };
-    static thread_local Scratch scratch;
-    DeviceBuffer &dcoef = scratch.coef, &dorder = scratch.order, &dstate = scratch.state, &dx = scratch.x, &dy = scratch.y;
+    // Arguments travel through the process-level staging arena (StageCall, common.h): one pinned block, one asynchronous
+    // upload and download on its stream — or none at all for widget-sized calls, which the kernel serves in place from
+    // page-locked memory.  (Rounds 2-3 kept five grow-only buffers per calling THREAD: their destructor ran hipFree at
+    // thread / process exit, possibly after the runtime's own teardown, and the copies were blocking null-stream ones.)
     std::vector<int> ord(1, order);
-    int rc;
-    auto cleanup = [&]() {};
-    if ((rc = upload(dcoef, coef)) || (rc = upload(dorder, ord)) || (rc = upload(dstate, st)) ||
-        (rc = dx.reserve((size_t)n * sizeof(double))) || (rc = dy.reserve((size_t)n * sizeof(double)))) {
-        return rc;
-    }
-    hipError_t e = hipMemcpy(dx.ptr, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+    StageCall sc;
+    const int icoef = sc.add_in(coef.data(), coef.size() * sizeof(double));
+    const int iord = sc.add_in(ord.data(), sizeof(int));
+    const int ist0 = sc.add_in(st.data(), kStates * sizeof(double));
+    const int ix = sc.add_in(x, (size_t)n * sizeof(double));
+    const int iy = sc.add_out(y, (size_t)n * sizeof(double));
+    const int ist = sc.add_out(st.data(), kStates * sizeof(double));      // the kernel updates its state block in place
+    int rc = sc.begin();
+    if (rc) return rc;
+    FRT_HIP_CHECK(hipMemcpyAsync(sc.ptr<double>(ist), sc.ptr<double>(ist0), kStates * sizeof(double), hipMemcpyDefault, sc.stream()));
     IirStageArgs s{};
-    s.x = dx.ptr;
+    s.x = sc.ptr<double>(ix);
     s.x_stride = n;
     s.n = n;
-    s.coef = dcoef.as<double>();
-    s.order = dorder.as<int>();
+    s.coef = sc.ptr<double>(icoef);
+    s.order = sc.ptr<int>(iord);
     s.nfilt = 1;
     s.dec_filter = -1;
-    s.state = dstate.as<double>();
+    s.state = sc.ptr<double>(ist);
     s.chunk = (n + 63) / 64 * 64;
     s.nchunks = 1;
     s.pass = 0;
-    s.y = dy.as<double>();
+    s.y = sc.ptr<double>(iy);
     s.y_cstride = n;
     s.band_index[0] = -1;
-    if (e == hipSuccess && launch_iir_stage(s, &order, 1, nullptr) != FRT_OK) e = hipErrorLaunchFailure;
-    if (e == hipSuccess) e = hipMemcpy(y, dy.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(st.data(), dstate.ptr, kStates * sizeof(double), hipMemcpyDeviceToHost);
-    cleanup();
-    if (e != hipSuccess) {
-        set_last_error("frt_lfilter_f64: %s", hipGetErrorString(e));
-        return FRT_ERR_HIP;
-    }
+    if ((rc = launch_iir_stage(s, &order, 1, sc.stream()))) return rc;
+    if ((rc = sc.finish())) return rc;
     for (int t = 0; t < order; ++t) zf[t] = st[t];
     return FRT_OK;
 }

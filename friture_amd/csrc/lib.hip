@@ -19,20 +19,26 @@ void set_last_error(const char* fmt, ...) {
 namespace {
 std::mutex g_retired_mutex;
 std::vector<void*> g_retired;
+size_t g_retired_bytes = 0;
 thread_local int g_capture_depth = 0;
 }  // namespace
 
-void retire_allocation(void* p) {
+void retire_allocation(void* p, size_t bytes) {
     std::lock_guard<std::mutex> lock(g_retired_mutex);
     g_retired.push_back(p);
+    g_retired_bytes += bytes;
 }
 
-void free_retired_allocations() {
+void free_retired_allocations(bool force) {
     std::vector<void*> mine;
     {
         std::lock_guard<std::mutex> lock(g_retired_mutex);
+        if (!force && g_retired_bytes <= kRetiredLimit && g_retired.size() <= 64) return;
         mine.swap(g_retired);
+        g_retired_bytes = 0;
     }
+    if (mine.empty()) return;
+    (void)hipDeviceSynchronize();              // whatever was enqueued against the parked blocks has run
     for (void* p : mine) (void)hipFree(p);
 }
 

@@ -776,6 +776,7 @@ extern "C" int frt_stft_create(frt_stft** out, int fft_size, int hop, int n_chan
 
 extern "C" void frt_stft_destroy(frt_stft* h) {
     if (!h) return;
+    free_retired_allocations(true);      // blocks parked by growing buffers (common.h); synchronises the device like the releases below
     h->window.release();
     h->tw.release();
     h->twn.release();

@@ -1,0 +1,80 @@
+"""Multi-threaded, multi-handle soak of the C ABI: several threads, each with its own handles, drive the
+stateless staging arena (frt_lfilter_f64 with growing lengths -> arena growth), growing DeviceBuffers (STFT outputs through host
+arrays of increasing size), GCC-PHAT plans and octave banks concurrently; every result is checked against the oracle, handles are
+destroyed from their own threads, and the process must exit cleanly under AMD_LOG_LEVEL=1 — no HIP error at thread or runtime
+teardown (round 3 kept thread_local device buffers whose destructors ran hipFree at exit)."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+WORKER = r'''
+import sys, threading
+sys.path.insert(0, %r)
+import numpy as np
+from friture_amd import _lib, filter_design
+from friture_amd.signal.lfilter import lfilter_float64_1D
+from friture_amd.signal.correlation import generalized_cross_correlation, GccPhat
+from friture_amd.audioproc import audioproc
+from friture_amd.octavefilters import Octave_Filters
+from oracle import dsp
+_lib.init(0)
+t = filter_design.load_tables()
+errors = []
+
+def work(tid):
+    try:
+        rng = np.random.default_rng(100 + tid)
+        ap = audioproc()
+        ap.set_fftsize(1024 << (tid %% 3))
+        bank = Octave_Filters(3 if tid %% 2 else 6)
+        obank = dsp.OlaBank(bank.bandsperoctave)
+        for rep in range(6):
+            n = 257 * (rep + 1) * (tid + 1)                       # growing: arena + scratch growth under concurrency
+            x = rng.standard_normal(n)
+            zi = rng.standard_normal(12) * 1e-3
+            y, zf = lfilter_float64_1D(t["bdec"], t["adec"], x, zi)
+            yr, zr = dsp.lfilter_df2t(t["bdec"], t["adec"], x, zi)
+            assert np.array_equal(y, yr) and np.array_equal(zf, zr), ("lfilter", tid, rep)
+            fr = rng.standard_normal(ap.fft_size)
+            p = ap.analyzelive(fr)
+            pr = dsp.psd_frame(fr, dsp.hann_symmetric(ap.fft_size))
+            assert np.max(np.abs(p - pr)) <= 1e-12 * np.max(pr), ("psd", tid, rep)
+            L = 2400 * (1 + (tid + rep) %% 3)
+            d0 = rng.standard_normal(L); d1 = np.roll(d0, 11) + 0.05 * rng.standard_normal(L)
+            xr, _, _ = dsp.gcc_phat(d0, d1)
+            xc = generalized_cross_correlation(d0.copy(), d1.copy())
+            assert np.argmax(np.abs(xc)) == np.argmax(np.abs(xr)) and np.max(np.abs(xc - xr)) <= 1e-9 * np.max(np.abs(xr)), ("gcc", tid, rep)
+            blk = rng.standard_normal(1024)
+            yb, dec = bank.filter(blk)
+            yo, deco = obank.filter(blk)
+            assert list(dec) == list(deco)
+            assert max(np.max(np.abs(a - b)) for a, b in zip(yb, yo)) <= 1e-9, ("ola", tid, rep)
+            g = GccPhat(2400, 1 + rep)                              # a handle created and destroyed inside the thread
+            del g
+        del ap, bank
+    except BaseException as exc:
+        errors.append(repr(exc))
+
+threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+for th in threads: th.start()
+for th in threads: th.join()
+print("SOAK", "FAILED" if errors else "OK", errors)
+sys.exit(1 if errors else 0)
+'''
+
+
+@pytest.mark.gpu
+def test_threads_and_handles_soak_exits_cleanly_under_amd_log_level_1(tmp_path):
+    script = tmp_path / "soak_worker.py"
+    script.write_text(WORKER % str(ROOT))
+    env = dict(os.environ, AMD_LOG_LEVEL="1")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0 and "SOAK OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    # AMD_LOG_LEVEL=1 prints runtime errors only: none may appear, in particular none from teardown
+    noisy = [ln for ln in r.stderr.splitlines() if ":1:" in ln or "hipError" in ln or "HSA_STATUS_ERROR" in ln]
+    assert not noisy, noisy[:10]
