@@ -63,13 +63,13 @@ def synth_channel(channel: int, n: int) -> np.ndarray:
 
 
 def kernel_source_digest() -> str:
-    """Digest of the sources of the headline kernel (stft_kernel, N <= 1024: stft.hip + fft_core.h; stft_big.h only defines the
-    N >= 2048 instances) — their code, i.e. with comments and blank lines removed: a PMC traffic figure is only quoted for the
-    code it was measured on (rewording a comment does not un-measure it).  tests/test_evidence_fresh.py fails while
-    profiles/pmc_traffic.json carries another digest."""
+    """Digest of the sources of the headline kernel (stft_kernel, N <= 1024: stft_wave.h + fft_core.h; stft.hip holds the host
+    side, stft_big.h / stft_pk.h the N >= 2048 instances) — their code, i.e. with comments and blank lines removed: a PMC
+    traffic figure is only quoted for the code it was measured on (rewording a comment does not un-measure it).
+    tests/test_evidence_fresh.py fails while profiles/pmc_traffic.json carries another digest."""
     import re
     h = hashlib.sha256()
-    for name in ("stft.hip", "fft_core.h"):
+    for name in ("stft_wave.h", "fft_core.h"):
         text = (ROOT / "friture_amd" / "csrc" / name).read_text()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         lines = [re.sub(r"//[^\n]*", "", ln).rstrip() for ln in text.splitlines()]

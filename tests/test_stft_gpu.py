@@ -156,7 +156,7 @@ def test_ring_and_register_window_instances_give_the_same_bits(engine_cls):
     assert e.psd(aligned).shape == (1, frames, n_fft // 2 + 1)
 
 
-@pytest.mark.parametrize("n_fft,hop", [(4096, 1024), (8192, 4096), (16384, 8192)])
+@pytest.mark.parametrize("n_fft,hop", [(4096, 1024), (8192, 4096), (16384, 8192), (16384, 4096)])
 def test_lds_staged_large_frame_instance_is_reproducible(engine_cls, n_fft, hop):
     """The large-frame instances that stage the next frame in LDS wait for the copy with a hand-counted vmcnt: a long
     signal, repeated, must give the same bits every time (a race on the staging buffer would not) and the spectra of the

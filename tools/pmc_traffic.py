@@ -44,7 +44,7 @@ def main():
            "method": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python bench.py --steps 5 --warmup 2 --cpu-budget 0 "
                      "--prewarm-ms 0 --no-legs; mean over the kernel's dispatches; FETCH_SIZE doubled per MI355X_MICROARCH.md",
            "algorithmic_bytes_per_launch": 131071 * 4100,
-           "kernel_sources_note": "digest of the code of stft.hip + fft_core.h (comments and blank lines removed) at the measured "
+           "kernel_sources_note": "digest of the code of stft_wave.h + fft_core.h (comments and blank lines removed) at the measured "
                                   "revision; bench.kernel_source_digest()"}
     (ROOT / "profiles" / "pmc_traffic.json").write_text(json.dumps(rec, indent=1))
     print(json.dumps({k: rec[k] for k in ("hbm_bytes_per_launch", "read_bytes", "write_bytes", "algorithmic_bytes_per_launch", "kernel_sources")}))
