@@ -30,7 +30,10 @@ static int launch_pk(const StftArgs& a, hipStream_t stream) {
     const dim3 grid(a.n_groups), block(PkPlan::BLOCK);
     switch (a.kind) {
         case FRT_STFT_PSD: hipLaunchKernelGGL((stft_pk_kernel<0, HS>), grid, block, 0, stream, a); break;
-        case FRT_STFT_IMAGE: hipLaunchKernelGGL((stft_pk_kernel<3, HS>), grid, block, 0, stream, a); break;
+        case FRT_STFT_IMAGE:
+            if (a.eps_free) hipLaunchKernelGGL((stft_pk_kernel<4, HS>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((stft_pk_kernel<3, HS>), grid, block, 0, stream, a);
+            break;
         default: hipLaunchKernelGGL((stft_pk_kernel<1, HS>), grid, block, 0, stream, a); break;
     }
     FRT_HIP_CHECK(hipGetLastError());

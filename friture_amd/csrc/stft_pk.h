@@ -25,6 +25,23 @@
 //   5. The output kind is a template parameter (the PSD kind keeps no weights in registers).
 #pragma once
 
+#ifndef FRT_PK_TIMING          // experiment builds only (wrong output by design): per-wave cycle counts of the frame's eight
+#define FRT_PK_TIMING 0        // intervals, written over the first row of every run (tools/exp/pk_timing.py reads them)
+#endif
+#ifndef FRT_PK_TW_AFTER        // 1: the first stage's twiddle products are issued after barrier A, between the transpose writes
+#define FRT_PK_TW_AFTER 1      // (the phase is bound by the LDS write path, its vector pipe is idle: +1-2 % at hop N/4, equal at N/2)
+#endif
+#ifndef FRT_PK_XREG            // 1: the exchange between the second and third pass of a sub-transform is a register transpose
+#define FRT_PK_XREG 0          // (v_permlane32_swap, v_permlane16_swap, masked DPP row_ror:8 moves) instead of an LDS round trip.
+#endif                         // Parity-green and measured equal (PSD -1 %, colour +0.7 %): it moves 1100 LDS-pipe cycles per frame
+                               // to ~950 cycles on each SIMD's vector pipe (a permlane swap issues every 8.3 cycles) — off
+#ifndef FRT_PK_STAGGER         // 1: the two rounds of sub-transforms half a pass apart (software pipeline); 0: in lock step
+#define FRT_PK_STAGGER 1
+#endif
+#ifndef FRT_PK_PRIO            // 1: waves 4-7 (the later-dispatched half) run at s_setprio 1; 2: the two halves of the workgroup
+#define FRT_PK_PRIO 0          // (the older and the younger wave of every SIMD) swap priority at every step of the frame
+#endif
+
 namespace frt {
 
 typedef float pk2 __attribute__((ext_vector_type(2)));
@@ -98,6 +115,50 @@ __device__ __forceinline__ void pk_cmul2_s(pk2& a0, pk2 w0, pk2& a1, pk2 w1) {
     a1 = r1;
 }
 
+// ---- 8 x 8 transpose between a lane's eight registers and lane bits 3-5 ---------------------------------------------------
+// After the second radix-8 pass lane i = 8 ih + il of a sub-transform holds the elements 64 ih + 8 q + il (q = register);
+// the third pass wants lane 8 q + il to hold 64 j + 8 q + il in register j: registers and the upper three lane bits trade
+// places, il stays.  Three butterfly stages, one per bit; the sub-transform phase is bound by LDS instruction throughput
+// (4260 cycles for 96 LDS instructions per wave, whatever their order), the vector pipe has room.
+typedef unsigned pk_u2 __attribute__((ext_vector_type(2)));
+// a[lanes 32-63] <-> b[lanes 0-31]
+__device__ __forceinline__ void pk_swap32(pk2& a, pk2& b) {
+    const pk_u2 r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    const pk_u2 r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = pk2{__uint_as_float(r0.x), __uint_as_float(r1.x)};
+    b = pk2{__uint_as_float(r0.y), __uint_as_float(r1.y)};
+}
+// a[rows 1, 3] <-> b[rows 0, 2] (rows of 16 lanes)
+__device__ __forceinline__ void pk_swap16(pk2& a, pk2& b) {
+    const pk_u2 r0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    const pk_u2 r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = pk2{__uint_as_float(r0.x), __uint_as_float(r1.x)};
+    b = pk2{__uint_as_float(r0.y), __uint_as_float(r1.y)};
+}
+// a[lanes with bit 3 set] <-> b[lanes with bit 3 clear], partner lane ^ 8: DPP moves (row_ror:8) whose bank mask writes only
+// the upper / lower half of every row of 16; the unwritten lanes keep `old`.  (v_cndmask_b32 on a vcc that a scalar
+// instruction wrote runs at 23 cycles per instruction on this chip — tools/exp/pk_pipes.cpp — a masked DPP move at 4.4.)
+__device__ __forceinline__ float pk_dpp_ror8(float old, float src, int bank_mask_hi) {
+    return bank_mask_hi ? __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(old), __float_as_uint(src), 0x128, 0xf, 0xc, false))
+                        : __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(old), __float_as_uint(src), 0x128, 0xf, 0x3, false));
+}
+__device__ __forceinline__ void pk_swap8(pk2& a, pk2& b) {
+    const pk2 na = {pk_dpp_ror8(a.x, b.x, 1), pk_dpp_ror8(a.y, b.y, 1)};      // lanes 8-15 of every row take b[lane ^ 8]
+    const pk2 nb = {pk_dpp_ror8(b.x, a.x, 0), pk_dpp_ror8(b.y, a.y, 0)};      // lanes 0-7 take a[lane ^ 8]
+    a = na;
+    b = nb;
+}
+__device__ __forceinline__ void pk_lane_transpose(pk2 (&u)[8]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pk_swap32(u[r], u[r + 4]);         // lane bit 5 <-> register bit 2
+    pk_swap16(u[0], u[2]);                                           // lane bit 4 <-> register bit 1
+    pk_swap16(u[1], u[3]);
+    pk_swap16(u[4], u[6]);
+    pk_swap16(u[5], u[7]);
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) pk_swap8(u[r], u[r + 1]);        // lane bit 3 <-> register bit 0
+}
+
 __device__ __forceinline__ void pk_dft4(pk2& a0, pk2& a1, pk2& a2, pk2& a3) {
     const pk2 s0 = a0 + a2, s1 = a0 - a2, s2 = a1 + a3, d = a1 - a3;
     a0 = s0 + s2;
@@ -165,12 +226,13 @@ __device__ __forceinline__ void lds_wr(uint32_t addr, pk2 v) { *(volatile lds_pk
 // slot of element e inside a 512-element region
 __device__ __forceinline__ int pk_sigma(int e) { return e ^ ((e >> 4) & 7) ^ (((e >> 6) & 1) << 3); }
 
-// KIND: 0 PSD, 1 dB / normalised (run-time choice), 3 colour image.  HS: ring slots (of 512 complex) a hop advances: 8 = hop N/2, 4 = hop N/4.
+// KIND: 0 PSD, 1 dB / normalised (run-time choice), 3 colour image, 4 colour image without the + 1e-30 (StftArgs::eps_free).  HS: ring slots (of 512 complex) a hop advances: 8 = hop N/2, 4 = hop N/4.
 template <int KIND, int HS>
 __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArgs a) {
     using P = PkPlan;
     constexpr int M = P::M, MS = P::MS, RS = P::RS;
     constexpr int PH = 16 / HS;                                     // frames until the ring is back in phase
+    constexpr bool IMAGE = KIND >= 3, EPS_FREE = KIND == 4;
     __shared__ __attribute__((aligned(1024))) char smem[P::LDS_BYTES];
     const uint32_t sm = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;      // LDS byte address of the block
     uint32_t* const lut_lds = (uint32_t*)(smem + P::LUT_OFF);
@@ -178,7 +240,7 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    if constexpr (KIND == 3) {
+    if constexpr (IMAGE) {
         if (t < 256) lut_lds[t] = a.lut[t];                         // visible after the first frame's barriers
     }
 
@@ -194,7 +256,7 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
     const pk2* tw = (const pk2*)a.tw;          // exp(-2 pi i n / M)
     const pk2* twn = (const pk2*)a.twn;        // exp(-2 pi i k / N)
     const pk2* tws = (const pk2*)a.tws;        // exp(-2 pi i n / 512)
-    const float* wgt = (const float*)(KIND == 3 ? a.wimage : a.weight);
+    const float* wgt = (const float*)(IMAGE ? a.wimage : a.weight);
     const float image_gain = (float)a.image_gain, norm_off = (float)a.norm_off, norm_scale = (float)a.norm_scale;
 
     // ---- per-thread constants of a run, in registers ------------------------------------------------------------------
@@ -271,11 +333,40 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
     };
     if (nfr > 0) copy_slots(f0, 0, 16, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if FRT_PK_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define PK_TICK(i)                                                         \
+    do {                                                                   \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime();     \
+        if ((i) >= 0) tacc[(i) < 0 ? 0 : (i)] += now__ - tprev;            \
+        tprev = now__;                                                     \
+    } while (0)
+#else
+#define PK_TICK(i) do { } while (0)
+#endif
+#if FRT_PK_PRIO == 1
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+#if FRT_PK_PRIO == 2
+    // The issue arbiter serves the older wave of a SIMD first (waves 0-3 here): measured with FRT_PK_TIMING, the older half
+    // finishes the sub-transform phase in 2940 cycles, the younger in 4315, and the older then idles at the barrier while the
+    // younger runs alone.  Swapping the priority at every step lets both halves progress at the same average rate.
+    const bool wave_hi = wave >= 4;
+#define PK_STEP(s)                                                         \
+    do {                                                                   \
+        if (wave_hi == (((s) & 1) != 0)) __builtin_amdgcn_s_setprio(1);    \
+        else __builtin_amdgcn_s_setprio(0);                                \
+    } while (0)
+#else
+#define PK_STEP(s) do { } while (0)
+#endif
 
     // ---- one frame; ph = (frame index inside the run) mod PH is a compile-time constant -------------------------------------
     auto frame = [&](auto phc, int g) -> bool {
         constexpr int ph = decltype(phc)::value;
         if (g >= nfr) return false;
+        PK_TICK(-1);
+        PK_STEP(0);
         // the copy of this frame's new samples has landed once at most the 16 row stores of the previous frame (issued
         // after it) are outstanding — vector-memory operations retire in order
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -287,61 +378,132 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
         // frame's new samples — which are the next frame's slots 16 - HS .. 15
         asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
         asm volatile("" : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+        PK_TICK(0);
         if (g + 1 < nfr) copy_slots(f0 + g + 1, 16 - HS, HS, ph * HS);
         pk_dft16(v);
+#if !FRT_PK_TW_AFTER
 #pragma unroll
         for (int k0 = 1; k0 < 15; k0 += 2) pk_cmul2(v[k0], tw1[k0 - 1], v[k0 + 1], tw1[k0]);
         v[15] = pk_cmul(v[15], tw1[14]);
+#endif
+        PK_TICK(1);
         __syncthreads();                                            // A: the previous frame's unpack has read the regions
+        PK_TICK(2);
+        PK_STEP(1);
+#if FRT_PK_TW_AFTER
+        lds_wr(tr_lane, v[0]);
+#pragma unroll
+        for (int k0 = 1; k0 < 15; k0 += 2) {
+            pk_cmul2(v[k0], tw1[k0 - 1], v[k0 + 1], tw1[k0]);
+            lds_wr(tr_lane + k0 * (RS * 8), v[k0]);
+            lds_wr(tr_lane + (k0 + 1) * (RS * 8), v[k0 + 1]);
+        }
+        v[15] = pk_cmul(v[15], tw1[14]);
+        lds_wr(tr_lane + 15 * (RS * 8), v[15]);
+#else
 #pragma unroll
         for (int k0 = 0; k0 < 16; ++k0) lds_wr(tr_lane + k0 * (RS * 8), v[k0]);
+#endif
+        PK_TICK(3);
         __syncthreads();                                            // B
-        // ---- 2. sixteen 512-point transforms over t: this wave's regions `wave` and 8 + wave, interleaved -------------------
+        PK_TICK(4);
+        PK_STEP(2);
+        // ---- 2. sixteen 512-point transforms over t: this wave's regions `wave` (round 0) and 8 + wave (round 1) ------------------
+        // LDS traffic of a wave is executed in order and the accesses are volatile (program order), so the scatter of a pass
+        // and the gather behind it need no fence; what the source order decides is which round's arithmetic covers which
+        // round's LDS round trip.
         pk2 u[2][8];
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) u[r][j] = lds_rd(((j & 1) ? g1 : g0) + r * (8 * RS * 8) + j * 512);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) pk_dft8(u[r]);
-        pass_sync<true>();
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t p = sub + ((s0 ^ q) << 3);
-            lds_wr(p, u[0][q]);
-            lds_wr(p + 8 * RS * 8, u[1][q]);
-        }
-        pass_sync<true>();
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
+        auto gather = [&](int r) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) u[r][j] = lds_rd(((j & 1) ? g1 : g0) + r * (8 * RS * 8) + j * 512);
+        };
+        auto scatter0 = [&](int r) {
 #pragma unroll
-        for (int q = 1; q < 8; ++q) pk_cmul2(u[0][q], twp1[q - 1], u[1][q], twp1[q - 1]);      // the two rounds share their factors
+            for (int q = 0; q < 8; ++q) lds_wr(sub + ((s0 ^ q) << 3) + r * (8 * RS * 8), u[r][q]);
+        };
+        auto scatter1 = [&](int r) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) pk_dft8(u[r]);
-        pass_sync<true>();
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t p = sub + ((s1 ^ (((q >> 1) & 3) | ((q & 1) << 3))) << 3) + (q & ~1) * 64;
-            lds_wr(p, u[0][q]);
-            lds_wr(p + 8 * RS * 8, u[1][q]);
-        }
-        pass_sync<true>();
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) u[r][j] = lds_rd(((j & 1) ? g1 : g0) + r * (8 * RS * 8) + j * 512);
-#pragma unroll
-        for (int q = 1; q < 8; ++q) pk_cmul2(u[0][q], twp2[q - 1], u[1][q], twp2[q - 1]);      // the two rounds share their factors
-#pragma unroll
-        for (int r = 0; r < 2; ++r) pk_dft8(u[r]);
-        pass_sync<true>();
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
+            for (int q = 0; q < 8; ++q)
+                lds_wr(sub + ((s1 ^ (((q >> 1) & 3) | ((q & 1) << 3))) << 3) + (q & ~1) * 64 + r * (8 * RS * 8), u[r][q]);
+        };
+        auto writeback = [&](int r) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) lds_wr(((j & 1) ? g1 : g0) + r * (8 * RS * 8) + j * 512, u[r][j]);
+        };
+#if FRT_PK_STAGGER
+        // round 1 runs half a pass behind round 0: while one round's scatter and gather are in flight the other computes
+        auto twiddle = [&](int r, const pk2 (&w)[7]) {
+#pragma unroll
+            for (int q = 1; q < 7; q += 2) pk_cmul2(u[r][q], w[q - 1], u[r][q + 1], w[q]);
+            u[r][7] = pk_cmul(u[r][7], w[6]);
+        };
+        gather(0);
+        gather(1);
+        pk_dft8(u[0]);
+        scatter0(0);
+        gather(0);
+        pk_dft8(u[1]);
+        scatter0(1);
+        gather(1);
+        twiddle(0, twp1);
+        pk_dft8(u[0]);
+#if FRT_PK_XREG
+        pk_lane_transpose(u[0]);
+        twiddle(1, twp1);
+        pk_dft8(u[1]);
+        pk_lane_transpose(u[1]);
+#else
+        scatter1(0);
+        gather(0);
+        twiddle(1, twp1);
+        pk_dft8(u[1]);
+        scatter1(1);
+        gather(1);
+#endif
+        twiddle(0, twp2);
+        pk_dft8(u[0]);
+        writeback(0);
+        twiddle(1, twp2);
+        pk_dft8(u[1]);
+        writeback(1);
+#else
+        gather(0);
+        gather(1);
+        pk_dft8(u[0]);
+        pk_dft8(u[1]);
+        PK_STEP(3);
+        scatter0(0);
+        scatter0(1);
+        PK_STEP(4);
+        gather(0);
+        gather(1);
+#pragma unroll
+        for (int q = 1; q < 8; ++q) pk_cmul2(u[0][q], twp1[q - 1], u[1][q], twp1[q - 1]);      // the two rounds share their factors
+        pk_dft8(u[0]);
+        pk_dft8(u[1]);
+        PK_STEP(5);
+#if FRT_PK_XREG
+        pk_lane_transpose(u[0]);
+        pk_lane_transpose(u[1]);
+#else
+        scatter1(0);
+        scatter1(1);
+        PK_STEP(6);
+        gather(0);
+        gather(1);
+#endif
+#pragma unroll
+        for (int q = 1; q < 8; ++q) pk_cmul2(u[0][q], twp2[q - 1], u[1][q], twp2[q - 1]);
+        pk_dft8(u[0]);
+        pk_dft8(u[1]);
+        PK_STEP(7);
+        writeback(0);
+        writeback(1);
+#endif
+        PK_TICK(5);
         __syncthreads();                                            // C
+        PK_TICK(6);
+        PK_STEP(8);
         // ---- 3. conjugate-symmetric unpack of the pairs (k, M - k), k = t + 512 q ---------------------------------------------
         float* row = (float*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
         uint32_t* prow = (uint32_t*)row;
@@ -365,44 +527,64 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
             if (a.kind == FRT_STFT_NORM) vv = (vv + norm_off) * norm_scale;
             return vv;
         };
-        auto image4 = [&](int q, const int (&k)[4], const float (&pw)[4], const float (&w)[4]) {
-            float vv[4];
-            uint32_t c[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                vv[e] = clamp_index(image_gain * log2_t(pw[e] + 1e-30f) + w[e]);
-                c[e] = lut_lds[(int)vv[e]];
-            }
-            const float m = fminf(fminf(__builtin_amdgcn_fractf(vv[0]), __builtin_amdgcn_fractf(vv[1])),
-                                  fminf(__builtin_amdgcn_fractf(vv[2]), __builtin_amdgcn_fractf(vv[3])));
-            if (__any(m < a.edge2)) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool near_edge = __builtin_amdgcn_fractf(vv[e]) < a.edge2;
-                    const int n = exact_colour_index(near_edge, pw[e], k[e], (int)vv[e], a);
-                    if (near_edge) c[e] = lut_lds[n];
-                }
-            }
-            prow[t + q * MS] = c[0];
-            prow[M - t - q * MS] = c[1];
-            prow[t + (q + 1) * MS] = c[2];
-            prow[M - t - (q + 1) * MS] = c[3];
+        // colour index of a power (exact, see stft_wave.h: exact_colour_index): float32 value, clamped into the LUT's range
+        auto index_value = [&](float p, float w) -> float {
+            return clamp_index(image_gain * log2_t(EPS_FREE ? p : p + 1e-30f) + w);
         };
+        // Groups of two pairs (q, q + 1).  The Z values of the NEXT group are requested before this group's arithmetic and
+        // the colour kind stores the PREVIOUS group's pixels (their LUT reads have had a whole group to arrive): one exposed
+        // LDS round trip per frame instead of one (PSD) or two (colour) per group.
+        pk2 z[2][4];
+        auto request = [&](int q, pk2 (&zz)[4]) {
+            zz[0] = zlo(q);
+            zz[1] = zhi(q);
+            zz[2] = zlo(q + 1);
+            zz[3] = zhi(q + 1);
+        };
+        request(0, z[0]);
+        uint32_t cprev[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < 8; q += 2) {
-            pk2 za0 = zlo(q), zb0 = zhi(q), za1 = zlo(q + 1), zb1 = zhi(q + 1);
-            if (q == 0) zb0 = t == 0 ? za0 : zb0;                   // Z[M] = Z[0]
+        for (int gq = 0; gq < 4; ++gq) {
+            const int q = 2 * gq;
+            if (gq < 3) request(q + 2, z[(gq + 1) & 1]);
+            pk2 (&zz)[4] = z[gq & 1];
+            if (gq == 0) zz[1] = t == 0 ? zz[0] : zz[1];           // Z[M] = Z[0]
+            if (gq == 2) PK_STEP(9);
             float pw[4];
-            pair_powers2(za0, zb0, twur[q], za1, zb1, twur[q + 1], pw);
+            pair_powers2(zz[0], zz[1], twur[q], zz[2], zz[3], twur[q + 1], pw);
             if constexpr (KIND == 0) {
                 row[t + q * MS] = pw[0];
                 row[M - t - q * MS] = pw[1];
                 row[t + (q + 1) * MS] = pw[2];
                 row[M - t - (q + 1) * MS] = pw[3];
-            } else if constexpr (KIND == 3) {
+            } else if constexpr (IMAGE) {
                 const int k[4] = {t + q * MS, M - t - q * MS, t + (q + 1) * MS, M - t - (q + 1) * MS};
                 const float w[4] = {wgr[q], wgr[8 + q], wgr[q + 1], wgr[8 + q + 1]};
-                image4(q, k, pw, w);
+                float vv[4];
+                uint32_t c[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vv[e] = index_value(pw[e], w[e]);
+                    c[e] = lut_lds[(int)vv[e]];
+                }
+                const float m = fminf(fminf(__builtin_amdgcn_fractf(vv[0]), __builtin_amdgcn_fractf(vv[1])),
+                                      fminf(__builtin_amdgcn_fractf(vv[2]), __builtin_amdgcn_fractf(vv[3])));
+                if (__any(m < a.edge2)) {                           // within 2 thr above an index edge: one float64 comparison decides
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool near_edge = __builtin_amdgcn_fractf(vv[e]) < a.edge2;
+                        const int n = exact_colour_index(near_edge, pw[e], k[e], (int)vv[e], a);
+                        if (near_edge) c[e] = lut_lds[n];
+                    }
+                }
+                if (gq > 0) {
+                    prow[t + (q - 2) * MS] = cprev[0];
+                    prow[M - t - (q - 2) * MS] = cprev[1];
+                    prow[t + (q - 1) * MS] = cprev[2];
+                    prow[M - t - (q - 1) * MS] = cprev[3];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cprev[e] = c[e];
             } else {
                 row[t + q * MS] = finish(pw[0], wgr[q]);
                 row[M - t - q * MS] = finish(pw[1], wgr[8 + q]);
@@ -410,13 +592,19 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
                 row[M - t - (q + 1) * MS] = finish(pw[3], wgr[8 + q + 1]);
             }
         }
+        if constexpr (IMAGE) {
+            prow[t + 6 * MS] = cprev[0];
+            prow[M - t - 6 * MS] = cprev[1];
+            prow[t + 7 * MS] = cprev[2];
+            prow[M - t - 7 * MS] = cprev[3];
+        }
         if (t == 0) {
             const pk2 zm = lds_rd(sm + 256 * 8);           // Z[M/2]: region 0, slot sigma(256) = 256
             const float pm = (zm.x * zm.x + zm.y * zm.y) * 4.f;
             if constexpr (KIND == 0) {
                 row[M / 2] = pm;
-            } else if constexpr (KIND == 3) {
-                const float vv = clamp_index(image_gain * log2_t(pm + 1e-30f) + wg_nyq);
+            } else if constexpr (IMAGE) {
+                const float vv = index_value(pm, wg_nyq);
                 int idx = (int)vv;
                 const bool near_edge = __builtin_amdgcn_fractf(vv) < a.edge2;
                 if (near_edge) idx = exact_colour_index(near_edge, pm, M / 2, idx, a);
@@ -425,6 +613,7 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
                 row[M / 2] = finish(pm, wg_nyq);
             }
         }
+        PK_TICK(7);
         return true;
     };
     for (int g = 0; g < nfr; g += PH) {
@@ -435,6 +624,17 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
             if (!frame(std::integral_constant<int, 3>{}, g + 3)) break;
         }
     }
+#if FRT_PK_TIMING
+    // interval i of this wave, summed over the run's frames: 0 wait for the copy + ring reads + window, 1 DFT16 (+ twiddles),
+    // 2 barrier A, 3 transpose writes, 4 barrier B, 5 sub-transforms, 6 barrier C, 7 unpack + stores
+    if (lane == 0 && nfr > 0) {
+        float* row = (float*)a.out + chan * a.out_cstride + f0 * (M + 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) row[wave * 8 + i] = (float)tacc[i] / (float)nfr;
+    }
+#endif
+#undef PK_TICK
+#undef PK_STEP
 }
 
 }  // namespace frt

@@ -75,6 +75,10 @@ def test_threads_and_handles_soak_exits_cleanly_under_amd_log_level_1(tmp_path):
     env = dict(os.environ, AMD_LOG_LEVEL="1")
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
     assert r.returncode == 0 and "SOAK OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
-    # AMD_LOG_LEVEL=1 prints runtime errors only: none may appear, in particular none from teardown
-    noisy = [ln for ln in r.stderr.splitlines() if ":1:" in ln or "hipError" in ln or "HSA_STATUS_ERROR" in ln]
+    # AMD_LOG_LEVEL=1 prints runtime errors only: none may appear, in particular none from teardown.  One message is expected
+    # and benign: the library asks the runtime whether a caller's pointer is device memory (hipPointerGetAttributes, is_device_
+    # pointer in csrc/lib.hip) and the runtime logs "Cannot get amd_mem_obj for ptr" for every plain host array before
+    # answering "no" — that is the question being answered, not a failure.
+    noisy = [ln for ln in r.stderr.splitlines()
+             if (":1:" in ln or "hipError" in ln or "HSA_STATUS_ERROR" in ln) and "Cannot get amd_mem_obj for ptr" not in ln]
     assert not noisy, noisy[:10]
