@@ -266,8 +266,11 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
     for (int j = 0; j < 16; ++j) winr[j] = win[t + j * MS];
 #pragma unroll
     for (int k0 = 1; k0 < 16; ++k0) tw1[k0 - 1] = tw[(t * k0) & (M - 1)];
+    // unpack: thread t owns the bin pairs (k, M - k), k = 4 t + c + 2048 g (c < 4, g < 2): four consecutive bins per 16-byte store
 #pragma unroll
-    for (int q = 0; q < 8; ++q) twur[q] = twn[t + q * MS];
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) twur[4 * g + c] = twn[4 * t + c + 2048 * g];
     // sub-transforms of 512 points, 8 per lane: pass 1 multiplies slot q by W_64^{q (lane & 7)}, pass 2 by W_512^{q lane}
 #pragma unroll
     for (int q = 1; q < 8; ++q) {
@@ -278,8 +281,9 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
     if constexpr (KIND != 0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            wgr[q] = wgt ? wgt[t + q * MS] : 0.f;
-            wgr[8 + q] = wgt ? wgt[M - t - q * MS] : 0.f;
+            const int k = 4 * t + (q & 3) + 2048 * (q >> 2);
+            wgr[q] = wgt ? wgt[k] : 0.f;
+            wgr[8 + q] = wgt ? wgt[M - k] : 0.f;
         }
         wg_nyq = wgt ? wgt[M / 2] : 0.f;
     }
@@ -298,22 +302,16 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
     const int s0 = pk_sigma(8 * lane);                              // pass-0 scatter: element 8 lane + q -> s0 ^ q
     const int b3 = (lane >> 3) & 1;
     const int s1 = (((lane >> 3) << 6) | (lane & 7)) ^ (12 * b3);   // pass-1 scatter: element 64 (lane >> 3) + (lane & 7) + 8 q
-    // unpack: Z[t + 512 q] and Z[M - t - 512 q] (lds_swizzle_model.py derives these forms)
-    // lo: region t & 15, slot sigma((t >> 4) + 32 q) = 32 q + (sigma5(t >> 4) ^ c(q)); hi with tm = 512 - t and q' = 15 - q;
-    // c(q) = ((q & 3) << 1) | (((q >> 1) & 1) << 3) takes four values: four byte bases per side, the rest is an immediate.
-    // Thread 0's mirror values are Z[512 (16 - q)] (region 0, slot 32 (16 - q)): its four bases are preset so that the
-    // same immediates land there; its Z[M] = Z[0] is patched in the frame.
-    uint32_t blo[4], bhi[4];
-    {
-        const int tm = MS - t;                                      // 1..512
-        const int ulo = (t & 15) * RS, ulo5 = (t >> 4) ^ ((t >> 8) & 1);
-        const int uhi = (tm & 15) * RS, uhi5 = (tm >> 4) ^ ((tm >> 8) & 1);
-        const int cls[4] = {0, 2, 12, 14}, lane0[4] = {34, 44, 46, 32};
+    // unpack: Z[k] = region k & 15, slot sigma(k >> 4).  For k = 4 t + c + 2048 g: region 4 (t & 3) + c, slot sigma(t >> 2) + 128 g
+    // (bit 7 of a slot is outside the swizzle): one lane base, c and g are immediates.  Z[M - k]: with u = 4 t + c, region
+    // (16 - (u & 15)) & 15 and slot 512 - 128 g - ((u + 15) >> 4): one lane base per c.  (u = 0: g = 0 reads the pad slot 512
+    // and is replaced by Z[0], g = 1 lands on Z[6144] = region 0, slot 384.)
+    const uint32_t ulo = sm + ((4 * (t & 3)) * RS + pk_sigma(t >> 2)) * 8;
+    uint32_t uhi[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            blo[c] = sm + (ulo + (ulo5 ^ cls[c])) * 8;
-            bhi[c] = sm + (t == 0 ? lane0[c] : uhi + (uhi5 ^ cls[c])) * 8;
-        }
+    for (int c = 0; c < 4; ++c) {
+        const int u = 4 * t + c, sl = 512 - ((u + 15) >> 4);
+        uhi[c] = sm + (((16 - (u & 15)) & 15) * RS + (sl < 512 ? pk_sigma(sl) : 512)) * 8;
     }
 
     // ---- sample copies ----------------------------------------------------------------------------------------------------
@@ -335,6 +333,7 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if FRT_PK_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    const unsigned long long run_t0 = __builtin_amdgcn_s_memtime(), run_r0 = __builtin_amdgcn_s_memrealtime();
 #define PK_TICK(i)                                                         \
     do {                                                                   \
         const unsigned long long now__ = __builtin_amdgcn_s_memtime();     \
@@ -367,9 +366,10 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
         if (g >= nfr) return false;
         PK_TICK(-1);
         PK_STEP(0);
-        // the copy of this frame's new samples has landed once at most the 16 row stores of the previous frame (issued
-        // after it) are outstanding — vector-memory operations retire in order
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        // the copy of this frame's new samples has landed once at most the 4 row stores of the previous frame (issued
+        // after it; wave 0 has a fifth, the bin N/4: it waits for one store more than it must) are outstanding — vector-
+        // memory operations retire in order
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         // ---- 1. samples from the wave's ring slots, window, 16-point DFT over j, twiddle ---------------------------------
         pk2 v[16];
 #pragma unroll
@@ -507,8 +507,8 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
         // ---- 3. conjugate-symmetric unpack of the pairs (k, M - k), k = t + 512 q ---------------------------------------------
         float* row = (float*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
         uint32_t* prow = (uint32_t*)row;
-        auto zlo = [&](int q) -> pk2 { return lds_rd(blo[q & 3] + 32 * q * 8); };
-        auto zhi = [&](int q) -> pk2 { return lds_rd(bhi[(15 - q) & 3] + 32 * (15 - q) * 8); };
+        auto zlo = [&](int c, int g) -> pk2 { return lds_rd(ulo + c * (RS * 8) + g * 1024); };
+        auto zhi = [&](int c, int g) -> pk2 { return lds_rd(uhi[c] - g * 1024); };
         // A = Z[k], B = Z[M-k], wk = exp(-2 pi i k / N):  S = A + conj B, tt = wk (A - conj B);
         // 2 X[k] = S + (-i) tt,  2 conj X[M-k] = S - (-i) tt  (the 1/2 rides in the window table)
         auto pair_powers2 = [&](pk2 A0, pk2 B0, pk2 w0, pk2 A1, pk2 B1, pk2 w1, float (&pw)[4]) {
@@ -531,72 +531,65 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
         auto index_value = [&](float p, float w) -> float {
             return clamp_index(image_gain * log2_t(EPS_FREE ? p : p + 1e-30f) + w);
         };
-        // Groups of two pairs (q, q + 1).  The Z values of the NEXT group are requested before this group's arithmetic and
-        // the colour kind stores the PREVIOUS group's pixels (their LUT reads have had a whole group to arrive): one exposed
-        // LDS round trip per frame instead of one (PSD) or two (colour) per group.
-        pk2 z[2][4];
-        auto request = [&](int q, pk2 (&zz)[4]) {
-            zz[0] = zlo(q);
-            zz[1] = zhi(q);
-            zz[2] = zlo(q + 1);
-            zz[3] = zhi(q + 1);
-        };
-        request(0, z[0]);
-        uint32_t cprev[4] = {0, 0, 0, 0};
+        // Two groups (g = 0, 1) of four pairs: bins k0 + c and M - k0 - c, k0 = 4 t + 2048 g — one 16-byte store per side and
+        // group (1 KB per wave-instruction; rows start on 4-byte boundaries, the hardware splits what straddles a line): 4
+        // vector-memory instructions per thread and frame instead of 16.  The memory-path counters of the N = 1024 kernel
+        // (profiles/r04_headline_memory_path_pmc.txt) show the texture addresser busy ~22 cycles per wave-instruction
+        // whatever it carries.  The Z values of group 1 are requested before group 0's arithmetic.
+        typedef float pk_f4 __attribute__((ext_vector_type(4), aligned(4)));
+        typedef uint32_t pk_u4 __attribute__((ext_vector_type(4), aligned(4)));
+        pk2 za[2][4], zb[2][4];
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const int q = 2 * gq;
-            if (gq < 3) request(q + 2, z[(gq + 1) & 1]);
-            pk2 (&zz)[4] = z[gq & 1];
-            if (gq == 0) zz[1] = t == 0 ? zz[0] : zz[1];           // Z[M] = Z[0]
-            if (gq == 2) PK_STEP(9);
-            float pw[4];
-            pair_powers2(zz[0], zz[1], twur[q], zz[2], zz[3], twur[q + 1], pw);
+        for (int c = 0; c < 4; ++c) { za[0][c] = zlo(c, 0); zb[0][c] = zhi(c, 0); }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (g == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { za[1][c] = zlo(c, 1); zb[1][c] = zhi(c, 1); }
+                zb[0][0] = t == 0 ? za[0][0] : zb[0][0];            // Z[M] = Z[0]
+            }
+            float plo[4], phi[4];
+            {
+                float pw[4];
+                pair_powers2(za[g][0], zb[g][0], twur[4 * g], za[g][1], zb[g][1], twur[4 * g + 1], pw);
+                plo[0] = pw[0]; phi[0] = pw[1]; plo[1] = pw[2]; phi[1] = pw[3];
+                pair_powers2(za[g][2], zb[g][2], twur[4 * g + 2], za[g][3], zb[g][3], twur[4 * g + 3], pw);
+                plo[2] = pw[0]; phi[2] = pw[1]; plo[3] = pw[2]; phi[3] = pw[3];
+            }
+            const int k0 = 4 * t + 2048 * g;
             if constexpr (KIND == 0) {
-                row[t + q * MS] = pw[0];
-                row[M - t - q * MS] = pw[1];
-                row[t + (q + 1) * MS] = pw[2];
-                row[M - t - (q + 1) * MS] = pw[3];
+                *(pk_f4*)(row + k0) = pk_f4{plo[0], plo[1], plo[2], plo[3]};
+                *(pk_f4*)(row + M - k0 - 3) = pk_f4{phi[3], phi[2], phi[1], phi[0]};
             } else if constexpr (IMAGE) {
-                const int k[4] = {t + q * MS, M - t - q * MS, t + (q + 1) * MS, M - t - (q + 1) * MS};
-                const float w[4] = {wgr[q], wgr[8 + q], wgr[q + 1], wgr[8 + q + 1]};
-                float vv[4];
-                uint32_t c[4];
+                float vv[8];
+                uint32_t cc[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    vv[e] = index_value(pw[e], w[e]);
-                    c[e] = lut_lds[(int)vv[e]];
+                for (int c = 0; c < 4; ++c) {
+                    vv[c] = index_value(plo[c], wgr[4 * g + c]);
+                    vv[4 + c] = index_value(phi[c], wgr[8 + 4 * g + c]);
                 }
-                const float m = fminf(fminf(__builtin_amdgcn_fractf(vv[0]), __builtin_amdgcn_fractf(vv[1])),
-                                      fminf(__builtin_amdgcn_fractf(vv[2]), __builtin_amdgcn_fractf(vv[3])));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cc[e] = lut_lds[(int)vv[e]];
+                float m = __builtin_amdgcn_fractf(vv[0]);
+#pragma unroll
+                for (int e = 1; e < 8; ++e) m = fminf(m, __builtin_amdgcn_fractf(vv[e]));
                 if (__any(m < a.edge2)) {                           // within 2 thr above an index edge: one float64 comparison decides
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < 8; ++e) {
                         const bool near_edge = __builtin_amdgcn_fractf(vv[e]) < a.edge2;
-                        const int n = exact_colour_index(near_edge, pw[e], k[e], (int)vv[e], a);
-                        if (near_edge) c[e] = lut_lds[n];
+                        const int kk = e < 4 ? k0 + e : M - k0 - (e - 4);
+                        const int n = exact_colour_index(near_edge, e < 4 ? plo[e] : phi[e - 4], kk, (int)vv[e], a);
+                        if (near_edge) cc[e] = lut_lds[n];
                     }
                 }
-                if (gq > 0) {
-                    prow[t + (q - 2) * MS] = cprev[0];
-                    prow[M - t - (q - 2) * MS] = cprev[1];
-                    prow[t + (q - 1) * MS] = cprev[2];
-                    prow[M - t - (q - 1) * MS] = cprev[3];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) cprev[e] = c[e];
+                *(pk_u4*)(prow + k0) = pk_u4{cc[0], cc[1], cc[2], cc[3]};
+                *(pk_u4*)(prow + M - k0 - 3) = pk_u4{cc[7], cc[6], cc[5], cc[4]};
             } else {
-                row[t + q * MS] = finish(pw[0], wgr[q]);
-                row[M - t - q * MS] = finish(pw[1], wgr[8 + q]);
-                row[t + (q + 1) * MS] = finish(pw[2], wgr[q + 1]);
-                row[M - t - (q + 1) * MS] = finish(pw[3], wgr[8 + q + 1]);
+                *(pk_f4*)(row + k0) = pk_f4{finish(plo[0], wgr[4 * g]), finish(plo[1], wgr[4 * g + 1]), finish(plo[2], wgr[4 * g + 2]),
+                                            finish(plo[3], wgr[4 * g + 3])};
+                *(pk_f4*)(row + M - k0 - 3) = pk_f4{finish(phi[3], wgr[8 + 4 * g + 3]), finish(phi[2], wgr[8 + 4 * g + 2]),
+                                                    finish(phi[1], wgr[8 + 4 * g + 1]), finish(phi[0], wgr[8 + 4 * g])};
             }
-        }
-        if constexpr (IMAGE) {
-            prow[t + 6 * MS] = cprev[0];
-            prow[M - t - 6 * MS] = cprev[1];
-            prow[t + 7 * MS] = cprev[2];
-            prow[M - t - 7 * MS] = cprev[3];
         }
         if (t == 0) {
             const pk2 zm = lds_rd(sm + 256 * 8);           // Z[M/2]: region 0, slot sigma(256) = 256
@@ -631,6 +624,8 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
         float* row = (float*)a.out + chan * a.out_cstride + f0 * (M + 1);
 #pragma unroll
         for (int i = 0; i < 8; ++i) row[wave * 8 + i] = (float)tacc[i] / (float)nfr;
+        // shader clock over the run: s_memtime ticks per 100 MHz s_memrealtime tick
+        row[64 + wave] = (float)(__builtin_amdgcn_s_memtime() - run_t0) / (float)(__builtin_amdgcn_s_memrealtime() - run_r0) * 0.1f;
     }
 #endif
 #undef PK_TICK

@@ -16,6 +16,8 @@ hop = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 N, C, T = 16384, 32, 1 << 20
 x = 0.25 * torch.randn((C, T), device="cuda", dtype=torch.float32)
+if os.environ.get("PK_ZERO_INPUT"):
+    x.zero_()
 e = StftEngine(N, hop, C, 32)
 e.set_epilogue(tables.weighting_db(tables.rfft_frequencies(N), 1e-50)[0], -140.0, 0.0, palette.cmr_lut())
 F = e.frames_for(T)
@@ -28,6 +30,8 @@ o = out.view(torch.float32).cpu().numpy()
 rows = [f for f in range(F) if np.all(o[0, f, :64] > 1.0) and np.all(o[0, f, :64] < 1e7)]
 run = rows[1] - rows[0] if len(rows) > 1 else F
 acc = np.array([o[c, f, :64].reshape(8, 8) for c in range(C) for f in rows])          # [runs][wave][interval]
+ghz = np.array([o[c, f, 64:72] for c in range(C) for f in rows])
+print(f"shader clock during the runs (s_memtime / s_memrealtime): mean {ghz.mean():.3f} GHz, min {ghz.min():.3f}, max {ghz.max():.3f}")
 names = ["copy wait + ring reads + window", "DFT16 + twiddles (+ copy issue)", "barrier A", "transpose writes", "barrier B",
          "sub-transforms (3 passes, 2 rounds)", "barrier C", "unpack + stores"]
 mean = acc.mean(axis=0)
