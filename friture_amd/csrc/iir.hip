@@ -410,7 +410,10 @@ static int launch_iir_stage(IirStageArgs a, const int* orders, int n_channels, h
 // produced here: calls that return signals keep the slot kernel and the reference's separately rounded operations).
 // A wavefront = 64 consecutive chunks of one channel x one filter group (up to kLaneBands band filters, or the decimator,
 // which also writes the even samples of its output as the next stage's input).
-constexpr int kLaneBands = 3;      // measured: one band filter per wavefront re-reads the samples per filter and is 15-70 % slower (bpo 3 / 24)
+#ifndef FRT_LANE_BANDS
+#define FRT_LANE_BANDS 3
+#endif
+constexpr int kLaneBands = FRT_LANE_BANDS;      // measured: one band filter per wavefront re-reads the samples per filter and is 15-70 % slower (bpo 3 / 24)
 
 template <int NF, int ORD, bool DEC, bool F32>
 __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0) {

@@ -2,7 +2,7 @@
 # One GPU-box session: parity tests, smoke, bench, rocprofv3 kernel stats + PMC traffic.  Outputs -> gpurun_out/.
 set -u
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 echo "== selftest"; timeout 300 tools/bin/stft_selftest check | tail -2
@@ -25,7 +25,7 @@ echo "== bench once more with the traffic figure of this session"
 timeout 900 python bench.py --steps 50 --warmup 5 --cpu-budget 0 --no-legs 2>/dev/null | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(json.dumps(r['roofline']))"
 echo "== large frames: rates, PMC summaries (N = 16384 and 4096)"
 ( export FRT_BENCH_SETS=4; for cfg in "16384 8192 32 20 0" "16384 8192 32 20 3" "8192 4096 32 21 0" "8192 4096 32 21 3" "4096 2048 16 22 0" "4096 1024 16 22 3" "2048 1024 8 24 0" "2048 512 8 24 3"; do tools/bin/stft_selftest bench $cfg 0 40 | tail -1; done ) > gpurun_out/${TAG}_stft_big_bench.txt 2>&1; cat gpurun_out/${TAG}_stft_big_bench.txt | cut -c1-150
-bash tools/gpu_pmc.sh ${TAG}_n16384 0 3 16384 8192 32 20 > /dev/null 2>&1; python tools/prof_summary.py pmc gpurun_out/pmc_${TAG}_n16384 stft_big > gpurun_out/${TAG}_stft16384_pmc.txt
+bash tools/gpu_pmc.sh ${TAG}_n16384 0 3 16384 8192 32 20 > /dev/null 2>&1; python tools/prof_summary.py pmc gpurun_out/pmc_${TAG}_n16384 stft_pk > gpurun_out/${TAG}_stft16384_pmc.txt
 bash tools/gpu_pmc.sh ${TAG}_n4096 0 3 4096 1024 16 22 > /dev/null 2>&1; python tools/prof_summary.py pmc gpurun_out/pmc_${TAG}_n4096 stft_big > gpurun_out/${TAG}_stft4096_pmc.txt
 echo "== kernel stats of the screen-space / widget / GCC kernels (their GPU tests under rocprofv3)"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/widgets -o w -- python -m pytest $R/tests/test_pipeline_gpu.py $R/tests/test_widgets_gpu.py $R/tests/test_gcc_gpu.py -q -m gpu -p no:cacheprovider > $R/gpurun_out/prof/widgets.log 2>&1 )
