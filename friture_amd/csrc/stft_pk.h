@@ -35,6 +35,9 @@
 #define FRT_PK_XREG 0          // (v_permlane32_swap, v_permlane16_swap, masked DPP row_ror:8 moves) instead of an LDS round trip.
 #endif                         // Parity-green and measured equal (PSD -1 %, colour +0.7 %): it moves 1100 LDS-pipe cycles per frame
                                // to ~950 cycles on each SIMD's vector pipe (a permlane swap issues every 8.3 cycles) — off
+#ifndef FRT_PK_OVERLAP         // 1: (PSD kind) the first stage of frame g + 1 is issued inside frame g's sub-transform phase.  Parity-
+#define FRT_PK_OVERLAP 0       // green, measured: the phase grows by 1150-1380 cycles for the 670 moved into it (8500 against 8200 cycles
+#endif                         // per frame): that phase has no idle issue slots to give — off
 #ifndef FRT_PK_STAGGER         // 1: the two rounds of sub-transforms half a pass apart (software pipeline); 0: in lock step
 #define FRT_PK_STAGGER 1
 #endif
@@ -360,25 +363,24 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
 #define PK_STEP(s) do { } while (0)
 #endif
 
-    // ---- one frame; ph = (frame index inside the run) mod PH is a compile-time constant -------------------------------------
-    auto frame = [&](auto phc, int g) -> bool {
+    // ---- first stage of frame g (ph = g mod PH, compile time): samples from the wave's ring slots, window, 16-point DFT over j
+    // (and the twiddles unless they ride between the transpose writes) ---------------------------------------------------------
+    // OVL (experiment, PSD kind: it has the 32 registers to keep the result alive through the unpack): the first stage of frame
+    // g + 1 issued INSIDE frame g's sub-transform phase instead of between barrier C of one frame and barrier A of the next.
+    constexpr bool OVL = FRT_PK_OVERLAP && KIND == 0;
+    pk2 v[16];                                                    // first-stage output of the frame about to be transposed
+    auto first_stage = [&](auto phc, int g) {
         constexpr int ph = decltype(phc)::value;
-        if (g >= nfr) return false;
-        PK_TICK(-1);
-        PK_STEP(0);
-        // the copy of this frame's new samples has landed once at most the 4 row stores of the previous frame (issued
-        // after it; wave 0 has a fifth, the bin N/4: it waits for one store more than it must) are outstanding — vector-
-        // memory operations retire in order
+        // the copy of this frame's new samples has landed once at most the 4 row stores issued after it (wave 0 has a
+        // fifth, the bin N/4: it waits for one store more than it must) are outstanding — vector-memory operations retire
+        // in order
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        // ---- 1. samples from the wave's ring slots, window, 16-point DFT over j, twiddle ---------------------------------
-        pk2 v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = lds_rd(ring_lane + ((j + ph * HS) & 15) * 512) * winr[j];
         // every lane of this wave has its samples (the products above exist): the oldest HS slots are free for the next
         // frame's new samples — which are the next frame's slots 16 - HS .. 15
         asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
         asm volatile("" : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
-        PK_TICK(0);
         if (g + 1 < nfr) copy_slots(f0 + g + 1, 16 - HS, HS, ph * HS);
         pk_dft16(v);
 #if !FRT_PK_TW_AFTER
@@ -386,6 +388,16 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
         for (int k0 = 1; k0 < 15; k0 += 2) pk_cmul2(v[k0], tw1[k0 - 1], v[k0 + 1], tw1[k0]);
         v[15] = pk_cmul(v[15], tw1[14]);
 #endif
+    };
+
+    // ---- one frame; ph = (frame index inside the run) mod PH is a compile-time constant -------------------------------------
+    auto frame = [&](auto phc, int g) -> bool {
+        constexpr int ph = decltype(phc)::value;
+        if (g >= nfr) return false;
+        PK_TICK(-1);
+        PK_STEP(0);
+        if constexpr (!OVL) first_stage(phc, g);                  // (OVL: issued inside the previous frame, or in front of the loop)
+        PK_TICK(0);
         PK_TICK(1);
         __syncthreads();                                            // A: the previous frame's unpack has read the regions
         PK_TICK(2);
@@ -445,6 +457,9 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
         pk_dft8(u[1]);
         scatter0(1);
         gather(1);
+        if constexpr (OVL) {
+            if (g + 1 < nfr) first_stage(std::integral_constant<int, (ph + 1) % PH>{}, g + 1);
+        }
         twiddle(0, twp1);
         pk_dft8(u[0]);
 #if FRT_PK_XREG
@@ -477,6 +492,9 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
         PK_STEP(4);
         gather(0);
         gather(1);
+        if constexpr (OVL) {
+            if (g + 1 < nfr) first_stage(std::integral_constant<int, (ph + 1) % PH>{}, g + 1);
+        }
 #pragma unroll
         for (int q = 1; q < 8; ++q) pk_cmul2(u[0][q], twp1[q - 1], u[1][q], twp1[q - 1]);      // the two rounds share their factors
         pk_dft8(u[0]);
@@ -609,6 +627,9 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
         PK_TICK(7);
         return true;
     };
+    if constexpr (OVL) {
+        if (nfr > 0) first_stage(std::integral_constant<int, 0>{}, 0);
+    }
     for (int g = 0; g < nfr; g += PH) {
         if (!frame(std::integral_constant<int, 0>{}, g)) break;
         if (!frame(std::integral_constant<int, 1>{}, g + 1)) break;
