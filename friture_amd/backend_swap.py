@@ -17,6 +17,8 @@ SWAPPED = ("audioproc", "octavefilters", "filter", "ringbuffer",
            "signal.color_tranform", "signal.transform_pipeline")
 
 _saved: dict = {}
+_saved_attr: dict = {}          # (parent module name, leaf) -> the attribute install() replaced (_MISSING when there was none)
+_MISSING = object()
 
 
 def install(target_package: str = "friture") -> None:
@@ -31,6 +33,8 @@ def install(target_package: str = "friture") -> None:
         parent_name, _, leaf = key.rpartition(".")
         parent = sys.modules.get(parent_name)
         if parent is not None:
+            if (parent_name, leaf) not in _saved_attr:
+                _saved_attr[(parent_name, leaf)] = getattr(parent, leaf, _MISSING)
             setattr(parent, leaf, mod)
 
 
@@ -41,3 +45,14 @@ def uninstall() -> None:
         else:
             sys.modules[key] = old
     _saved.clear()
+    # the parent packages' attributes too: `import friture.signal.correlation as m` resolves through them
+    for (parent_name, leaf), old in _saved_attr.items():
+        parent = sys.modules.get(parent_name)
+        if parent is None:
+            continue
+        if old is _MISSING:
+            if hasattr(parent, leaf):
+                delattr(parent, leaf)
+        else:
+            setattr(parent, leaf, old)
+    _saved_attr.clear()

@@ -2001,15 +2001,23 @@ __global__ void __launch_bounds__(1024) delay_window_std_kernel(const double* __
         for (int w = 0; w < 16; ++w) s += red[w];
         return s;
     };
-    double acc = 0.0;
-    for (int i = tid; i < length; i += 1024) acc += d[i];
+    // a constant window is silent: numpy.std of n copies of c is 0 or rounding noise of c, depending on c, n and the
+    // summation order (delay_estimator.py:127 gates on std > 0) — here "every sample equals the first" decides
+    const double first = d[0];
+    double acc = 0.0, differ = 0.0;
+    for (int i = tid; i < length; i += 1024) {
+        const double v = d[i];
+        acc += v;
+        differ += v != first ? 1.0 : 0.0;
+    }
     const double mean = block_sum(acc) / (double)length;
+    const bool constant = block_sum(differ) == 0.0;
     acc = 0.0;
     for (int i = tid; i < length; i += 1024) {
         const double t = d[i] - mean;
         acc += t * t;
     }
-    const double var = block_sum(acc) / (double)length;
+    const double var = constant ? 0.0 : block_sum(acc) / (double)length;
     if (tid == 0) out[blockIdx.x] = sqrt(var);
 }
 

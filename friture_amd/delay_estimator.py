@@ -88,7 +88,9 @@ class DelayEstimatorStream(DelayEstimator):
     samples a window of both rings (device pointers, same indices / mirror layout / growth as RingBuffer) goes to GCC-PHAT
     and the read-out on the same stream; the in-place mean removal the reference applies to its ring views
     (correlation.py:27-28) is applied to the same samples.  Per window two scalars (the std test of
-    delay_estimator.py:127-129) and the read-out come down."""
+    delay_estimator.py:127-129) and the read-out come down.  The gate treats a window whose samples are all equal as silent
+    (std = 0): numpy's std of a constant non-zero window is 0 or rounding noise depending on the value and the summation
+    order, so the reference's own behaviour there is not defined by its arithmetic."""
 
     def __init__(self, delayrange_s: float = DEFAULT_DELAYRANGE):
         super().__init__(delayrange_s)
@@ -99,7 +101,9 @@ class DelayEstimatorStream(DelayEstimator):
         from . import _lib
         self._torch, self._ct, self._libmod = torch, ctypes, _lib
         self._lib = _lib.init()
-        self.ringbuffer0 = self.ringbuffer1 = None              # the rings live inside the C object
+        # the rings live inside the C object; ringbuffer0 / ringbuffer1 stay inspectable (offset, data_indexed) as on the
+        # reference widget (friture/delay_estimator.py:52-53)
+        self.ringbuffer0, self.ringbuffer1 = _DeviceRingProxy(self, 0), _DeviceRingProxy(self, 1)
         self._h = ctypes.c_void_p()
         DP = ctypes.POINTER(ctypes.c_double)
         b, a = np.ascontiguousarray(self.bdec, np.float64), np.ascontiguousarray(self.adec, np.float64)
@@ -173,6 +177,24 @@ class DelayEstimatorStream(DelayEstimator):
         stds = (ct.c_double * 2)()
         check(self._lib.frt_delay_window_std(self._h, p0, p1, length, stds))                 # waits for the pushes in flight
         return np.stack([torch.as_tensor(_DeviceView(p.value, length), device=self._dev).cpu().numpy() for p in (p0, p1)])
+
+
+class _DeviceRingProxy:
+    """Read-only stand-in for one of DelayEstimatorStream's rings with the two members of friture/ringbuffer.py callers
+    inspect: `offset` (absolute index of the next sample) and `data_indexed(start, length)` (the `length` samples that end at
+    `start`, as a host array [1, length]; ringbuffer.py:87-99)."""
+
+    def __init__(self, owner, channel):
+        self._owner, self._channel = owner, channel
+
+    @property
+    def offset(self):
+        return self._owner.offset
+
+    def data_indexed(self, start, length):
+        if length <= 0:
+            raise ArithmeticError("negative or null length")
+        return self._owner.window(start, length)[self._channel:self._channel + 1]
 
 
 class _DeviceView:

@@ -33,14 +33,21 @@ class Transform_Pipeline:
         return ok
 
     def _constant_tables(self, fr, ct):
-        """The frequency table, the screen rows' frequencies and the LUT change only when the widget is reconfigured: their
-        contiguous copies and addresses are kept until one of the source arrays is replaced."""
+        """The frequency table, the screen rows' frequencies and the LUT as contiguous float64 / uint32 arrays and their
+        addresses.  When a source array already has that form it is passed as it is (nothing to go stale); when a converted
+        copy had to be made, the copy is kept for its address and REFRESHED from the source on every push — `ct.colors[:] = ...`
+        or any other in-place change of the widget's arrays reaches the device call like it reaches the per-block pushes
+        (ADVICE r3)."""
         t = self._tables
         if t is None or t[0] is not fr.freq or t[1] is not fr.xscaled or t[2] is not ct.colors:
             freq = np.ascontiguousarray(fr.freq, np.float64)
             targets = np.ascontiguousarray(fr.xscaled, np.float64)
             lut = np.ascontiguousarray(ct.colors, np.uint32)
             t = self._tables = (fr.freq, fr.xscaled, ct.colors, freq, targets, lut, freq.ctypes.data, targets.ctypes.data, lut.ctypes.data)
+        else:
+            for src, dst in ((t[0], t[3]), (t[1], t[4]), (t[2], t[5])):
+                if dst is not src:
+                    np.copyto(dst, src, casting="unsafe")
         return t[3:]
 
     def push(self, data):

@@ -161,7 +161,9 @@ class SpectrumAnalyzerStream(SpectrumAnalyzer):
         return self.freq, db, self.fmax, self.fpitch
 
     def _psd_dev(self, samples, n_frames):
-        """PSD frames [n_frames, bins] of a host window, left on the device (enqueued on the engine's stream, not waited for)."""
+        """PSD frames [n_frames, bins] of a host window, left on the device (enqueued on the engine's stream, not waited for).
+        frt_spectrum_post launches on the null stream, which is ordered behind blocking streams only (friture_hip.h): the
+        engine is put back on the null stream first, whatever a caller may have installed with frt_stft_set_stream."""
         torch = self._torch
         x = np.ascontiguousarray(samples, np.float64)
         nb = len(self.freq)
@@ -169,6 +171,7 @@ class SpectrumAnalyzerStream(SpectrumAnalyzer):
             self._d_psd = torch.empty((n_frames, nb), dtype=torch.float64, device=self._dev)
         nf = ctypes.c_int64(0)
         e = self._engine
+        _lib.check(e._lib.frt_stft_set_stream(e._h, None))
         _lib.check(e._lib.frt_stft_run(e._h, 0, x.ctypes.data, x.shape[0], x.shape[0], ctypes.c_void_p(self._d_psd.data_ptr()),
                                        ctypes.byref(nf)))
         assert nf.value == n_frames

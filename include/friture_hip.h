@@ -150,8 +150,10 @@ int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, int block, c
  * decimations by 2 of x [n_channels][n] -> out [n_channels][*n_out].  Needs a bands_per_octave = 0 handle. */
 int frt_decimate_multiple(frt_octbank* h, int n_stages, const double* x, int n, double* out, int* n_out);
 /* the same with the reference's functional interface (the states are arguments and results, decimate.py:45-71) as ONE call
- * on HOST arrays of one channel: zi / zf [n_stages][12] or NULL (zero state / not wanted); the handle's carried state is
- * not touched; n up to 32 Ki samples (read and written in place in page-locked memory). */
+ * on HOST arrays of one channel: zi / zf [n_stages][order] (order = the handle's decimator order: 12 for the bank's) or
+ * NULL (zero state / not wanted); the handle's carried state is not touched.  The samples are read and the result written
+ * in place in page-locked memory: roundup(8 n, 256) + 128 n_stages bytes must fit 256 KB, i.e. n <= 32 639 for two stages
+ * (FRT_ERR_INVALID above that: use frt_octbank_set_state + frt_decimate_multiple). */
 int frt_decimate_multiple_state(frt_octbank* h, int n_stages, const double* x, int n, const double* zi, double* out, int* n_out,
                                 double* zf);
 /* lfilter_float64_1D (friture/signal/lfilter.py:85-147): direct form II transposed IIR of one host
@@ -279,7 +281,14 @@ int frt_exp_smooth_2d(const double* kernel, int nk, double alpha, const double* 
  * db = 10 log10(smoothed + 1e-30) + weight_db (or - 10 log10(ref_smoothed + 1e-30) in dual-channel mode);
  * *peak_index_out = argmax(db); *pitch_index_out = argmax of the harmonic product spectrum
  * s[:K] s[::2][:K] s[::3][:K], K = n_bins / 3, of smoothed (of ref_smoothed in dual-channel mode).
- * psd / previous / weight_db / ref_smoothed / smoothed_out: all host or all device; db_out may be a host array either way. */
+ * psd / previous / weight_db / ref_smoothed / smoothed_out: all host or all device; db_out may be a host array either way.
+ * STREAM ORDER of device-resident arguments (this call and the other stateless entry points that accept device pointers:
+ * frt_freq_resample, frt_time_resample, frt_colour_map, frt_exp_smooth_2d, frt_screen_columns): the kernel is launched on
+ * the NULL stream, which is ordered behind every BLOCKING stream of the process and behind nothing else.  Whatever
+ * produced `psd` must therefore have been enqueued on the null stream or a blocking stream (the default of
+ * frt_stft_create; torch's current stream unless the caller made it a non-blocking side stream) — or be complete
+ * (hipStreamSynchronize / an event wait) before the call.  A handle whose stream was set to a hipStreamNonBlocking one with
+ * frt_stft_set_stream gives no such order. */
 int frt_spectrum_post(const void* psd, int psd_is_f32, int n_frames, int n_bins, int64_t frame_stride,
                       const double* kernel, int nk, double alpha, const double* previous, const double* weight_db,
                       const double* ref_smoothed, double* smoothed_out, double* db_out, int* peak_index_out,

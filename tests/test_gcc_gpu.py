@@ -270,6 +270,43 @@ def test_delay_object_rings_equal_host_rings(hip):
                 ref = np.concatenate([a.ringbuffer0.data_indexed(end, length), a.ringbuffer1.data_indexed(end, length)])
                 assert np.array_equal(b.window(end, length), ref), (i, end, length)
     assert a.delay_ms == b.delay_ms and a.correlation == b.correlation and a.correlation > 0
+    # the stream object's rings stay inspectable like the reference widget's (ringbuffer0 / ringbuffer1: offset, data_indexed)
+    assert b.ringbuffer0.offset == a.ringbuffer0.offset and b.ringbuffer1.offset == a.ringbuffer1.offset
+    for end, length in ((b.offset, 128), (b.offset - 1000, 2500)):
+        assert np.array_equal(b.ringbuffer0.data_indexed(end, length), a.ringbuffer0.data_indexed(end, length))
+        assert np.array_equal(b.ringbuffer1.data_indexed(end, length), a.ringbuffer1.data_indexed(end, length))
+
+
+def test_delay_object_gate_on_constant_windows(hip):
+    """The std of the gate of delay_estimator.py:127 as the device object computes it (frt_delay_window_std): numpy's value
+    on ordinary windows; exactly 0 on all-zero windows (the reference's silent case) AND on constant non-zero windows — for
+    which numpy's own std is 0 or rounding noise depending on the value and the summation order."""
+    import ctypes
+
+    import torch
+
+    from friture_amd import _lib
+    from friture_amd.delay_estimator import DelayEstimatorStream
+    b = DelayEstimatorStream(0.1)
+    b.handle_new_data(np.zeros((2, 512)))
+    rng = np.random.default_rng(17)
+    L = 4800
+    noise = rng.standard_normal(L)
+    one_off = np.full(L, 0.3)
+    one_off[L - 7] = 0.3000001
+    for w0, w1 in ((np.zeros(L), np.full(L, 0.1)), (np.full(L, 0.5), noise), (one_off, np.full(L, -3.7e-9))):
+        t0, t1 = torch.from_numpy(w0).cuda(), torch.from_numpy(w1).cuda()
+        stds = (ctypes.c_double * 2)()
+        _lib.check(hip.frt_delay_window_std(b._h, ctypes.c_void_p(t0.data_ptr()), ctypes.c_void_p(t1.data_ptr()), L, stds))
+        for got, w in zip(stds, (w0, w1)):
+            if np.all(w == w[0]):
+                assert got == 0.0
+            else:
+                assert got > 0.0 and abs(got - np.std(w)) <= 1e-12 * np.std(w)
+    # and the silent chain end to end: nothing is estimated
+    for _ in range(24):
+        b.handle_new_data(np.zeros((2, 512)))
+    assert b.delay_ms == 0. and b.correlation == 0 and b.Xcorr_extremum == 0.
 
 
 def test_delay_object_argument_checks(hip):

@@ -95,3 +95,30 @@ def test_frequency_scale_names_cover_the_reference_list():
     assert np.array_equal(fs.OctaveC.transform(f), fs.Octave.transform(f)) and np.array_equal(fs.OctaveC.inverse(f[1:] / 1e3), fs.Octave.inverse(f[1:] / 1e3))
     want = dsp.frequency_targets("octave", 20.0, 20000.0, 37)
     assert np.array_equal(fs.OctaveC.inverse(np.linspace(fs.OctaveC.transform(20.0), fs.OctaveC.transform(20000.0), 37)), want)
+
+
+def test_backend_swap_uninstall_restores_parent_attributes():
+    """install() binds the swapped modules as attributes of their parent packages (what `import pkg.sub as m` resolves);
+    uninstall() must put back what was there — or remove what was not."""
+    import sys
+    import types
+
+    from friture_amd import backend_swap
+    pkg, sig = types.ModuleType("frt_fakepkg"), types.ModuleType("frt_fakepkg.signal")
+    pkg.signal = sig
+    sig.correlation = "original correlation"
+    sys.modules["frt_fakepkg"], sys.modules["frt_fakepkg.signal"] = pkg, sig
+    sys.modules["frt_fakepkg.signal.correlation"] = "original module"
+    try:
+        for _ in range(2):                                             # a second cycle must not lose the originals either
+            backend_swap.install("frt_fakepkg")
+            import friture_amd.audioproc
+            import friture_amd.signal.correlation
+            assert pkg.audioproc is friture_amd.audioproc and sig.correlation is friture_amd.signal.correlation
+            assert sys.modules["frt_fakepkg.signal.correlation"] is friture_amd.signal.correlation
+            backend_swap.uninstall()
+            assert sig.correlation == "original correlation" and not hasattr(pkg, "audioproc")
+            assert sys.modules["frt_fakepkg.signal.correlation"] == "original module" and "frt_fakepkg.audioproc" not in sys.modules
+    finally:
+        for k in [k for k in sys.modules if k.startswith("frt_fakepkg")]:
+            sys.modules.pop(k, None)

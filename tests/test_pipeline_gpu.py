@@ -145,3 +145,12 @@ def test_fused_transform_pipeline_equals_block_by_block(hip):
         assert np.array_equal(got, want), step
         assert np.array_equal(fused[1].old_data, plain[1].old_data)
         assert (fused[1].orig_index, fused[1].resampled_index) == (plain[1].orig_index, plain[1].resampled_index)
+        if step == 30:
+            # in-place changes of the blocks' arrays (no setter involved) must reach the fused call like they reach the
+            # per-block pushes: a float32 LUT copy forces the fused path to keep a converted copy, then mutate it
+            for b in (fused, plain):
+                b[2].colors = b[2].colors.astype(np.uint64)          # not uint32: the fused path converts
+        if step == 33:
+            for b in (fused, plain):
+                b[2].colors[:] = b[2].colors[::-1].copy()            # in place
+                b[0].xscaled[:] = b[0].xscaled * 0.999               # in place
