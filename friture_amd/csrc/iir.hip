@@ -1476,7 +1476,10 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
                 const int slice_min = use_vector_alu ? 8 : 16;
                 const long long colwaves = ((long long)h->n_channels * a.nchunks + cols_per_wave - 1) / cols_per_wave;
                 static const int max_slices = getenv("FRT_ZS_MAX_SLICES") ? atoi(getenv("FRT_ZS_MAX_SLICES")) : kMaxSlices;      // A/B runs
-                static const int wave_goal = getenv("FRT_ZS_WAVE_GOAL") ? atoi(getenv("FRT_ZS_WAVE_GOAL")) : 2048;
+                // (round 4: one wavefront per CU is where splitting K stops paying — every doubling adds the partial sums'
+                // traffic and, from 2 slices on, a launch that sums them: 2048 -> 256 took configs[4]'s 216-band bank from
+                // 0.90 to 0.72 ms and configs[2]'s from 0.72 to 0.70, profiles/r04_zero_state_slices.txt)
+                static const int wave_goal = getenv("FRT_ZS_WAVE_GOAL") ? atoi(getenv("FRT_ZS_WAVE_GOAL")) : device_cu_count();
                 while (n_slices < max_slices && colwaves * n_slices < wave_goal && a.chunk % (2 * n_slices * slice_min) == 0) n_slices *= 2;      // whole K-blocks per slice
                 ZeroStateArgs z{};
                 z.x = a.x; z.x_stride = a.x_stride; z.n = a.n; z.in_f32 = a.in_f32;
