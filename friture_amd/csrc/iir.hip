@@ -68,6 +68,8 @@ struct IirStageArgs {
     double* eblock;            // [C][nblocks][nbands] zero-state block energies or null
     int eblock_len;            // samples of this stage per energy block (power of two)
     int eblock_shift;          // log2(eblock_len)
+    int eblock_mul;            // lane kernel: this stage's energy block spans eblock_mul entries of the block axis (its value goes to the
+                               // last of them, zeros to the others): stages whose share of an internal block is under 4 samples
     int nblocks;
     int nbands;
     int band_index[kMaxFilters];    // global band index of each filter (-1 for the decimator)
@@ -522,11 +524,15 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0) {
                 }
             }
             if (energy && ((k + 4) & (elen - 1)) == 0 && valid) {
-                const long long blk = (s0 + k) >> a.eblock_shift;
+                const long long blk = ((s0 + k) >> a.eblock_shift) * a.eblock_mul;      // first entry of the block axis this block spans
 #pragma unroll
                 for (int m = 0; m < NF; ++m) {
                     const int band = a.band_index[f0 + m];
-                    if (band >= 0) a.eblock[((size_t)c * a.nblocks + blk) * a.nbands + band] = alpha[m] * acc[m];
+                    if (band >= 0) {
+                        double* e = a.eblock + ((size_t)c * a.nblocks + blk) * a.nbands + band;
+                        for (int i = 0; i + 1 < a.eblock_mul; ++i) e[(size_t)i * a.nbands] = 0.0;
+                        e[(size_t)(a.eblock_mul - 1) * a.nbands] = alpha[m] * acc[m];
+                    }
                 }
             }
         }
@@ -918,17 +924,19 @@ constexpr int kEnergyThreads = 256;
 constexpr int kEnergyPerThread = 8;                                   // tile = 2048 values
 static_assert((kMaxFilters - 1) * kNOctave <= kEnergyThreads, "one recurrence thread per band");
 
+// `sub`: the block axis is `sub` times finer than the caller's blocks (a time-parallel chunk shorter than the block, see
+// frt_octbank_energies): the recurrence runs over every entry, every sub-th value is an output.
 __global__ void __launch_bounds__(kEnergyThreads) energy_scan_kernel(const double* __restrict__ eblock,
                                                                      const double* __restrict__ decay_n, double* __restrict__ smooth,
                                                                      void* __restrict__ out, int out_f32, int nblocks, int nbands,
-                                                                     const double* __restrict__ weight_db, int as_db) {
+                                                                     const double* __restrict__ weight_db, int as_db, int sub) {
     __shared__ double tile[kEnergyThreads * kEnergyPerThread];
     __shared__ double seg_end[kEnergyThreads], seg_pow[kEnergyThreads], seg_carry[kEnergyThreads];
     const int c = blockIdx.x, tid = threadIdx.x;
     const int tile_blocks = kEnergyThreads * kEnergyPerThread / nbands;      // whole blocks per tile (nbands <= 256)
     const int tile_vals = tile_blocks * nbands;
     const double* src = eblock + (size_t)c * nblocks * nbands;
-    const size_t obase = (size_t)c * nblocks * nbands;
+    const size_t obase = (size_t)c * (nblocks / sub) * nbands;
     double prev = tid < nbands ? smooth[(size_t)c * nbands + tid] : 0.0;
     double pre[kEnergyPerThread];
     auto fetch = [&](int b0) {
@@ -986,9 +994,11 @@ __global__ void __launch_bounds__(kEnergyThreads) energy_scan_kernel(const doubl
         __syncthreads();
         const int vals = nb * nbands;
         for (int i = tid; i < vals; i += kEnergyThreads) {
+            const int bi = b0 + i / nbands, band = i % nbands;
+            if ((bi + 1) % sub != 0) continue;
             double v = tile[i];
-            if (as_db) v = 10.0 * log10(v + 1e-30) + (weight_db ? weight_db[i % nbands] : 0.0);
-            const size_t o = obase + (size_t)b0 * nbands + i;
+            if (as_db) v = 10.0 * log10(v + 1e-30) + (weight_db ? weight_db[band] : 0.0);
+            const size_t o = obase + (size_t)(bi / sub) * nbands + band;
             if (out_f32) ((float*)out)[o] = (float)v;
             else ((double*)out)[o] = v;
         }
@@ -1030,7 +1040,7 @@ __global__ void energy_local_kernel(double* __restrict__ eblock, const double* _
 
 __global__ void energy_finish_kernel(const double* __restrict__ local, const double* __restrict__ decay_n,
                                      double* seg_end, const double* __restrict__ smooth, void* __restrict__ out,
-                                     int out_f32, int nblocks, int nbands, const double* __restrict__ weight_db, int as_db) {
+                                     int out_f32, int nblocks, int nbands, const double* __restrict__ weight_db, int as_db, int sub) {
     const int band = threadIdx.x, sp = blockIdx.x, c = blockIdx.y, nsplit = gridDim.x;
     if (band >= nbands) return;
     const int b0 = sp * kEnergySplit, b1 = (b0 + kEnergySplit) < nblocks ? (b0 + kEnergySplit) : nblocks;
@@ -1059,9 +1069,10 @@ __global__ void energy_finish_kernel(const double* __restrict__ local, const dou
             if (b + j < b1) {
                 last = e[j] + carry * pw;
                 pw *= d;
+                if ((b + j + 1) % sub != 0) continue;               // an entry inside a caller's block
                 double v = last;
                 if (as_db) v = 10.0 * log10(v + 1e-30) + w;
-                const size_t o = base + (size_t)(b - b0 + j) * nbands;
+                const size_t o = ((size_t)c * (nblocks / sub) + (size_t)((b + j) / sub)) * nbands + band;
                 if (out_f32) ((float*)out)[o] = (float)v;
                 else ((double*)out)[o] = v;
             }
@@ -1202,8 +1213,8 @@ extern "C" int frt_octbank_set_chunk(frt_octbank* h, int chunk0) {
     // A/B and tests: a negative value selects the same chunking with pass 1 run as a second recurrence
     h->zero_state_by_recurrence = chunk0 < 0;
     if (chunk0 < 0) chunk0 = -chunk0;
-    FRT_REQUIRE(chunk0 == 0 || (chunk0 >= 1024 && chunk0 % 64 == 0),
-                "frt_octbank_set_chunk: chunk %d must be 0 (sequential) or a multiple of 64, at least 1024", chunk0);
+    FRT_REQUIRE(chunk0 == 0 || (chunk0 >= 256 && chunk0 % 64 == 0),
+                "frt_octbank_set_chunk: chunk %d must be 0 (sequential) or a multiple of 64, at least 256", chunk0);
     h->chunk0 = chunk0;
     return FRT_OK;
 }
@@ -1453,6 +1464,11 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
         a.xnext_stride = j + 1 < kNOctave ? len[j + 1] : 0;
         a.eblock = d_eblock;
         a.eblock_len = d_eblock ? (eblock0 >> j) : 1;
+        a.eblock_mul = 1;
+        while (d_eblock && a.eblock_len < 4) {                  // (only when the block axis is finer than 1024 samples: see frt_octbank_energies)
+            a.eblock_len <<= 1;
+            a.eblock_mul <<= 1;
+        }
         a.eblock_shift = 0;
         while ((1 << a.eblock_shift) < a.eblock_len) ++a.eblock_shift;
         a.nblocks = nblocks;
@@ -1513,7 +1529,10 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
             a.fused = (d_y == nullptr && d_eblock != nullptr && !exact_ops) ? 1 : 0;
             a.n_channels = h->n_channels;
             if (lane_kernel_serves(a, h->h_order.data())) rc = launch_iir_lane(a, h->n_channels, h->stream);
-            else rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream);
+            else {
+                FRT_REQUIRE(a.eblock_mul == 1, "octave bank: a chunk shorter than the energy block needs 16-byte aligned device input in whole chunks");
+                rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream);
+            }
             if (rc) return rc;
             a.fused = 0;
         }
@@ -1661,19 +1680,29 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
     FRT_REQUIRE(chunk_call || (block >= 256 && (block & (block - 1)) == 0), "frt_octbank_energies: block %d must be a power of two >= 256", block);
     FRT_REQUIRE(h->mode == 0 || block <= 1024, "frt_octbank_energies: the FFT bank's cadence is blocks of at most 1024 samples");
     FRT_REQUIRE(n > 0 && n % block == 0 && n < (1ll << 31), "frt_octbank_energies: n must be a positive multiple of block");
-    FRT_REQUIRE(h->chunk0 == 0 || h->chunk0 % block == 0, "frt_octbank_energies: chunk must be a multiple of block");
+    FRT_REQUIRE(h->chunk0 == 0 || h->chunk0 % block == 0 || (h->mode == 0 && block % h->chunk0 == 0),
+                "frt_octbank_energies: chunk and block must divide one another");
     FRT_REQUIRE(x && alphas && energy_out, "frt_octbank_energies: null buffer");
-    const int nblocks = (int)(n / block);
+    // A time-parallel chunk SHORTER than the block (mode 0; more, shorter recurrences: the output pass has one lane per chunk):
+    // the block axis of the energy pipeline becomes the chunk — sp_b = E_b + sp_{b-1} (1 - alpha)^m holds for any partition of
+    // the samples into consecutive blocks — and every sub-th smoothed value is one of the caller's.
+    const int eb = (h->mode == 0 && h->chunk0 > 0 && h->chunk0 < block && !chunk_call) ? h->chunk0 : block;
+    const int sub = block / eb;
+    FRT_REQUIRE(sub == 1 || (n % h->chunk0 == 0 && is_device_pointer(x) && (uintptr_t)x % 16 == 0),
+                "frt_octbank_energies: a chunk shorter than the block needs 16-byte aligned device input in whole chunks");
+    const int nblocks = (int)(n / eb);                            // entries of the block axis
     const size_t ecount = (size_t)h->n_channels * nblocks * h->nbands;
+    const size_t ocount = ecount / sub;                           // values the caller receives
     int rc;
     std::vector<double> al(alphas, alphas + h->nbands), dn(h->nbands);
     {
         long long slen[kNOctave];
         slen[0] = block;
         for (int j = 1; j < kNOctave; ++j) slen[j] = (slen[j - 1] + 1) / 2;
-        for (int k = 0; k < h->nbands; ++k) {    // (1 - alpha)^m with m = the band's samples per block (block / dec; ceil chain for a ragged chunk)
+        for (int k = 0; k < h->nbands; ++k) {    // (1 - alpha)^m with m = the band's samples per entry (eb / dec; ceil chain for a ragged chunk)
             const int j = kNOctave - 1 - k / h->bpo;
-            dn[k] = std::pow(1.0 - al[k], (double)(chunk_call ? slen[j] : (long long)(block >> j)));
+            dn[k] = sub > 1 ? std::pow(1.0 - al[k], (double)eb / (double)(1 << j))
+                            : std::pow(1.0 - al[k], (double)(chunk_call ? slen[j] : (long long)(block >> j)));
         }
     }
     if ((rc = upload_if_changed(h->alpha, h->alpha_host, al, h->stream)) || (rc = upload_if_changed(h->decay_n, h->decay_host, dn, h->stream)) ||
@@ -1693,7 +1722,7 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
     float* d_out = energy_out;
     // host buffers of the widget-sized calls travel through the handle's pinned blocks (from pageable memory the runtime
     // stages the copy itself and blocks the caller)
-    const size_t xbytes = (size_t)h->n_channels * n * sizeof(float), obytes = ecount * sizeof(float);
+    const size_t xbytes = (size_t)h->n_channels * n * sizeof(float), obytes = ocount * sizeof(float);
     const bool pinned = !dx && xbytes <= ((size_t)1 << 20) && obytes <= ((size_t)1 << 20);
     if (!dx) {
         if ((rc = h->xin.reserve(xbytes)) || (rc = h->eout.reserve(obytes))) return rc;
@@ -1744,7 +1773,7 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
         return FRT_OK;
     }
     if (h->mode == 1) rc = frt_ola_filter_batch(h, d_x, 1, n, nullptr, 0, h->eblock.as<double>(), block, nblocks, alphas);
-    else rc = run_stages(h, d_x, 1, n, (int)n, nullptr, 0, h->eblock.as<double>(), block, nblocks);
+    else rc = run_stages(h, d_x, 1, n, (int)n, nullptr, 0, h->eblock.as<double>(), eb, nblocks);
     if (rc) return rc;
     if (nblocks >= 4 * kEnergySplit) {
         const int nsplit = (nblocks + kEnergySplit - 1) / kEnergySplit, threads = (h->nbands + 63) / 64 * 64;
@@ -1753,13 +1782,13 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
                            h->decay_n.as<double>(), h->eseg.as<double>(), nblocks, h->nbands);
         hipLaunchKernelGGL(energy_finish_kernel, dim3(nsplit, h->n_channels), dim3(threads), 0, h->stream, h->eblock.as<double>(),
                            h->decay_n.as<double>(), h->eseg.as<double>(), h->smooth.as<double>(), (void*)d_out, 1, nblocks, h->nbands,
-                           weight_db ? h->weight.as<double>() : nullptr, as_db);
+                           weight_db ? h->weight.as<double>() : nullptr, as_db, sub);
         hipLaunchKernelGGL(energy_carry_kernel, dim3(h->n_channels), dim3(threads), 0, h->stream, h->eseg.as<double>(),
                            h->smooth.as<double>(), nsplit, h->nbands);
     } else {
         hipLaunchKernelGGL(energy_scan_kernel, dim3(h->n_channels), dim3(kEnergyThreads), 0, h->stream, h->eblock.as<double>(),
                            h->decay_n.as<double>(), h->smooth.as<double>(), (void*)d_out, 1, nblocks, h->nbands,
-                           weight_db ? h->weight.as<double>() : nullptr, as_db);
+                           weight_db ? h->weight.as<double>() : nullptr, as_db, sub);
     }
     FRT_HIP_CHECK(hipGetLastError());
     if (!dx) {

@@ -121,8 +121,9 @@ void frt_octbank_destroy(frt_octbank* h);
 int frt_octbank_set_stream(frt_octbank* h, void* hip_stream);
 /* zero every carried state (octave_filter_bank_decimation_filtic, friture/filter.py:121-133) */
 int frt_octbank_reset(frt_octbank* h);
-/* 0 (default): sequential in time, bit-identical to the reference.  chunk0 > 0 (multiple of 64, >= 1024;
- * a multiple of the energy block for frt_octbank_energies): batches of at least 2*chunk0 samples are
+/* 0 (default): sequential in time, bit-identical to the reference.  chunk0 > 0 (multiple of 64, >= 256; for
+ * frt_octbank_energies a multiple of the energy block, or a divisor of it — the latter for 16-byte aligned device
+ * input in whole chunks only): batches of at least 2*chunk0 samples are
  * processed time-parallel, octave stage j in chunks of max(64, chunk0 / 2^j) of its own samples.  The two modes
  * agree to ~1e-10 of the input scale (same recurrences, other association order).  A negative value selects
  * the same chunking with the zero-state pass run as a second recurrence instead of a table product (A/B runs). */

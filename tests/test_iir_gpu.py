@@ -187,6 +187,37 @@ def test_band_energies(tabs, bpo, chunk):
     assert np.max(np.abs(db - (10 * np.log10(got.astype(np.float64) + 1e-30) + A))) < 1e-3
 
 
+@pytest.mark.parametrize("chunk,nblocks", [(512, 64), (256, 48), (512, 320)])
+def test_band_energies_with_chunks_shorter_than_the_block(tabs, chunk, nblocks):
+    """A time-parallel chunk shorter than the energy block (frt_octbank_set_chunk(256 / 512) with blocks of 1024): the
+    block axis of the smoothing recurrence becomes the chunk and every second / fourth value is the caller's — the same
+    energies as the oracle's block-by-block restatement, and the carried state serves a second call."""
+    import torch
+    from friture_amd.filter import IirBank
+    bpo, C = 3, 2
+    boct, aoct = list(tabs[f"boct_{bpo}"]), list(tabs[f"aoct_{bpo}"])
+    n = 1024 * nblocks
+    x32 = np.stack([synth("noise", 2 * n, 21), synth("chirp", 2 * n, 22)])
+    alphas, kernels = dsp.band_smoothing_setup(bpo, 0.125)
+    bank = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, C)
+    bank.set_chunk(chunk)
+    xd = torch.from_numpy(x32).cuda()
+    got = torch.cat([bank.energies(xd[:, :n].contiguous(), 1024, alphas), bank.energies(xd[:, n:].contiguous(), 1024, alphas)], dim=1).cpu().numpy()
+    assert got.shape == (C, 2 * nblocks, 27)
+    for c in range(C):
+        zs = dsp.iir_bank_filtic(tabs["bdec"], tabs["adec"], boct, aoct)
+        prev = [0.0] * 27
+        for blk in range(2 * nblocks):
+            y, _, zs = dsp.iir_bank(tabs["bdec"], tabs["adec"], boct, aoct, x32[c, blk * 1024:(blk + 1) * 1024].astype(np.float64), zs)
+            prev = dsp.band_energies(y, kernels, alphas, prev)
+            ref = np.array(prev)
+            # 1e-5 per band; a band 14 decades under the block's loudest (the chirp far from it) sits at the re-association
+            # noise of the time-parallel mode (1e-10 of the signal's scale, DESIGN.md §3 K2) and is held to that instead
+            assert np.all(np.abs(got[c, blk] - ref) <= 1e-5 * ref + 1e-14 * ref.max()), (c, blk)
+    with pytest.raises(Exception):
+        bank.energies(x32[:, :n], 1024, alphas)                  # host arrays: not served with a chunk below the block
+
+
 def test_energy_recurrence_split_along_time_equals_tiled(tabs):
     """Long batches run the block-energy recurrence split along time (energy_local / energy_finish kernels, >= 256 blocks),
     short calls the one-workgroup-per-channel tile kernel: a 600-block batch (ten splits, the last one ragged) must carry
