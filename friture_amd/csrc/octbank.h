@@ -28,7 +28,7 @@ struct frt_ola_state {
     // batched path (ola.hip, ola_batch_kernel): one transform size for every stage, tables built at the first batched call;
     // its launches read the tails of `pending` and write the new ones to `pending_next`, then the two swap
     frt::DeviceBuffer pending_next;
-    frt::DeviceBuffer btw, btwl, bH, ewt;
+    frt::DeviceBuffer btw, btwl, bH, bHw, ewt;
     std::vector<long long> ewt_off;     // per band: offset of its smoothing weights in ewt
     int ewt_block = 0;
     std::vector<double> ewt_alpha;

@@ -199,6 +199,7 @@ void frt_ola_destroy(frt_octbank* h) {
     h->ola->btw.release();
     h->ola->btwl.release();
     h->ola->bH.release();
+    h->ola->bHw.release();
     h->ola->ewt.release();
     h->ola->taps.release();
     h->ola->ewt_off_dev.release();
@@ -287,6 +288,8 @@ struct OlaBatchArgs {
     const double* ewt;         // smoothing weights alpha (1 - alpha)^(elen - 1 - i), per band at ewt_off
     long long ewt_off[kMaxFilters];
     double ewr[kMaxFilters];   // (1 - alpha)^w of the band, w = lanes per energy block (see the kernel)
+    const double* Hw;          // ola_pair_kernel: [nfilt][2048] conj(H_f) / 2048 of the 2048-point transform
+    double er[kMaxFilters];    // ola_pair_kernel: 1 - alpha of the band
 };
 
 #ifndef FRT_OB_ABLATE           // experiment builds only (wrong results): 1 twiddle gathers -> one address, 2 H loads -> one address,
@@ -577,6 +580,13 @@ __global__ void __launch_bounds__(kObThreads, FRT_OB_MIN_WAVES) ola_batch_kernel
     }
 }
 
+#include "ola_wave.h"
+#if FRT_OW_TIMING
+extern "C" int frt_ow_timing_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(frt::ow_timing), sizeof(frt::ow_timing)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 static int ola_batch_tables(frt_octbank* h) {
     frt_ola_state* o = h->ola;
     if (o->bH.ptr) return FRT_OK;
@@ -606,6 +616,22 @@ static int ola_batch_tables(frt_octbank* h) {
         }
     }
     if ((rc = upload(o->bH, Hh))) return rc;
+    // ola_pair_kernel: every bin of the 2048-point transform (H[k] = H4096[2 k]), conjugated and scaled for the inverse
+    std::vector<double> Hw((size_t)nfilt * kOwN * 2);
+    for (int f = 0; f < nfilt; ++f) {
+        const double* taps = &o->h_taps[(size_t)f * kFirLength];
+        for (int k = 0; k < kOwN; ++k) {
+            long double re = 0, im = 0;
+            for (int t = 0; t < kFirLength; ++t) {
+                const int idx = (2 * k * t) & (kObF - 1);
+                re += taps[t] * ct[idx];
+                im -= taps[t] * st[idx];
+            }
+            Hw[((size_t)f * kOwN + k) * 2] = (double)(re / kOwN);
+            Hw[((size_t)f * kOwN + k) * 2 + 1] = (double)(-im / kOwN);
+        }
+    }
+    if ((rc = upload(o->bHw, Hw))) return rc;
     if ((rc = o->pending_next.reserve(o->pending.bytes))) return rc;
     return FRT_OK;
 }
@@ -641,6 +667,8 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
     frt_ola_state* o = h->ola;
     // one energy block = the whole call (the widget's chunk, any length): a band's block is its stage's whole output
     const bool whole = d_eblock && nblocks == 1 && eblock0 == n;
+    // ola_pair_kernel (ola_wave.h) for everything but that A/B path; FRT_OLA_NO_WAVE: the round-2 kernel
+    const bool use_wave = !whole && getenv("FRT_OLA_NO_WAVE") == nullptr;
     int rc;
     if ((rc = ola_batch_tables(h))) return rc;
     long long len[kNOctave];
@@ -684,6 +712,28 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
         }
         a.xnext = j + 1 < kNOctave ? h->xbuf[j + 1].as<double>() : nullptr;
         a.xnext_stride = j + 1 < kNOctave ? len[j + 1] : 0;
+        if (use_wave) {
+            // one workgroup of ola_pair_kernel per set of 3072 outputs; the stage has len + 511 of them (the last 511 are the new
+            // tails).  Filter groups repeat the forward transform: as many as make the launch's rounds x transforms per
+            // workgroup smallest (four workgroups fit a CU)
+            a.Hw = o->bHw.as<double>();
+            for (int i = 0; i < h->bpo; ++i) a.er[i] = d_eblock ? 1.0 - o->ewt_alpha[a.band_index[i]] : 0.0;
+            const long long nsets = (len[j] + kTail + kOwSet - 1) / kOwSet, slots = 4ll * device_cu_count();
+            long long best = -1;
+            int best_groups = 1;
+            for (int g = 1; g <= h->nfilt; ++g) {
+                const int gs = (h->nfilt + g - 1) / g, g2 = (h->nfilt + gs - 1) / gs;
+                const long long rounds = (nsets * h->n_channels * g2 + slots - 1) / slots, cost = rounds * (1 + gs);
+                if (best < 0 || cost < best) {
+                    best = cost;
+                    best_groups = g2;
+                }
+            }
+            a.gsize = (h->nfilt + best_groups - 1) / best_groups;
+            hipLaunchKernelGGL(ola_pair_kernel, dim3((unsigned)nsets, best_groups, h->n_channels), dim3(kOwThreads), 0, h->stream, a);
+            FRT_HIP_CHECK(hipGetLastError());
+            continue;
+        }
         const long long nblk = (len[j] + kObL - 1) / kObL;
         // filter groups: every workgroup repeats the forward transform of its window, so as few groups as still fill the chip
         int groups = 1;
