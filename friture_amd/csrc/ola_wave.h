@@ -59,11 +59,6 @@ __device__ __forceinline__ cpx<double> ow_tw16(cpx<double> v) {
         return {v.x * wr - v.y * wi, v.x * wi + v.y * wr};
     }
 }
-// The workgroup's barrier with the LDS operations waited for and nothing else: __syncthreads() also drains the vector memory
-// counter, i.e. every table load requested a transform ahead and every output store would be waited for at the next barrier
-// (measured: 69 % of the wave-cycles in s_waitcnt).  Nothing here communicates through global memory inside a launch.
-__device__ __forceinline__ void ow_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // 16-point DFT of v[0..15] inside a thread: in v[i + 4 s], out bin q + 4 r at v[r + 4 q]
 __device__ __forceinline__ void ow_dft16(cpx<double> (&v)[16]) {
 #pragma unroll
@@ -127,7 +122,7 @@ __device__ __forceinline__ void ow_fft(cpx<double> (&v)[16], cpx<double>* xb, in
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) wr[8 * (q + 4 * r)] = v[r + 4 * q];
-        ow_sync();
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = xb[t + 128 * j];
     }
@@ -136,7 +131,7 @@ __device__ __forceinline__ void ow_fft(cpx<double> (&v)[16], cpx<double>* xb, in
     ow_twiddle16(v, w128);
     OW_T(4);
     asm volatile("" : "+v"(t));
-    ow_sync();                     // exchange 1 has been read by everybody
+    __syncthreads();                     // exchange 1 has been read by everybody
     {
         const int b = t & 7, k2h = t >> 4, k2l = (t >> 3) & 1;
         C* wr = xb + ((k2h ^ b) + 128 * k2l + 256 * b);
@@ -144,7 +139,7 @@ __device__ __forceinline__ void ow_fft(cpx<double> (&v)[16], cpx<double>* xb, in
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) wr[8 * (q + 4 * r)] = v[r + 4 * q];
-        ow_sync();
+        __syncthreads();
 #pragma unroll
         for (int bb = 0; bb < 8; ++bb)
 #pragma unroll
@@ -217,13 +212,13 @@ __global__ void __launch_bounds__(kOwThreads, 2) ola_pair_kernel(const OlaBatchA
         asm volatile("" : "+v"(t));
         // spectrum to natural order (bin t + 128 j in register j), conjugated: the inverse is conj(fft(conj(X) conj(H) / N)),
         // conj(H) / N being the table.  Bin k sits at k ^ ((k >> 3) & 1).
-        ow_sync();
+        __syncthreads();
         const int K0 = 2 * (t & 7) + 16 * (t >> 3), x3 = (t >> 2) & 1;
 #pragma unroll
         for (int d = 0; d < 8; ++d)
 #pragma unroll
             for (int e = 0; e < 2; ++e) xb[K0 + (e ^ x3) + 256 * d] = v[e + 2 * d];
-        ow_sync();
+        __syncthreads();
         const int R3 = t ^ ((t >> 3) & 1);
         const C* H = (const C*)a.Hw + (size_t)(grp * a.gsize) * kOwN;
 #pragma unroll
@@ -231,7 +226,7 @@ __global__ void __launch_bounds__(kOwThreads, 2) ola_pair_kernel(const OlaBatchA
             xc[j] = cconj(xb[R3 + 128 * j]);
             v[j] = cmul(xc[j], (H + 128 * j)[t]);                     // the first filter's products
         }
-        ow_sync();
+        __syncthreads();
     }
     for (int it = 0; it < nf; ++it) {
         const int f = grp * a.gsize + it;
@@ -262,7 +257,7 @@ __global__ void __launch_bounds__(kOwThreads, 2) ola_pair_kernel(const OlaBatchA
         const double rr = a.er[f];
         double* eo = a.eblock + ((size_t)ch * a.nblocks) * a.nbands + a.band_index[f];
         const int nleft = (int)((n - S) < kOwSet + kTail ? (n - S) : kOwSet + kTail);      // outputs of the stage in this set (tau < nleft)
-        if (tail_set) ow_sync();                                     // xb is written below: the transform's last reads are done
+        if (tail_set) __syncthreads();                                     // xb is written below: the transform's last reads are done
         double contrib[12];
 #pragma unroll
         for (int win = 0; win < 2; ++win)
@@ -294,7 +289,7 @@ __global__ void __launch_bounds__(kOwThreads, 2) ola_pair_kernel(const OlaBatchA
             }
         if (tail_set) {
             // elements of the runs that straddle the stage's end, and the new tails: outputs n .. n + 510 of the stage
-            ow_sync();
+            __syncthreads();
             const double* res = (const double*)xb;
             double* po = a.pend_out + ((size_t)ch * a.nfilt + f) * kTail;
             const int nout = nleft < 0 ? 0 : nleft < kOwSet ? nleft : kOwSet;        // tau < nout: samples of the stage
@@ -343,7 +338,7 @@ __global__ void __launch_bounds__(kOwThreads, 2) ola_pair_kernel(const OlaBatchA
                         const double e = group_sum(part[i], 64);
                         if (lane == 0) wsum[t >> 6][i] = e;
                     }
-                ow_sync();
+                __syncthreads();
                 if (t < np) {
                     const long long eg = (S >> (31 - __builtin_clz(m))) * 1 + t;
                     if (eg < a.nblocks) eo[(size_t)eg * a.nbands] = wsum[0][t] + wsum[1][t];
@@ -351,7 +346,7 @@ __global__ void __launch_bounds__(kOwThreads, 2) ola_pair_kernel(const OlaBatchA
             }
         }
         OW_T(7);
-        ow_sync();                                                   // xb and wsum are free again
+        __syncthreads();                                                   // xb and wsum are free again
         if (it + 1 < nf) {
             // the next filter's products.  (Its response requested earlier — before the transform, or before the outputs — does
             // not fit the 256 registers beside the spectrum: the allocator then spills the spectrum and brings it back one value

@@ -138,7 +138,7 @@ def test_batched_bank_ragged_and_short_batches(hip):
             assert np.max(np.abs(got[0][k] - want)) <= 1e-11 * max(np.max(np.abs(want)), 1e-3), (n, k)
 
 
-@pytest.mark.parametrize("bpo,block", [(3, 1024), (24, 1024), (3, 256)])
+@pytest.mark.parametrize("bpo,block", [(3, 1024), (24, 1024), (3, 256), (3, 512)])
 def test_batched_bank_energies(hip, bpo, block):
     """frt_octbank_energies on the FIR bank: smoothed band energies per block (octavespectrum.py:101-121) against the
     oracle's OlaBank + exp smoothing fed block by block; 1e-5 is the north star's band-energy tolerance (measured 1e-12),
@@ -158,6 +158,35 @@ def test_batched_bank_energies(hip, bpo, block):
             want = np.array(prev)
             # (a band that has not responded yet holds rounding noise of the transform, 1e-30 of the loudest band)
             assert np.all(np.abs(got[c, b] - want) <= 1e-5 * want + 1e-20 * want.max()), (c, b)
+
+
+@pytest.mark.parametrize("bpo,block", [(3, 1024), (24, 512)])
+def test_pair_kernel_equals_round2_kernel_on_a_long_batch(hip, bpo, block, monkeypatch):
+    """ola_pair_kernel (two real windows per complex transform, csrc/ola_wave.h) against the round-2 kernel (one real 4096-point
+    transform per workgroup; FRT_OLA_NO_WAVE=1) on a batch long enough for interior sets at every octave stage (2^18 samples,
+    an odd tail length in the second call): band signals to 1e-11 of each band's maximum, the float32 band energies to 1e-6, the
+    carried tails compared through a third call."""
+    from friture_amd.filter import FirBank
+    C, n = 2, 1 << 18
+    x = np.stack([synth("noise", n + 5000, 11 + c) for c in range(C)]).astype(np.float64)
+    alphas, _ = dsp.band_smoothing_setup(bpo, 0.125)
+    out = {}
+    for name in ("pair", "round2"):
+        if name == "round2":
+            monkeypatch.setenv("FRT_OLA_NO_WAVE", "1")
+        fb, eb = FirBank(bpo, C), FirBank(bpo, C)
+        out[name] = (fb.filter(x[:, :n])[0], fb.filter(x[:, n:n + 4097])[0], fb.filter(x[:, n + 4097:n + 5000])[0],
+                     eb.energies(x[:, :n].astype(np.float32), block, alphas))
+    monkeypatch.delenv("FRT_OLA_NO_WAVE")
+    for call in range(3):
+        for c in range(C):
+            for k in range(9 * bpo):
+                a, b = out["pair"][call][c][k], out["round2"][call][c][k]
+                assert a.shape == b.shape
+                assert np.max(np.abs(a - b)) <= 1e-11 * max(np.max(np.abs(b)), 1e-3), (call, c, k)
+    ea, eb_ = out["pair"][3], out["round2"][3]
+    assert ea.shape == (C, n // block, 9 * bpo)
+    assert np.all(np.abs(ea - eb_) <= 1e-6 * eb_ + 1e-20 * eb_.max())
 
 
 @pytest.mark.parametrize("bpo", [1, 3, 24])
