@@ -310,7 +310,7 @@ def stft16384_leg(dev, world, rank, consts):
                 "value": world * ch * F / dt, "unit": "spectra/s", "ms_per_step": dt * 1e3,
                 "config": f"{ch} ch/GPU x 2^20 samples, N = {n_fft}, hop {hop}, "
                           f"{'dB + A-weighting + colour LUT -> u32 pixels' if kind == 3 else 'PSD'}, three batches rotated",
-                "roofline": {"bound": "hbm", "kernel": "stft_pk_kernel", "unit": "GB/s", "achieved": bytes_per_launch / (ev_ms * 1e-3) / 1e9,
+                "roofline": {"bound": "hbm", "kernel": "stft_pk16_kernel", "unit": "GB/s", "achieved": bytes_per_launch / (ev_ms * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "frac": bytes_per_launch / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": ev_ms}}
             del outs

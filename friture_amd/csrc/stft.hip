@@ -21,6 +21,7 @@
 
 #include "stft_big.h"
 #include "stft_pk.h"
+#include "stft_pk16.h"
 
 namespace frt {
 
@@ -40,6 +41,22 @@ static int launch_pk(const StftArgs& a, hipStream_t stream) {
     return FRT_OK;
 }
 
+// the same with the sub-transforms factored 16 x 16 x 2 (stft_pk16.h)
+template <int HS>
+static int launch_pk16(const StftArgs& a, hipStream_t stream) {
+    const dim3 grid(a.n_groups), block(Pk16Plan::BLOCK);
+    switch (a.kind) {
+        case FRT_STFT_PSD: hipLaunchKernelGGL((stft_pk16_kernel<0, HS>), grid, block, 0, stream, a); break;
+        case FRT_STFT_IMAGE:
+            if (a.eps_free) hipLaunchKernelGGL((stft_pk16_kernel<4, HS>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((stft_pk16_kernel<3, HS>), grid, block, 0, stream, a);
+            break;
+        default: hipLaunchKernelGGL((stft_pk16_kernel<1, HS>), grid, block, 0, stream, a); break;
+    }
+    FRT_HIP_CHECK(hipGetLastError());
+    return FRT_OK;
+}
+
 // ---- host side -----------------------------------------------------------------------------------
 
 template <typename T, int LOG2M>
@@ -51,7 +68,12 @@ static int launch_big_one(const StftArgs& a, hipStream_t stream) {
         const bool aligned16 = ((uintptr_t)a.x % 16 == 0) && (a.x_stride % 4 == 0) && (a.hop % 4 == 0);
         if constexpr (LOG2M == PkPlan::LOG2M) {
             static const bool no_pk = getenv("FRT_STFT_NO_PK") != nullptr;       // A/B runs: round 3's instance
+            static const bool pk16 = getenv("FRT_STFT_NO_PK16") == nullptr;      // A/B runs: stft_pk_kernel (8 x 8 x 8 sub-transforms)
             if (aligned16 && !no_pk && !getenv("FRT_STFT_NO_DMA")) {
+                if (pk16) {
+                    if (a.hop == B::M) return launch_pk16<8>(a, stream);
+                    if (a.hop == B::M / 2) return launch_pk16<4>(a, stream);
+                }
                 if (a.hop == B::M) return launch_pk<8>(a, stream);
                 if (a.hop == B::M / 2) return launch_pk<4>(a, stream);
             }
