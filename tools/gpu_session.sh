@@ -35,3 +35,7 @@ python tools/bench_gcc.py 2>/dev/null | grep -v "^{" > gpurun_out/${TAG}_gcc_bat
 echo "== banks and latency"
 python tools/bench_firbank.py > gpurun_out/${TAG}_banks.json 2>&1; cut -c1-250 gpurun_out/${TAG}_banks.json
 python tools/stream_latency.py > gpurun_out/${TAG}_stream_latency.json 2>gpurun_out/stream_latency.err; head -c 300 gpurun_out/${TAG}_stream_latency.json
+echo "== N = 16384: stft_pk_kernel (FRT_STFT_NO_PK16=1) against stft_pk16_kernel, same session"
+( for cfg in "16384 8192 32 20 0" "16384 8192 32 20 3" "16384 4096 32 20 0" "16384 4096 32 20 3"; do echo "pk  : $(FRT_STFT_NO_PK16=1 tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; echo "pk16: $(tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; done ) > gpurun_out/${TAG}_stft16384_pk16_ab.txt 2>&1; cat gpurun_out/${TAG}_stft16384_pk16_ab.txt
+echo "== overlap-add bank: launch durations per octave stage (ola_pair_kernel / FRT_OLA_NO_WAVE=1: ola_batch_kernel)"
+bash tools/exp/session_r4p.sh > gpurun_out/${TAG}_ola_stage_times.txt 2>&1; head -12 gpurun_out/${TAG}_ola_stage_times.txt
