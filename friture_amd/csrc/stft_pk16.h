@@ -137,6 +137,18 @@ __global__ void __launch_bounds__(Pk16Plan::BLOCK, 2) stft_pk16_kernel(const Stf
     };
     if (nfr > 0) copy_slots(f0, 0, 16, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if FRT_PK_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    const unsigned long long run_t0 = __builtin_amdgcn_s_memtime(), run_r0 = __builtin_amdgcn_s_memrealtime();
+#define PK_TICK(i)                                                         \
+    do {                                                                   \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime();     \
+        if ((i) >= 0) tacc[(i) < 0 ? 0 : (i)] += now__ - tprev;            \
+        tprev = now__;                                                     \
+    } while (0)
+#else
+#define PK_TICK(i) do { } while (0)
+#endif
 
     // ---- first stage of frame g (ph = g mod PH, compile time): samples from the wave's ring slots, window, 16-point DFT over j
     pk2 v[16];
@@ -155,8 +167,12 @@ __global__ void __launch_bounds__(Pk16Plan::BLOCK, 2) stft_pk16_kernel(const Stf
 
     auto frame = [&](auto phc, int g) -> bool {
         if (g >= nfr) return false;
+        PK_TICK(-1);
         first_stage(phc, g);
+        PK_TICK(0);
+        PK_TICK(1);
         __syncthreads();                                            // A: the previous frame's unpack has read the regions
+        PK_TICK(2);
         lds_wr(tr_lane, v[0]);
 #pragma unroll
         for (int k0 = 1; k0 < 15; k0 += 2) {
@@ -166,7 +182,9 @@ __global__ void __launch_bounds__(Pk16Plan::BLOCK, 2) stft_pk16_kernel(const Stf
         }
         v[15] = pk_cmul(v[15], tw1[14]);
         lds_wr(tr_lane + 15 * (RS * 8), v[15]);
+        PK_TICK(3);
         __syncthreads();                                            // B
+        PK_TICK(4);
         // ---- 2. sixteen 512-point transforms over n1, one per half-wave: LDS traffic of a wave is executed in order and the
         // accesses are volatile, so the exchange between the two passes needs no fence
 #pragma unroll
@@ -191,7 +209,9 @@ __global__ void __launch_bounds__(Pk16Plan::BLOCK, 2) stft_pk16_kernel(const Stf
         }
 #pragma unroll
         for (int w = 0; w < 16; ++w) lds_wr(fw + w * 128, v[w]);
+        PK_TICK(5);
         __syncthreads();                                            // C
+        PK_TICK(6);
         // ---- 3. Z = T_0 +- T_1 and the conjugate-symmetric unpack of the pairs (k, M - k), (k + 4096, 4096 - k), k = 4 t + c ---
         float* row = (float*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
         uint32_t* prow = (uint32_t*)row;
@@ -303,6 +323,7 @@ __global__ void __launch_bounds__(Pk16Plan::BLOCK, 2) stft_pk16_kernel(const Stf
                 }
             }
         }
+        PK_TICK(7);
         return true;
     };
     for (int g = 0; g < nfr; g += PH) {
@@ -313,6 +334,17 @@ __global__ void __launch_bounds__(Pk16Plan::BLOCK, 2) stft_pk16_kernel(const Stf
             if (!frame(std::integral_constant<int, 3>{}, g + 3)) break;
         }
     }
+#if FRT_PK_TIMING
+    // interval i of this wave, summed over the run's frames (tools/exp/pk_timing.py): 0 copy wait + ring reads + window + DFT16,
+    // 1 -, 2 barrier A, 3 transpose writes, 4 barrier B, 5 the two radix-16 passes, 6 barrier C, 7 unpack + stores
+    if (lane == 0 && nfr > 0) {
+        float* row = (float*)a.out + chan * a.out_cstride + f0 * (M + 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) row[wave * 8 + i] = (float)tacc[i] / (float)nfr;
+        row[64 + wave] = (float)(__builtin_amdgcn_s_memtime() - run_t0) / (float)(__builtin_amdgcn_s_memrealtime() - run_r0) * 0.1f;
+    }
+#endif
+#undef PK_TICK
 }
 
 }  // namespace frt
