@@ -10,7 +10,7 @@
 //       smoothed = 0.3 Xcorr + 0.7 old;  i = argmax |smoothed|;  delay_ms = 1e3 i / rate (wrapped);
 //       confidence from |smoothed[i]| / (3 std(smoothed))
 //
-// Kernel shape: one workgroup of 1024 threads per channel pair / window, float64.  A real
+// Kernel shape: one workgroup of kGccThreads (512) threads per channel pair / window, float64.  A real
 // transform of length L is a complex transform of length M = L/2; M = R * M2 is split DIT-wise
 // into R interleaved sub-transforms of length M2 <= 6144 so that one sub-transform (96 KB of
 // complex doubles) fits in LDS next to nothing else; sub-spectra and the cross spectrum pass
@@ -25,9 +25,12 @@
 
 namespace frt {
 
-constexpr int kGccThreads = 1024;
+#ifndef FRT_GCC_THREADS          // threads per workgroup of every kernel here.  Measured 256 / 384 / 512 / 768 / 1024 (1024 pairs of the default
+#define FRT_GCC_THREADS 512      // window): 0.82 / 0.70 / 0.60 / 0.61 / 0.64 ms — half as many waves at the barriers, twice the points per thread
+#endif
+constexpr int kGccThreads = FRT_GCC_THREADS;
 constexpr int kGccMaxM2 = 6144;
-constexpr int kGccMaxB = 3;            // ceil((6144 / 2) / 1024)
+constexpr int kGccMaxB = (kGccMaxM2 / 2 + kGccThreads - 1) / kGccThreads;      // radix-2 butterflies of the largest sub-transform per thread
 constexpr int kGccMaxR = 4;
 
 struct GccArgs {
@@ -556,7 +559,7 @@ __global__ void __launch_bounds__(kGccThreads) gcc_readout_kernel(const double* 
 
 
 // ---- the same transform as three phases of SMALL workgroups ---------------------------------------------------------
-// gcc_phat_kernel keeps a window pair in one 1024-thread workgroup: a batch of 100 pairs (BASELINE configs[4]) then
+// gcc_phat_kernel keeps a window pair in one workgroup: a batch of 100 pairs (BASELINE configs[4]) then
 // occupies 100 of the 256 CUs.  For batches that do not fill the chip the work of a pair is dealt to more workgroups —
 // 2 R forward sub-transforms, the cross spectrum in slices, R inverse sub-transforms — at the price of four kernel
 // boundaries; every phase reads what the previous one left in the pair's scratch slab (same layout as above).
