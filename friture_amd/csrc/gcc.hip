@@ -44,6 +44,7 @@ struct GccArgs {
     const double* tw2;     // per-pass twiddle tables of the M2-point plan (fft_mixed.h, make_pass_twiddles)
     const double* tws;     // tables of the compile-time plan (fft_static.h) when M2 = 6000
     const double* twl;     // [M+1] exp(-2 pi i k / L)
+    const double* dw;      // [M+1] complex: rfft(window) — the mean of a signal leaves its spectrum as mean * dw (gcc_phat_kernel)
     double* scratch;       // [pairs][4 M + 2] complex
     MixedPlan plan;        // for M2
     int L, M, M2, R;
@@ -245,6 +246,32 @@ __device__ __forceinline__ double gcc_forward_signal(const GccArgs& a, const dou
     return mean;
 }
 
+// dw[k] = rfft(window)[k], k <= M = L / 2, by the definition (compensated sums; the twiddles are the table's own entries:
+// exp(-2 pi i j / L) = twl[j] for j <= M, conj(twl[L - j]) above).  Runs once per handle.
+__global__ void __launch_bounds__(256) gcc_window_rfft_kernel(const double* __restrict__ window, const double* __restrict__ twl, int L, int M,
+                                                              double* __restrict__ dw) {
+    using C = cpx<double>;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k > M) return;
+    const C* tw = (const C*)twl;
+    double sr = 0.0, si = 0.0, cr = 0.0, ci = 0.0;
+    int j = 0;                                           // n k mod L
+    for (int n = 0; n < L; ++n) {
+        const C e = j <= M ? tw[j] : cconj(tw[L - j]);
+        const double w = window[n];
+        const double yr = w * e.x - cr, tr = sr + yr;
+        cr = (tr - sr) - yr;
+        sr = tr;
+        const double yi = w * e.y - ci, ti = si + yi;
+        ci = (ti - si) - yi;
+        si = ti;
+        j += k;
+        if (j >= L) j -= L;
+    }
+    dw[2 * k] = sr;
+    dw[2 * k + 1] = si;
+}
+
 // One window pair per workgroup, everything between the two signals and the correlation in this launch.  What passes
 // through the pair's scratch slab is only what cannot stay on the CU: of the 2 R sub-spectra (M2 complex each, one LDS
 // array's worth) all but the last, which the cross spectrum reads where the transform left it.  The cross spectrum itself
@@ -294,37 +321,28 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
     C* Zi = S + 2 * (size_t)M + (M + 1);                         // [M] packed inverse input (R = 4 only)
     const C* twm = (const C*)a.twm;
     const C* twl = (const C*)a.twl;
+    const C* dwt = (const C*)a.dw;
 
     GCC_STAMP(0);
-    // ---- means -----------------------------------------------------------------------------------------------
-    double mean[2];
-    {
-        // (one load per trip and signal: eight in flight per thread — gcc_thread_sum — measured 5 % SLOWER for the kernel as a
-        // whole at 1 and at 1024 pairs; this kernel's workgroups are alone on their CUs and meet HBM in bursts either way)
-        double acc0 = 0.0, acc1 = 0.0;
-        for (int t = tid; t < L; t += kGccThreads) {
-            acc0 += sig[0][t];
-            acc1 += sig[1][t];
-        }
-        mean[0] = block_sum(acc0, red) / (double)L;
-        mean[1] = block_sum(acc1, red) / (double)L;
-    }
-    if (tid == 0 && a.means) {
-        a.means[2 * pair] = mean[0];
-        a.means[2 * pair + 1] = mean[1];
-    }
-
-    GCC_STAMP(1);
+    GCC_STAMP(1);                                        // (the means have no phase of their own any more)
     // ---- forward sub-transforms: S[s][r][k'] = FFT_M2( z_s[R m + r] ); the last one stays in LDS ---------------
+    // The mean is NOT subtracted here: (x - mean) w has the spectrum rfft(x w) - mean rfft(w), so the samples' sum is taken while
+    // they pass through on their way into the sub-transforms (every sample pair is loaded exactly once over r) and the
+    // correction mean * dw[k] is applied where the cross spectrum forms D_s[k].  The separate pass over the two windows that
+    // computed the means first was a fifth of this kernel at a full chip (28 of 150 us per pair: the chip's whole HBM stream).
+    // (Requesting the samples of the next sub-transform while the one before it runs — twelve 16-byte loads per thread held across
+    // it — was measured: 0.58 against 0.54 ms for 1024 pairs; the kernel sits at its 256 registers and spills.)
+    double mean[2];
     GccSub<R> sub;
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s) {
+        double acc = 0.0;
         for (int r = 0; r < R; ++r) {
             {
                 const double2* wn = (const double2*)a.window;
-                const double mu = mean[s];
                 for (int m = tid; m < M2; m += kGccThreads) {
                     const double2 x = gcc_pair_at(sig[s], R * m + r, a.vec), w = wn[R * m + r];
-                    buf[m] = {(x.x - mu) * w.x, (x.y - mu) * w.y};
+                    acc += x.x + x.y;
+                    buf[m] = {x.x * w.x, x.y * w.y};
                 }
             }
             __syncthreads();
@@ -339,6 +357,12 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
                 __syncthreads();
             }
         }
+        mean[s] = block_sum(acc, red) / (double)L;
+    }
+    if (tid == 0 && a.means) {
+        a.means[2 * pair] = mean[0];
+        a.means[2 * pair + 1] = mean[1];
+    }
     __threadfence_block();
     __syncthreads();
     GCC_STAMP(4);
@@ -354,8 +378,11 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const C Za = gcc_zfull_at<R>(sub, twm, s, k, M, M2), Zb = gcc_zfull_at<R>(sub, twm, s, km, M, M2);
-            d_lo[s] = gcc_unpack(Za, Zb, tk);               // D_s[k]
+            const C wl = dwt[k], wh = dwt[M - k];
+            d_lo[s] = gcc_unpack(Za, Zb, tk);               // D_s[k] of x w ...
             d_hi[s] = gcc_unpack(Zb, Za, tm);               // D_s[M - k]
+            d_lo[s] = {d_lo[s].x - mean[s] * wl.x, d_lo[s].y - mean[s] * wl.y};      // ... of (x - mean) w
+            d_hi[s] = {d_hi[s].x - mean[s] * wh.x, d_hi[s].y - mean[s] * wh.y};
         }
         glo = cmul(cconj(d_lo[0]), d_lo[1]);
         ghi = cmul(cconj(d_hi[0]), d_hi[1]);
@@ -1030,7 +1057,7 @@ struct frt_gcc {
     int L = 0, M = 0, M2 = 0, R = 1, n_pairs = 0;
     MixedPlan plan{};
     hipStream_t stream = nullptr;
-    DeviceBuffer window, twm, tw2, tws, twl, scratch;
+    DeviceBuffer window, twm, tw2, tws, twl, dw, scratch;
     bool static_plan = false;            // M2 = 6000: the compile-time plan of fft_static.h
     DeviceBuffer in0, in1, out, argmax, means, old, sm, stats;
     size_t lds_bytes = 0;
@@ -1043,7 +1070,7 @@ struct frt_gcc {
 extern "C" void frt_gcc_destroy(frt_gcc* h) {
     if (!h) return;
     free_retired_allocations(true);      // blocks parked by growing buffers (common.h); synchronises the device like the releases below
-    DeviceBuffer* bufs[] = {&h->window, &h->twm, &h->tw2, &h->tws, &h->twl, &h->scratch, &h->in0, &h->in1,
+    DeviceBuffer* bufs[] = {&h->window, &h->twm, &h->tw2, &h->tws, &h->twl, &h->dw, &h->scratch, &h->in0, &h->in1,
                             &h->out, &h->argmax, &h->means, &h->old, &h->sm, &h->stats,
                             &h->chirp, &h->bhat, &h->work, &h->spec, &h->twr, &h->twc, &h->gmax, &h->part_val, &h->part_idx, &h->prof};
     for (auto* b : bufs) b->release();
@@ -1119,6 +1146,18 @@ extern "C" int frt_gcc_create(frt_gcc** out, int length, int n_pairs) {
         (rc = h->scratch.reserve((size_t)n_pairs * (4 * (size_t)h->M + 2) * 2 * sizeof(double)))) {
         frt_gcc_destroy(h);
         return rc;
+    }
+    // rfft(window): the means' contribution to the spectra (gcc_phat_kernel subtracts mean * dw instead of the mean itself)
+    if ((rc = h->dw.reserve((size_t)(h->M + 1) * 16))) {
+        frt_gcc_destroy(h);
+        return rc;
+    }
+    hipLaunchKernelGGL(gcc_window_rfft_kernel, dim3((h->M + 1 + 255) / 256), dim3(256), 0, nullptr, h->window.as<double>(), h->twl.as<double>(),
+                       length, h->M, h->dw.as<double>());
+    if (hipDeviceSynchronize() != hipSuccess) {
+        set_last_error("frt_gcc_create: the window's spectrum failed");
+        frt_gcc_destroy(h);
+        return FRT_ERR_HIP;
     }
     h->lds_bytes = (size_t)h->M2 * 16 + 16 * sizeof(double) + 16 * sizeof(int);
     h->static_plan = h->M2 == kGccStaticM2 && getenv("FRT_GCC_NO_STATIC_PLAN") == nullptr;
@@ -1212,6 +1251,7 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
     a.M2 = h->M2;
     a.R = h->R;
     a.tws = h->tws.as<double>();
+    a.dw = h->dw.as<double>();
     static const bool profile = getenv("FRT_GCC_PROFILE") != nullptr;
     if (profile) {
         if ((rc = h->prof.reserve(16 * sizeof(long long)))) return rc;
