@@ -53,6 +53,25 @@ def test_gcc_lengths_against_oracle(hip, L):
         assert list(am) == [lag] * 3 and x[2, lag] < 0 < x[0, lag]
 
 
+@pytest.mark.parametrize("L", [540, 24000, 49152])
+@pytest.mark.parametrize("one_workgroup", ["0", "1"])
+def test_gcc_signals_with_a_large_mean(hip, L, one_workgroup, monkeypatch):
+    """The one-workgroup kernel takes the means while the samples pass into the sub-transforms and removes them in the spectrum
+    (mean x rfft(window), csrc/gcc.hip); the launch shape with sub-transforms as workgroups of their own subtracts them in time.
+    Signals whose mean is 10-20 times their deviation (the leakage of the mean's window spectrum reaches every bin), both shapes,
+    R = 1 / 2 / 4: same tolerance, same means as numpy."""
+    from friture_amd.signal.correlation import GccPhat
+    monkeypatch.setenv("FRT_GCC_ONE_WORKGROUP", one_workgroup)
+    rng = np.random.default_rng(7 * L)
+    d0 = 0.25 * rng.standard_normal((2, L)) + 2.5
+    d1 = np.roll(d0, 9, axis=1) - 2.5 - 4.0 + 0.02 * rng.standard_normal((2, L))
+    x, am = GccPhat(L, 2).correlate(d0, d1)
+    for p in range(2):
+        ref, _, _ = dsp.gcc_phat(d0[p], d1[p])
+        assert rel_max(x[p], ref) <= 1e-9, (L, p, rel_max(x[p], ref))
+        assert am[p] == int(np.argmax(np.abs(ref))) == 9
+
+
 @pytest.mark.parametrize("L", [2640, 14336, 26400, 50400, 232800, 1_200_000])
 def test_gcc_any_window_length(hip, L):
     """The delay-range spin box gives windows of 2400 r samples, r = 1..10000 (delay_estimator.py:114-115,222-226): most
