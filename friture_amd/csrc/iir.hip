@@ -845,22 +845,29 @@ __device__ __forceinline__ double row_matvec(const double (&m)[kStates], double 
 // consecutive rows and re-runs the two rows in front of them (halo) so that it needs nobody else's end states.
 // The output pass composes a chunk's initial state itself: chunk_init[q] + (A^L)^(q - row start) S[row]
 // (iir_stage_body, iir_lane_body).  power_l / power_g: [nfilt][16][16] row-major A^L and M.
-constexpr int kScanRows = 32;             // rows per workgroup: 2 halo + 30 owned
-constexpr int kScanOwned = kScanRows - 2;
+// Round 4: a row is at most kScanRowMax chunks.  At the low-rate stages a chunk is 64 samples and the decay takes 64 chunks: rows
+// of 64 were 64 dependent steps of ~0.3 us, 20 us per stage for a few KB of states — the largest launch of stages 4-8.  Rows of
+// 8 chunks need more than two predecessors: S[r] = sum_{k=1..K} Mr^(k-1) E[r-k], K = the rows the decay spans (Horner: K - 1
+// dependent products, all rows at once), with E[-1] = the carried state.  8 + 15 dependent steps instead of 64 + 1.
+constexpr int kScanRows = 32;             // rows per workgroup: `halo` of them re-run their predecessors', the rest are owned
+constexpr int kScanRowMax = 8;
 constexpr int kScanBatch = 8;
 
 template <int NT>
 __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l, const double* __restrict__ power_g,
                                               const double* __restrict__ state, const double* __restrict__ chunk_end,
                                               double* __restrict__ chunk_init, double* __restrict__ group_start, int gid, int seg, int f,
-                                              bool live, int nchunks, int group, int nrows, double (*gend)[kStates]) {
+                                              bool live, int nchunks, int group, int nrows, int halo, double (*gend)[kStates]) {
     const int row = threadIdx.x >> 4, s = threadIdx.x & 15;
-    const int r = seg * kScanOwned - 2 + row;                 // global row; rows 0 and 1 of the workgroup are the halo
+    const int r = seg * (kScanRows - halo) - halo + row;      // global row; the first `halo` rows of the workgroup are the halo
     const bool row_ok = r >= 0 && r < nrows;
-    const bool owned = row >= 2 && row_ok;
-    double m[kStates];
+    const bool owned = row >= halo && row_ok;
+    double m[kStates], mg[kStates];                            // (both requested up front: the second table is needed after the rows' walk)
 #pragma unroll
     for (int t = 0; t < kStates; ++t) m[t] = power_l[((size_t)f * kStates + s) * kStates + t];
+#pragma unroll
+    for (int t = 0; t < kStates; ++t) mg[t] = power_g[((size_t)f * kStates + s) * kStates + t];
+    const double s0 = live ? state[(size_t)gid * kStates + s] : 0.0;
     const double* ce = chunk_end + (size_t)gid * nchunks * kStates + s;
     double* ci = chunk_init + (size_t)gid * nchunks * kStates + s;
     const int q0 = row_ok ? r * group : 0;
@@ -888,13 +895,10 @@ __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l
     gend[row][s] = z;
     __syncthreads();
     // the true state at the start of every owned row, from its two predecessors (or the carried state next to the start)
-    double mg[kStates];
-#pragma unroll
-    for (int t = 0; t < kStates; ++t) mg[t] = power_g[((size_t)f * kStates + s) * kStates + t];
-    const double s0 = live ? state[(size_t)gid * kStates + s] : 0.0;
-    const double e1 = (row >= 1 && r >= 1) ? gend[row - 1][s] : 0.0;
-    const double e2 = (row >= 2 && r >= 2) ? gend[row - 2][s] : (r == 1 ? s0 : 0.0);
-    const double start = r == 0 ? s0 : e1 + row_matvec<NT>(mg, e2);
+    // E[r - k]: the workgroup's own rows (k <= row), the carried state for the virtual row -1, zero before it
+    auto end_of = [&](int k) -> double { return r - k >= 0 ? (k <= row ? gend[row - k][s] : 0.0) : (r - k == -1 ? s0 : 0.0); };
+    double start = end_of(halo);
+    for (int k = halo - 1; k >= 1; --k) start = end_of(k) + row_matvec<NT>(mg, start);
     if (owned) group_start[((size_t)gid * nrows + r) * kStates + s] = start;
 }
 
@@ -905,15 +909,15 @@ __global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* 
                                                                   const double* __restrict__ chunk_end,
                                                                   const int* __restrict__ order,
                                                                   double* __restrict__ chunk_init, double* __restrict__ group_start, int nfilt,
-                                                                  int nchunks, int group, int nrows, int nseg) {
+                                                                  int nchunks, int group, int nrows, int nseg, int halo) {
     __shared__ double gend[kScanRows][kStates];
     const int gid = blockIdx.x / nseg, seg = blockIdx.x - gid * nseg;      // gid: (channel, filter) pair
     const int f = gid % nfilt;
     const int ord = order[f];                                 // uniform in the workgroup
     const bool live = (int)(threadIdx.x & 15) < ord;
-    if (ord <= 4) iir_scan_body<4>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, seg, f, live, nchunks, group, nrows, gend);
-    else if (ord <= 12) iir_scan_body<12>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, seg, f, live, nchunks, group, nrows, gend);
-    else iir_scan_body<16>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, seg, f, live, nchunks, group, nrows, gend);
+    if (ord <= 4) iir_scan_body<4>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, seg, f, live, nchunks, group, nrows, halo, gend);
+    else if (ord <= 12) iir_scan_body<12>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, seg, f, live, nchunks, group, nrows, halo, gend);
+    else iir_scan_body<16>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, seg, f, live, nchunks, group, nrows, halo, gend);
 }
 
 // sp_blk = E_blk + sp_{blk-1} * (1-alpha)^n  (exp_smoothing.py:52-54), optional dB + weighting.
@@ -1308,10 +1312,16 @@ static int ensure_powers(frt_octbank* h, int n) {
     const size_t per = (size_t)kNOctave * h->nfilt * kStates * kStates;
     std::vector<double> p(2 * per);
     h->sgroup.assign(kNOctave, 1);
+    h->shalo.assign(kNOctave, 2);
     for (int j = 0; j < kNOctave; ++j) {
         const int cj = stage_chunk(h->chunk0, j);
         const int nj = (len[j] + cj - 1) / cj;
-        h->sgroup[j] = scan_group_for(h, cj, nj);
+        // g chunks make M = A^(L g) with M^2 = 0: the decay spans 2 g chunks = `halo` rows of sgroup chunks
+        const int g = scan_group_for(h, cj, nj);
+        int rg = kScanRowMax;
+        while ((2 * g + rg - 1) / rg > kScanRows / 2) rg *= 2;              // at most half of a workgroup's rows are halo
+        h->sgroup[j] = g <= rg || getenv("FRT_IIR_LONG_SCAN_ROWS") ? g : rg;
+        h->shalo[j] = g <= rg || getenv("FRT_IIR_LONG_SCAN_ROWS") ? 2 : (2 * g + rg - 1) / rg;
         for (int f = 0; f < h->nfilt; ++f) {
             const double* ac = &h->h_coef[(size_t)f * kCoefStride + kMaxOrder + 1];
             transition_power(ac, h->h_order[f], cj, &p[((size_t)j * h->nfilt + f) * kStates * kStates]);
@@ -1519,11 +1529,11 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
                                        h->chunk_end.as<double>(), slice_stride, n_slices, slice_stride);
             }
             const size_t per = (size_t)kNOctave * h->nfilt * kStates * kStates, off = (size_t)j * h->nfilt * kStates * kStates;
-            const int nseg = (a.scan_rows + kScanOwned - 1) / kScanOwned;
+            const int halo = h->shalo[j], nseg = (a.scan_rows + (kScanRows - halo) - 1) / (kScanRows - halo);
             hipLaunchKernelGGL(iir_scan_kernel, dim3((unsigned)(h->n_channels * h->nfilt * nseg)), dim3(kScanRows * 16), 0, h->stream,
                                h->power.as<double>() + off, h->power.as<double>() + per + off, a.state, h->chunk_end.as<double>(),
                                h->order.as<int>(), h->chunk_init.as<double>(), h->gstart.as<double>(), h->nfilt, a.nchunks,
-                               a.scan_group, a.scan_rows, nseg);
+                               a.scan_group, a.scan_rows, nseg, halo);
             a.pass = 2;
             static const bool exact_ops = getenv("FRT_IIR_EXACT_OPS") != nullptr;      // A/B runs
             a.fused = (d_y == nullptr && d_eblock != nullptr && !exact_ops) ? 1 : 0;
