@@ -845,12 +845,15 @@ __device__ __forceinline__ double row_matvec(const double (&m)[kStates], double 
 // consecutive rows and re-runs the two rows in front of them (halo) so that it needs nobody else's end states.
 // The output pass composes a chunk's initial state itself: chunk_init[q] + (A^L)^(q - row start) S[row]
 // (iir_stage_body, iir_lane_body).  power_l / power_g: [nfilt][16][16] row-major A^L and M.
-// Round 4: a row is at most kScanRowMax chunks.  At the low-rate stages a chunk is 64 samples and the decay takes 64 chunks: rows
+// Round 4: a row is at most kScanRowMax (16) chunks.  At the low-rate stages a chunk is 64 samples and the decay takes 64 chunks: rows
 // of 64 were 64 dependent steps of ~0.3 us, 20 us per stage for a few KB of states — the largest launch of stages 4-8.  Rows of
-// 8 chunks need more than two predecessors: S[r] = sum_{k=1..K} Mr^(k-1) E[r-k], K = the rows the decay spans (Horner: K - 1
-// dependent products, all rows at once), with E[-1] = the carried state.  8 + 15 dependent steps instead of 64 + 1.
+// 16 chunks need more than two predecessors: S[r] = sum_{k=1..K} Mr^(k-1) E[r-k], K = the rows the decay spans (Horner: K - 1
+// dependent products, all rows at once), with E[-1] = the carried state.  16 + 7 dependent steps instead of 64 + 1.
 constexpr int kScanRows = 32;             // rows per workgroup: `halo` of them re-run their predecessors', the rest are owned
-constexpr int kScanRowMax = 8;
+#ifndef FRT_SCAN_ROW_MAX
+#define FRT_SCAN_ROW_MAX 16
+#endif
+constexpr int kScanRowMax = FRT_SCAN_ROW_MAX;      // measured 4 / 8 / 16: see tools/exp/README.md
 constexpr int kScanBatch = 8;
 
 template <int NT>

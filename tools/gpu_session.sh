@@ -39,3 +39,7 @@ echo "== N = 16384: stft_pk_kernel (FRT_STFT_NO_PK16=1) against stft_pk16_kernel
 ( for cfg in "16384 8192 32 20 0" "16384 8192 32 20 3" "16384 4096 32 20 0" "16384 4096 32 20 3"; do echo "pk  : $(FRT_STFT_NO_PK16=1 tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; echo "pk16: $(tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; done ) > gpurun_out/${TAG}_stft16384_pk16_ab.txt 2>&1; cat gpurun_out/${TAG}_stft16384_pk16_ab.txt
 echo "== overlap-add bank: launch durations per octave stage (ola_pair_kernel / FRT_OLA_NO_WAVE=1: ola_batch_kernel)"
 bash tools/exp/session_r4p.sh > gpurun_out/${TAG}_ola_stage_times.txt 2>&1; head -12 gpurun_out/${TAG}_ola_stage_times.txt
+echo "== N = 8192: stft_big_kernel (FRT_STFT_NO_PK16H=1) against stft_pk16h_kernel, same session"
+( for cfg in "8192 4096 32 21 0" "8192 4096 32 21 3" "8192 2048 32 21 0" "8192 2048 32 21 3"; do echo "big  : $(FRT_STFT_NO_PK16H=1 tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; echo "pk16h: $(tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; done ) > gpurun_out/${TAG}_stft8192_ab.txt 2>&1; cat gpurun_out/${TAG}_stft8192_ab.txt
+echo "== exact IIR bank: the launches of one call"
+( cd /tmp && rm -rf /tmp/iirt && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/iirt -- python $R/tools/exp/iir_stage_times.py 8 3 22 > /dev/null 2>&1; python $R/tools/exp/iir_stage_times.py --parse /tmp/iirt ) > gpurun_out/${TAG}_iir_launches.txt 2>&1; tail -3 gpurun_out/${TAG}_iir_launches.txt
