@@ -8,23 +8,29 @@ rely on that side effect (friture/delay_estimator.py:125-132).
 from __future__ import annotations
 
 import ctypes
+import threading
 
 import numpy as np
 
 from .. import _lib
 
+# One handle per window length, shared by every caller of the module-level function; a handle owns its staging and scratch
+# buffers, so calls on it are serialised (ctypes drops the GIL for the duration of the C call: two threads asking for the same
+# length would otherwise run on the same buffers — the reference has one GUI thread, tests/test_soak_gpu.py has four).
 _plans: dict = {}
+_plans_lock = threading.Lock()
 
 
 def _plan(length: int, n_pairs: int = 1):
     key = (length, n_pairs)
-    h = _plans.get(key)
-    if h is None:
-        lib = _lib.init()
-        h = ctypes.c_void_p()
-        _lib.check(lib.frt_gcc_create(ctypes.byref(h), length, n_pairs))
-        _plans[key] = h
-    return h
+    with _plans_lock:
+        entry = _plans.get(key)
+        if entry is None:
+            lib = _lib.init()
+            h = ctypes.c_void_p()
+            _lib.check(lib.frt_gcc_create(ctypes.byref(h), length, n_pairs))
+            entry = _plans[key] = (h, threading.Lock())
+    return entry
 
 
 def generalized_cross_correlation(d0, d1):
@@ -33,10 +39,11 @@ def generalized_cross_correlation(d0, d1):
     lib = _lib.init()
     a0 = np.ascontiguousarray(d0, np.float64)
     a1 = np.ascontiguousarray(d1, np.float64)
-    h = _plan(len(a0))
+    h, busy = _plan(len(a0))
     xcorr = np.empty(len(a0), np.float64)
     means = np.empty(2, np.float64)
-    _lib.check(lib.frt_gcc_phat(h, a0.ctypes.data, a1.ctypes.data, xcorr.ctypes.data, None, means.ctypes.data))
+    with busy:
+        _lib.check(lib.frt_gcc_phat(h, a0.ctypes.data, a1.ctypes.data, xcorr.ctypes.data, None, means.ctypes.data))
     # the reference's in-place side effect on the caller's buffers
     d0 -= means[0]
     d1 -= means[1]

@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch, time
 from friture_amd import _lib, filter_design
 from friture_amd.filter import IirBank
@@ -12,7 +12,7 @@ for bpo, C, n in ((3, 8, 1 << 22), (24, 8, 1 << 20)):
     gen = torch.Generator(device="cuda").manual_seed(5)
     x = 0.25 * torch.randn((C, n), generator=gen, device="cuda", dtype=torch.float32)
     ref = None
-    for chunk in (1024, 512, 256):
+    for chunk in (2048, 1024, 512, 256):
         b = IirBank(t["bdec"], t["adec"], boct, aoct, C)
         b.set_chunk(chunk)
         out = torch.empty((C, n // 1024, 9 * bpo), dtype=torch.float32, device="cuda")
