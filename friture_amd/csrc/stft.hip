@@ -23,6 +23,7 @@
 #include "stft_pk.h"
 #include "stft_pk16.h"
 #include "stft_pk16h.h"
+#include "stft_pk16q.h"
 
 namespace frt {
 
@@ -74,6 +75,22 @@ static int launch_pk16h(const StftArgs& a, hipStream_t stream) {
     return FRT_OK;
 }
 
+// N = 4096: one more size down (stft_pk16q.h)
+template <int HS>
+static int launch_pk16q(const StftArgs& a, hipStream_t stream) {
+    const dim3 grid(a.n_groups), block(Pk16qPlan::BLOCK);
+    switch (a.kind) {
+        case FRT_STFT_PSD: hipLaunchKernelGGL((stft_pk16q_kernel<0, HS>), grid, block, 0, stream, a); break;
+        case FRT_STFT_IMAGE:
+            if (a.eps_free) hipLaunchKernelGGL((stft_pk16q_kernel<4, HS>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((stft_pk16q_kernel<3, HS>), grid, block, 0, stream, a);
+            break;
+        default: hipLaunchKernelGGL((stft_pk16q_kernel<1, HS>), grid, block, 0, stream, a); break;
+    }
+    FRT_HIP_CHECK(hipGetLastError());
+    return FRT_OK;
+}
+
 // ---- host side -----------------------------------------------------------------------------------
 
 template <typename T, int LOG2M>
@@ -93,6 +110,13 @@ static int launch_big_one(const StftArgs& a, hipStream_t stream) {
                 }
                 if (a.hop == B::M) return launch_pk<8>(a, stream);
                 if (a.hop == B::M / 2) return launch_pk<4>(a, stream);
+            }
+        }
+        if constexpr (LOG2M == Pk16qPlan::LOG2M) {
+            static const bool pk16q = getenv("FRT_STFT_NO_PK16Q") == nullptr;    // A/B runs: stft_big_kernel
+            if (aligned16 && pk16q && !getenv("FRT_STFT_NO_DMA")) {
+                if (a.hop == B::M) return launch_pk16q<8>(a, stream);
+                if (a.hop == B::M / 2) return launch_pk16q<4>(a, stream);
             }
         }
         if constexpr (LOG2M == Pk16hPlan::LOG2M) {
@@ -436,11 +460,11 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
             const int resident = h->log2m >= 13 ? 1 : h->log2m == 12 ? 2 : h->log2m == 11 ? 4 : 8;   // groups per CU
             const long long need = (long long)device_cu_count() * resident;
             auto groups = [&](int r) { return ((F + r - 1) / r) * h->n_channels; };
-            brun = h->log2m >= 12 ? 16 : h->log2m == 10 ? 32 : 8;
+            brun = h->log2m >= 11 ? 16 : h->log2m == 10 ? 32 : 8;
             while (h->log2m == 10 && brun > 8 && groups(brun) < 2 * need) brun /= 2;
             while (brun > 1 && groups(brun) < need) brun /= 2;
-            if (h->log2m >= 12) {
-                // one workgroup per CU (N = 16384) or two (N = 8192): the groups should come in whole rounds of the chip (F = 253 frames x 32 channels in
+            if (h->log2m >= 11) {
+                // one workgroup per CU (N = 16384), two (N = 8192) or four (N = 4096): the groups should come in whole rounds of the chip (F = 253 frames x 32 channels in
                 // runs of 16 are 512 groups = two rounds, the second one short; in runs of 32 one round) with runs as long as
                 // that allows (every run re-reads N - hop samples of its predecessor and loads ~120 constants per thread)
                 const long long total = (long long)F * h->n_channels;
