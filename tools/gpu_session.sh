@@ -26,7 +26,7 @@ timeout 900 python bench.py --steps 50 --warmup 5 --cpu-budget 0 --no-legs 2>/de
 echo "== large frames: rates, PMC summaries (N = 16384 and 4096)"
 ( export FRT_BENCH_SETS=4; for cfg in "16384 8192 32 20 0" "16384 8192 32 20 3" "8192 4096 32 21 0" "8192 4096 32 21 3" "4096 2048 16 22 0" "4096 1024 16 22 3" "2048 1024 8 24 0" "2048 512 8 24 3"; do tools/bin/stft_selftest bench $cfg 0 40 | tail -1; done ) > gpurun_out/${TAG}_stft_big_bench.txt 2>&1; cat gpurun_out/${TAG}_stft_big_bench.txt | cut -c1-150
 bash tools/gpu_pmc.sh ${TAG}_n16384 0 3 16384 8192 32 20 > /dev/null 2>&1; python tools/prof_summary.py pmc gpurun_out/pmc_${TAG}_n16384 stft_pk > gpurun_out/${TAG}_stft16384_pmc.txt
-bash tools/gpu_pmc.sh ${TAG}_n4096 0 3 4096 1024 16 22 > /dev/null 2>&1; python tools/prof_summary.py pmc gpurun_out/pmc_${TAG}_n4096 stft_big > gpurun_out/${TAG}_stft4096_pmc.txt
+bash tools/gpu_pmc.sh ${TAG}_n4096 0 3 4096 1024 16 22 > /dev/null 2>&1; python tools/prof_summary.py pmc gpurun_out/pmc_${TAG}_n4096 stft_pk16q > gpurun_out/${TAG}_stft4096_pmc.txt
 echo "== kernel stats of the screen-space / widget / GCC kernels (their GPU tests under rocprofv3)"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/widgets -o w -- python -m pytest $R/tests/test_pipeline_gpu.py $R/tests/test_widgets_gpu.py $R/tests/test_gcc_gpu.py -q -m gpu -p no:cacheprovider > $R/gpurun_out/prof/widgets.log 2>&1 )
 python tools/prof_summary.py stats gpurun_out/prof/widgets/w_results.db > gpurun_out/${TAG}_widgets_kernel_stats.txt 2>/dev/null; head -5 gpurun_out/${TAG}_widgets_kernel_stats.txt | cut -c1-160
