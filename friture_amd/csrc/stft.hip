@@ -24,6 +24,7 @@
 #include "stft_pk16.h"
 #include "stft_pk16h.h"
 #include "stft_pk16q.h"
+#include "stft_pk16w.h"
 
 namespace frt {
 
@@ -91,12 +92,35 @@ static int launch_pk16q(const StftArgs& a, hipStream_t stream) {
     return FRT_OK;
 }
 
+// N = 2048: one wavefront per frame (stft_pk16w.h)
+template <int HS>
+static int launch_pk16w(const StftArgs& a, hipStream_t stream) {
+    const dim3 grid(a.n_groups), block(Pk16wPlan::BLOCK);
+    switch (a.kind) {
+        case FRT_STFT_PSD: hipLaunchKernelGGL((stft_pk16w_kernel<0, HS>), grid, block, 0, stream, a); break;
+        case FRT_STFT_IMAGE:
+            if (a.eps_free) hipLaunchKernelGGL((stft_pk16w_kernel<4, HS>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((stft_pk16w_kernel<3, HS>), grid, block, 0, stream, a);
+            break;
+        default: hipLaunchKernelGGL((stft_pk16w_kernel<1, HS>), grid, block, 0, stream, a); break;
+    }
+    FRT_HIP_CHECK(hipGetLastError());
+    return FRT_OK;
+}
+
 // ---- host side -----------------------------------------------------------------------------------
 
 template <typename T, int LOG2M>
 static int launch_big_one(const StftArgs& a, hipStream_t stream) {
     using B = BigPlan<LOG2M>;
     const int blocks = (a.n_groups + B::GPB - 1) / B::GPB;
+    if constexpr (sizeof(T) == 4 && LOG2M == Pk16wPlan::LOG2M) {
+        static const bool pk16w = getenv("FRT_STFT_NO_PK16W") == nullptr;        // A/B runs: stft_big_kernel
+        if (pk16w && ((uintptr_t)a.x % 16 == 0) && (a.x_stride % 4 == 0) && (a.hop % 4 == 0)) {
+            if (a.hop == B::M) return launch_pk16w<8>(a, stream);
+            if (a.hop == B::M / 2) return launch_pk16w<4>(a, stream);
+        }
+    }
     if constexpr (sizeof(T) == 4 && LOG2M >= FRT_BIG_DMA_MIN_LOG2M) {
         // rows on 16-byte boundaries (the library's own staging buffers and torch tensors are): the LDS-DMA variant
         const bool aligned16 = ((uintptr_t)a.x % 16 == 0) && (a.x_stride % 4 == 0) && (a.hop % 4 == 0);
@@ -460,15 +484,15 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
             const int resident = h->log2m >= 13 ? 1 : h->log2m == 12 ? 2 : h->log2m == 11 ? 4 : 8;   // groups per CU
             const long long need = (long long)device_cu_count() * resident;
             auto groups = [&](int r) { return ((F + r - 1) / r) * h->n_channels; };
-            brun = h->log2m >= 11 ? 16 : h->log2m == 10 ? 32 : 8;
-            while (h->log2m == 10 && brun > 8 && groups(brun) < 2 * need) brun /= 2;
+            brun = h->log2m >= 10 ? 16 : 8;
             while (brun > 1 && groups(brun) < need) brun /= 2;
-            if (h->log2m >= 11) {
-                // one workgroup per CU (N = 16384), two (N = 8192) or four (N = 4096): the groups should come in whole rounds of the chip (F = 253 frames x 32 channels in
+            if (h->log2m >= 10) {
+                // one workgroup per CU (N = 16384), two (N = 8192), four (N = 4096) or eight (N = 2048): the groups should come in whole rounds of the chip (F = 253 frames x 32 channels in
                 // runs of 16 are 512 groups = two rounds, the second one short; in runs of 32 one round) with runs as long as
                 // that allows (every run re-reads N - hop samples of its predecessor and loads ~120 constants per thread)
                 const long long total = (long long)F * h->n_channels;
-                const long long rounds = (total + need * 48 - 1) / (need * 48);               // at most ~48 frames per run
+                const int cap = h->log2m == 10 ? 16 : 48;                                     // frames per run at most (measured per size)
+                const long long rounds = (total + need * cap - 1) / (need * cap);
                 long long rpc = (need * rounds + h->n_channels / 2) / h->n_channels;          // runs per channel
                 if (rpc < 1) rpc = 1;
                 long long r = (F + rpc - 1) / rpc;
