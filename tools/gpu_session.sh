@@ -43,3 +43,6 @@ echo "== N = 8192: stft_big_kernel (FRT_STFT_NO_PK16H=1) against stft_pk16h_kern
 ( for cfg in "8192 4096 32 21 0" "8192 4096 32 21 3" "8192 2048 32 21 0" "8192 2048 32 21 3"; do echo "big  : $(FRT_STFT_NO_PK16H=1 tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; echo "pk16h: $(tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; done ) > gpurun_out/${TAG}_stft8192_ab.txt 2>&1; cat gpurun_out/${TAG}_stft8192_ab.txt
 echo "== exact IIR bank: the launches of one call"
 ( cd /tmp && rm -rf /tmp/iirt && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/iirt -- python $R/tools/exp/iir_stage_times.py 8 3 22 > /dev/null 2>&1; python $R/tools/exp/iir_stage_times.py --parse /tmp/iirt ) > gpurun_out/${TAG}_iir_launches.txt 2>&1; tail -3 gpurun_out/${TAG}_iir_launches.txt
+echo "== N = 4096 / 2048: stft_big_kernel (FRT_STFT_NO_PK16Q=1 / FRT_STFT_NO_PK16W=1) against stft_pk16q_kernel / stft_pk16w_kernel"
+( for cfg in "4096 2048 16 22 0" "4096 2048 16 22 3" "4096 1024 16 22 0" "4096 1024 16 22 3"; do echo "big  : $(FRT_STFT_NO_PK16Q=1 tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; echo "pk16q: $(tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; done ) > gpurun_out/${TAG}_stft4096_ab.txt 2>&1; cat gpurun_out/${TAG}_stft4096_ab.txt
+( for cfg in "2048 1024 8 24 0" "2048 1024 8 24 3" "2048 512 8 24 0" "2048 512 8 24 3"; do echo "big  : $(FRT_STFT_NO_PK16W=1 tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; echo "pk16w: $(tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; done ) > gpurun_out/${TAG}_stft2048_ab.txt 2>&1; cat gpurun_out/${TAG}_stft2048_ab.txt
