@@ -496,7 +496,9 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
                 long long rpc = (need * rounds + h->n_channels / 2) / h->n_channels;          // runs per channel
                 if (rpc < 1) rpc = 1;
                 long long r = (F + rpc - 1) / rpc;
-                if (r >= 8 && r <= 64) brun = (int)r;
+                const int rmin = h->log2m == 10 ? 12 : 8;       // (N = 2048, one channel of 2^24 samples: runs of 8 / 12 / 16: 0.45 / 0.50 / 0.49)
+                if (r < rmin) r = rmin;
+                if (r <= 64) brun = (int)r;
             }
         }
         if (brun > F) brun = (int)F;
