@@ -854,7 +854,10 @@ constexpr int kScanRows = 32;             // rows per workgroup: `halo` of them 
 #define FRT_SCAN_ROW_MAX 16
 #endif
 constexpr int kScanRowMax = FRT_SCAN_ROW_MAX;      // measured 4 / 8 / 16: see tools/exp/README.md
-constexpr int kScanBatch = 8;
+#ifndef FRT_SCAN_BATCH
+#define FRT_SCAN_BATCH 8
+#endif
+constexpr int kScanBatch = FRT_SCAN_BATCH;         // end states requested per trip of a row's walk
 
 template <int NT>
 __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l, const double* __restrict__ power_g,
@@ -1021,77 +1024,136 @@ __global__ void __launch_bounds__(kEnergyThreads) energy_scan_kernel(const doubl
 // before its own (sp = end_g + carry d^len, a few dozen steps), folds the carry in (local_b + carry d^(b - b0 + 1)),
 // converts and writes.
 constexpr int kEnergySplit = 64;
+#ifndef FRT_ENERGY_BATCH
+#define FRT_ENERGY_BATCH 8
+#endif
+#ifndef FRT_ENERGY_CHAIN
+#define FRT_ENERGY_CHAIN 8
+#endif
+// Values a thread requests per trip.  Both kernels are one or four wavefronts per workgroup walking strided columns: what they
+// cost is their dependent memory round trips, so the next trip's values are requested before this trip's are used (first
+// kernel 15 -> 6 us).  Trips of 32 / 64 values in the block loops and a chain trip of 64 end values in the finishing kernel
+// were measured slower or equal (tools/exp/README.md).
+constexpr int kEnergyBatch = FRT_ENERGY_BATCH, kEnergyChain = FRT_ENERGY_CHAIN;
+static_assert(kEnergySplit % kEnergyBatch == 0, "a split is walked in whole batches");
 
-__global__ void energy_local_kernel(double* __restrict__ eblock, const double* __restrict__ decay_n, double* __restrict__ seg_end,
-                                    int nblocks, int nbands) {
+// seg_end: [channel][nsplit + 1][nbands]; slot nsplit of a channel holds the carry the batch starts from (a copy of `smooth`
+// taken here, so that the finishing launch may replace `smooth` while its other workgroups still need the old value).
+// FULL: the split is whole (every split but a batch's last may be ragged) — no bounds in the loops, and the compiler barrier keeps
+// the next trip's requests in front of this trip's stores (left alone it sinks them behind the stores and waits for all of them).
+template <bool FULL>
+__device__ __forceinline__ void energy_local_body(double* p, double* __restrict__ end_slot, double d, int count, int nbands) {
+    double local = 0.0;
+    double nx[kEnergyBatch];
+    auto request = [&](int i) {
+#pragma unroll
+        for (int j = 0; j < kEnergyBatch; ++j) nx[j] = (FULL || i + j < count) ? p[(size_t)(i + j) * nbands] : 0.0;
+    };
+    request(0);
+    for (int i = 0; i < count; i += kEnergyBatch) {
+        double e[kEnergyBatch];
+#pragma unroll
+        for (int j = 0; j < kEnergyBatch; ++j) e[j] = nx[j];
+        if (i + kEnergyBatch < count) request(i + kEnergyBatch);      // (entries this trip does not write)
+        if (FULL) asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < kEnergyBatch; ++j) {
+            if (FULL || i + j < count) {
+                local = e[j] + local * d;
+                p[(size_t)(i + j) * nbands] = local;
+            }
+        }
+    }
+    *end_slot = local;
+}
+
+__global__ void __launch_bounds__(256) energy_local_kernel(double* eblock, const double* __restrict__ decay_n, double* __restrict__ seg_end,
+                                                           const double* __restrict__ smooth, int nblocks, int nbands) {
     const int band = threadIdx.x, sp = blockIdx.x, c = blockIdx.y, nsplit = gridDim.x;
     if (band >= nbands) return;
     const int b0 = sp * kEnergySplit, b1 = (b0 + kEnergySplit) < nblocks ? (b0 + kEnergySplit) : nblocks;
     const double d = decay_n[band];
     double* p = eblock + ((size_t)c * nblocks + b0) * nbands + band;
-    double local = 0.0;
-    for (int b = b0; b < b1; b += 8) {
-        double e[8];
+    if (sp == 0) seg_end[((size_t)c * (nsplit + 1) + nsplit) * nbands + band] = smooth[(size_t)c * nbands + band];
+    double* end_slot = seg_end + ((size_t)c * (nsplit + 1) + sp) * nbands + band;
+    if (b1 - b0 == kEnergySplit) energy_local_body<true>(p, end_slot, d, kEnergySplit, nbands);
+    else energy_local_body<false>(p, end_slot, d, b1 - b0, nbands);
+}
+
+struct EnergyOut {
+    void* out;
+    const double* weight_db;
+    int sub, nbands;
+    size_t row0;                 // index of the channel's first output row
+};
+
+// carry: the smoothed value in front of the split; returns the split's last smoothed value
+template <bool FULL, bool AS_DB, bool OUT_F32>
+__device__ __forceinline__ double energy_finish_body(const double* __restrict__ lp, double nx[kEnergyBatch], double carry, double d, int b0,
+                                                     int count, int band, const EnergyOut& o) {
+    const double w = (AS_DB && o.weight_db) ? o.weight_db[band] : 0.0;
+    double pw = d, last = carry;
+    // entry b is a caller's value when (b + 1) % sub == 0, its row b / sub: counted, not divided (two integer divisions per
+    // entry were most of this kernel's instructions)
+    int rem = b0 % o.sub;
+    size_t idx = (o.row0 + (size_t)(b0 / o.sub)) * o.nbands + band;
+    for (int i = 0; i < count; i += kEnergyBatch) {
+        double e[kEnergyBatch];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = b + j < b1 ? p[(size_t)(b - b0 + j) * nbands] : 0.0;
+        for (int j = 0; j < kEnergyBatch; ++j) e[j] = nx[j];
+        if (i + kEnergyBatch < count) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (b + j < b1) {
-                local = e[j] + local * d;
-                p[(size_t)(b - b0 + j) * nbands] = local;
+            for (int j = 0; j < kEnergyBatch; ++j) nx[j] = (FULL || i + kEnergyBatch + j < count) ? lp[(size_t)(i + kEnergyBatch + j) * o.nbands] : 0.0;
+        }
+        if (FULL) asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < kEnergyBatch; ++j) {
+            if (FULL || i + j < count) {
+                last = e[j] + carry * pw;
+                pw *= d;
+                if (++rem != o.sub) continue;                       // an entry inside a caller's block
+                rem = 0;
+                double v = last;
+                if (AS_DB) v = 10.0 * log10(v + 1e-30) + w;
+                if (OUT_F32) ((float*)o.out)[idx] = (float)v;
+                else ((double*)o.out)[idx] = v;
+                idx += o.nbands;
             }
         }
     }
-    seg_end[((size_t)c * nsplit + sp) * nbands + band] = local;
+    return last;
 }
 
-__global__ void energy_finish_kernel(const double* __restrict__ local, const double* __restrict__ decay_n,
-                                     double* seg_end, const double* __restrict__ smooth, void* __restrict__ out,
-                                     int out_f32, int nblocks, int nbands, const double* __restrict__ weight_db, int as_db, int sub) {
+// AS_DB / OUT_F32 are instances, not branches: the conversion's code (a float64 log10 per entry) between the entries of the linear
+// instance made every trip a string of taken branches through cold instruction-cache lines — most of the launch's 20 us.
+template <bool AS_DB, bool OUT_F32>
+__global__ void __launch_bounds__(256) energy_finish_kernel(const double* __restrict__ local, const double* __restrict__ decay_n,
+                                                            const double* __restrict__ seg_end, double* __restrict__ smooth, void* __restrict__ out,
+                                                            int nblocks, int nbands, const double* __restrict__ weight_db, int sub) {
     const int band = threadIdx.x, sp = blockIdx.x, c = blockIdx.y, nsplit = gridDim.x;
     if (band >= nbands) return;
     const int b0 = sp * kEnergySplit, b1 = (b0 + kEnergySplit) < nblocks ? (b0 + kEnergySplit) : nblocks;
     const double d = decay_n[band];
+    const double* lp = local + ((size_t)c * nblocks + b0) * nbands + band;
+    double nx[kEnergyBatch];                                     // the split's first values travel while the chain is formed
+#pragma unroll
+    for (int j = 0; j < kEnergyBatch; ++j) nx[j] = j < b1 - b0 ? lp[(size_t)j * nbands] : 0.0;
     double dlen = 1.0;                                           // d^kEnergySplit (every split before this one is full)
     for (int i = 0; i < kEnergySplit; ++i) dlen *= d;
-    double carry = smooth[(size_t)c * nbands + band];           // read by every split of the channel; written by the last one
-    const double* se = seg_end + (size_t)c * nsplit * nbands + band;
-    for (int g = 0; g < sp; g += 8) {
-        double e[8];
+    const double* se = seg_end + (size_t)c * (nsplit + 1) * nbands + band;
+    double carry = se[(size_t)nsplit * nbands];                  // the smoothed value the batch starts from (energy_local_kernel's copy)
+    for (int g = 0; g < sp; g += kEnergyChain) {
+        double e[kEnergyChain];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = g + j < sp ? se[(size_t)(g + j) * nbands] : 0.0;
+        for (int j = 0; j < kEnergyChain; ++j) e[j] = g + j < sp ? se[(size_t)(g + j) * nbands] : 0.0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < kEnergyChain; ++j)
             if (g + j < sp) carry = e[j] + carry * dlen;
     }
-    const double w = (as_db && weight_db) ? weight_db[band] : 0.0;
-    const size_t base = ((size_t)c * nblocks + b0) * nbands + band;
-    double pw = d, last = carry;
-    for (int b = b0; b < b1; b += 8) {
-        double e[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = b + j < b1 ? local[base + (size_t)(b - b0 + j) * nbands] : 0.0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (b + j < b1) {
-                last = e[j] + carry * pw;
-                pw *= d;
-                if ((b + j + 1) % sub != 0) continue;               // an entry inside a caller's block
-                double v = last;
-                if (as_db) v = 10.0 * log10(v + 1e-30) + w;
-                const size_t o = ((size_t)c * (nblocks / sub) + (size_t)((b + j) / sub)) * nbands + band;
-                if (out_f32) ((float*)out)[o] = (float)v;
-                else ((double*)out)[o] = v;
-            }
-        }
-    }
-    // the channel's other splits read `smooth` too: it is replaced by a third launch-ordered step, below (energy_carry_kernel)
-    if (sp == nsplit - 1) seg_end[((size_t)c * nsplit + sp) * nbands + band] = last;      // parked in its own slot (nobody reads it here)
-}
-
-__global__ void energy_carry_kernel(const double* __restrict__ seg_end, double* __restrict__ smooth, int nsplit, int nbands) {
-    const int band = threadIdx.x, c = blockIdx.x;
-    if (band < nbands) smooth[(size_t)c * nbands + band] = seg_end[((size_t)c * nsplit + nsplit - 1) * nbands + band];
+    const EnergyOut o{out, weight_db, sub, nbands, (size_t)c * (nblocks / sub)};
+    const double last = (b1 - b0 == kEnergySplit) ? energy_finish_body<true, AS_DB, OUT_F32>(lp, nx, carry, d, b0, kEnergySplit, band, o)
+                                                  : energy_finish_body<false, AS_DB, OUT_F32>(lp, nx, carry, d, b0, b1 - b0, band, o);
+    if (sp == nsplit - 1) smooth[(size_t)c * nbands + band] = last;      // the other splits read energy_local_kernel's copy
 }
 
 // ---- host side -----------------------------------------------------------------------------------
@@ -1790,14 +1852,13 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
     if (rc) return rc;
     if (nblocks >= 4 * kEnergySplit) {
         const int nsplit = (nblocks + kEnergySplit - 1) / kEnergySplit, threads = (h->nbands + 63) / 64 * 64;
-        if ((rc = h->eseg.reserve((size_t)h->n_channels * nsplit * h->nbands * sizeof(double)))) return rc;
+        if ((rc = h->eseg.reserve((size_t)h->n_channels * (nsplit + 1) * h->nbands * sizeof(double)))) return rc;
         hipLaunchKernelGGL(energy_local_kernel, dim3(nsplit, h->n_channels), dim3(threads), 0, h->stream, h->eblock.as<double>(),
-                           h->decay_n.as<double>(), h->eseg.as<double>(), nblocks, h->nbands);
-        hipLaunchKernelGGL(energy_finish_kernel, dim3(nsplit, h->n_channels), dim3(threads), 0, h->stream, h->eblock.as<double>(),
-                           h->decay_n.as<double>(), h->eseg.as<double>(), h->smooth.as<double>(), (void*)d_out, 1, nblocks, h->nbands,
-                           weight_db ? h->weight.as<double>() : nullptr, as_db, sub);
-        hipLaunchKernelGGL(energy_carry_kernel, dim3(h->n_channels), dim3(threads), 0, h->stream, h->eseg.as<double>(),
-                           h->smooth.as<double>(), nsplit, h->nbands);
+                           h->decay_n.as<double>(), h->eseg.as<double>(), h->smooth.as<double>(), nblocks, h->nbands);
+        auto finish = as_db ? energy_finish_kernel<true, true> : energy_finish_kernel<false, true>;
+        hipLaunchKernelGGL(finish, dim3(nsplit, h->n_channels), dim3(threads), 0, h->stream, h->eblock.as<double>(),
+                           h->decay_n.as<double>(), h->eseg.as<double>(), h->smooth.as<double>(), (void*)d_out, nblocks, h->nbands,
+                           weight_db ? h->weight.as<double>() : nullptr, sub);
     } else {
         hipLaunchKernelGGL(energy_scan_kernel, dim3(h->n_channels), dim3(kEnergyThreads), 0, h->stream, h->eblock.as<double>(),
                            h->decay_n.as<double>(), h->smooth.as<double>(), (void*)d_out, 1, nblocks, h->nbands,

@@ -9,12 +9,12 @@ if len(sys.argv) > 2 and sys.argv[1] == "--parse":
     rows = []
     for f in glob.glob(sys.argv[2] + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-28:],
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("<")[0][-28:],
                          int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"])))
     rows.sort()
     names = [r[2] for r in rows]
-    # one call = from an energy_carry / energy_scan kernel to the next: take the last complete call
-    ends = [i for i, n in enumerate(names) if "energy_carry" in n or "energy_scan" in n]
+    # one call = from an energy_finish / energy_scan kernel to the next: take the last complete call
+    ends = [i for i, n in enumerate(names) if "energy_finish" in n or "energy_scan" in n]
     if len(ends) < 2:
         print("no complete call found"); sys.exit(0)
     a, b = ends[-2] + 1, ends[-1] + 1

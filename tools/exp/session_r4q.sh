@@ -1,11 +1,15 @@
 #!/bin/bash
-# SQ counters of the batched overlap-add bank's kernel (two passes), 8 ch x 2^22, bpo 3
-cd /tmp && export TMPDIR=/tmp
+# Round 4, energy recurrence of the banks: pipelined trips + no carry launch (shipped) against the previous kernels (head) and a chain trip of 8 (c8).
+#   gpurun --timeout 400 -- 'bash tools/exp/session_r4q.sh'
+set -u
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/pmc_r4q
-rm -rf $OUT; mkdir -p $OUT
-CMD="python $R/tools/exp/ola_stage_times.py 8 3 22"
-pass() { name=$1; shift; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$name -o p --output-format csv -- $CMD > $OUT/$name.log 2>&1 ); echo "pass $name rc=$?"; }
-pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT
-pass sq2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
-python $R/tools/prof_summary.py pmc $OUT ola_pair | tee $R/gpurun_out/r04_ola_pair_pmc.txt
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+echo "== parity: banks"; timeout 300 python -m pytest tests/test_iir_gpu.py tests/test_ola_gpu.py -x -q -m gpu 2>&1 | tail -3
+for v in "" head; do
+  for bpo in 3 24; do
+    echo -n "variant '${v:-shipped}' bpo $bpo: "; FRT_LIB_VARIANT=$v timeout 120 python tools/bench_octbank.py --chunk 1024 --bpo $bpo --iters 40 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('%.4f ms  %.3e octave-bands/s' % (r['ms'], r['octave_bands_per_s']))"
+  done
+done
+echo "== launches of one call (shipped)"
+( cd /tmp && rm -rf /tmp/iirt && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/iirt -- python $R/tools/exp/iir_stage_times.py 8 3 22 > /dev/null 2>&1; python $R/tools/exp/iir_stage_times.py --parse /tmp/iirt ) > gpurun_out/r04_iir_launches.txt 2>&1; tail -8 gpurun_out/r04_iir_launches.txt
