@@ -55,9 +55,7 @@ struct IirStageArgs {
     int nchunks;
     int pass;                  // 0 sequential, 1 zero-state scan pass, 2 output pass from chunk_init
     double* chunk_end;         // [C][nfilt][nchunks][kStates] pass 1 result
-    const double* chunk_init;  // [C][nfilt][nchunks][kStates] pass 2: a chunk's state had its scan row started from zero ...
-    const double* group_start; // [C][nfilt][scan_rows][kStates] ... the rows' true initial states ...
-    const double* group_pow;   // [nfilt][scan_group][kStates][kStates] ... and (A^L)^i, i = the chunk's index in its row
+    const double* chunk_init;  // [C][nfilt][nchunks][kStates] pass 2: every chunk's true initial state (iir_scan_kernel)
     int scan_group;            // chunks per scan row
     int scan_rows;             // scan rows per (channel, filter)
     double* y;                 // band outputs (packed per channel) or null
@@ -218,13 +216,7 @@ __device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long 
     if (live) {
         if (a.pass == 0) z = a.state[sidx];
         else if (a.pass == 2) {
-            // true initial state = zero-start prefix + (A^L)^i x the scan row's initial state (iir_scan_kernel)
-            const int srow = q / a.scan_group, i = q - srow * a.scan_group;
-            const double* pw = a.group_pow + (((size_t)f * a.scan_group + i) * kStates + s) * kStates;
-            const double* gs = a.group_start + (((size_t)c * a.nfilt + f) * a.scan_rows + srow) * kStates;
-            double acc = a.chunk_init[cidx];
-            for (int t = 0; t < ord; ++t) acc += pw[t] * gs[t];
-            z = acc;
+            z = a.chunk_init[cidx];      // the chunk's true initial state (iir_scan_kernel)
         }
     }
 
@@ -427,25 +419,20 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0) {
     const int qc = valid ? q : a.nchunks - 1;                  // lanes past the end shadow the last chunk, store nothing
     const int L = a.chunk;
 
-    // initial state of every filter of the group: zero-start prefix + (A^L)^i x the scan row's true start (iir_scan_kernel)
+    // initial state of every filter of the group: formed by iir_scan_kernel (zero-start prefix + (A^L)^i x the scan row's true
+    // start).  Until round 4 every lane composed it here from three tables — per-lane gathers of a 16 x 16 power, 13-15 dependent
+    // round trips, most of what a low-rate stage's launch lasted.
+    static_assert(ORD % 2 == 0, "states are read as pairs of doubles");
     double z[NF][ORD], acc[NF], alpha[NF], decay[NF];
-    const int srow = qc / a.scan_group, irow = qc - srow * a.scan_group;
 #pragma unroll
     for (int m = 0; m < NF; ++m) {
         const int f = f0 + m;
         const double* init = a.chunk_init + (((size_t)c * a.nfilt + f) * a.nchunks + qc) * kStates;
-        const double* pw = a.group_pow + ((size_t)f * a.scan_group + irow) * kStates * kStates;
-        const double* gs = a.group_start + (((size_t)c * a.nfilt + f) * a.scan_rows + srow) * kStates;
-        double g[ORD];
 #pragma unroll
-        for (int t = 0; t < ORD; ++t) g[t] = gs[t];
-#pragma unroll
-        for (int st = 0; st < ORD; ++st) {
-            double v = init[st];
-#pragma unroll
-            for (int t = 0; t < ORD; ++t) v += pw[st * kStates + t] * g[t];
-            z[m][st] = v;
-            asm volatile("" ::: "memory");                      // one row of the power table in flight at a time (144 loads otherwise)
+        for (int t = 0; t < ORD; t += 2) {
+            const double2 iv = *(const double2*)(init + t);
+            z[m][t] = iv.x;
+            z[m][t + 1] = iv.y;
         }
         const int band = a.band_index[f];
         alpha[m] = (!DEC && band >= 0) ? a.alpha[band] : 0.0;
@@ -843,8 +830,8 @@ __device__ __forceinline__ double row_matvec(const double (&m)[kStates], double 
 // is the same sum to the last bit that matters — no chain: every row depends on its two predecessors only, rows are a few
 // chunks long at the high-rate stages (4 chunks of 1024 samples) and all of them run at once.  A workgroup owns 30
 // consecutive rows and re-runs the two rows in front of them (halo) so that it needs nobody else's end states.
-// The output pass composes a chunk's initial state itself: chunk_init[q] + (A^L)^(q - row start) S[row]
-// (iir_stage_body, iir_lane_body).  power_l / power_g: [nfilt][16][16] row-major A^L and M.
+// A chunk's initial state is chunk_init[q] + (A^L)^(q - row start) S[row]: the owned rows form it at the end of this kernel
+// (until round 4 the output pass did, lane by lane).  power_l / power_g: [nfilt][16][16] row-major A^L and M.
 // Round 4: a row is at most kScanRowMax (16) chunks.  At the low-rate stages a chunk is 64 samples and the decay takes 64 chunks: rows
 // of 64 were 64 dependent steps of ~0.3 us, 20 us per stage for a few KB of states — the largest launch of stages 4-8.  Rows of
 // 16 chunks need more than two predecessors: S[r] = sum_{k=1..K} Mr^(k-1) E[r-k], K = the rows the decay spans (Horner: K - 1
@@ -862,7 +849,7 @@ constexpr int kScanBatch = FRT_SCAN_BATCH;         // end states requested per t
 template <int NT>
 __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l, const double* __restrict__ power_g,
                                               const double* __restrict__ state, const double* __restrict__ chunk_end,
-                                              double* __restrict__ chunk_init, double* __restrict__ group_start, int gid, int seg, int f,
+                                              double* __restrict__ chunk_init, int gid, int seg, int f,
                                               bool live, int nchunks, int group, int nrows, int halo, double (*gend)[kStates]) {
     const int row = threadIdx.x >> 4, s = threadIdx.x & 15;
     const int r = seg * (kScanRows - halo) - halo + row;      // global row; the first `halo` rows of the workgroup are the halo
@@ -885,16 +872,29 @@ __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l
 #pragma unroll
         for (int j = 0; j < kScanBatch; ++j) e[j] = (live && q + j < q1) ? ce[(size_t)(q + j) * kStates] : 0.0;
     };
-    // the row's chunks from a zero state
+    // the row's chunks from a zero state.  Rows of at most kScanRowMax chunks (every shape but a workgroup short of halo rows) keep
+    // their end states in registers for the second walk below.
+    constexpr int kKeep = kScanRowMax / kScanBatch;
+    static_assert(kScanRowMax % kScanBatch == 0, "a kept row is whole batches");
+    const bool keep = group <= kScanRowMax;                     // uniform
+    double ek[kKeep][kScanBatch];
     double z = 0.0;
-    for (int q = q0; q < q1; q += kScanBatch) {
-        double e[kScanBatch];
-        end_states(q, e);
+    if (keep) {
 #pragma unroll
-        for (int j = 0; j < kScanBatch; ++j) {
-            if (q + j < q1) {
-                if (owned) ci[(size_t)(q + j) * kStates] = z;
-                z = e[j] + row_matvec<NT>(m, z);
+        for (int b = 0; b < kKeep; ++b) end_states(q0 + b * kScanBatch, ek[b]);
+#pragma unroll
+        for (int b = 0; b < kKeep; ++b) {
+#pragma unroll
+            for (int j = 0; j < kScanBatch; ++j)
+                if (q0 + b * kScanBatch + j < q1) z = ek[b][j] + row_matvec<NT>(m, z);
+        }
+    } else {
+        for (int q = q0; q < q1; q += kScanBatch) {
+            double e[kScanBatch];
+            end_states(q, e);
+#pragma unroll
+            for (int j = 0; j < kScanBatch; ++j) {
+                if (q + j < q1) z = e[j] + row_matvec<NT>(m, z);
             }
         }
     }
@@ -905,7 +905,38 @@ __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l
     auto end_of = [&](int k) -> double { return r - k >= 0 ? (k <= row ? gend[row - k][s] : 0.0) : (r - k == -1 ? s0 : 0.0); };
     double start = end_of(halo);
     for (int k = halo - 1; k >= 1; --k) start = end_of(k) + row_matvec<NT>(mg, start);
-    if (owned) group_start[((size_t)gid * nrows + r) * kStates + s] = start;
+    // The true initial state of every chunk of an owned row: the row is walked once more, from its true start — the same
+    // z <- s_q + A^L z, 16 dependent steps at most, the table already in registers.  (Until round 4 the output pass composed it lane
+    // by lane as prefix + (A^L)^i S[r] from a table of the in-row powers: per-lane gathers of a 16 x 16 matrix, 13-15 dependent
+    // round trips, most of what a low-rate stage's launch lasted.  Rows were 128 chunks long when the replay was dropped in round 2.)
+    if (owned) {
+        double zt = start;
+        if (keep) {
+#pragma unroll
+            for (int b = 0; b < kKeep; ++b) {
+#pragma unroll
+                for (int j = 0; j < kScanBatch; ++j) {
+                    const int q = q0 + b * kScanBatch + j;
+                    if (q < q1) {
+                        ci[(size_t)q * kStates] = zt;
+                        zt = ek[b][j] + row_matvec<NT>(m, zt);
+                    }
+                }
+            }
+        } else {
+            for (int q = q0; q < q1; q += kScanBatch) {
+                double e[kScanBatch];
+                end_states(q, e);
+#pragma unroll
+                for (int j = 0; j < kScanBatch; ++j) {
+                    if (q + j < q1) {
+                        ci[(size_t)(q + j) * kStates] = zt;
+                        zt = e[j] + row_matvec<NT>(m, zt);
+                    }
+                }
+            }
+        }
+    }
 }
 
 // grid.x = (channel, filter) pairs x segments of kScanOwned rows
@@ -914,16 +945,16 @@ __global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* 
                                                                   const double* __restrict__ state,
                                                                   const double* __restrict__ chunk_end,
                                                                   const int* __restrict__ order,
-                                                                  double* __restrict__ chunk_init, double* __restrict__ group_start, int nfilt,
+                                                                  double* __restrict__ chunk_init, int nfilt,
                                                                   int nchunks, int group, int nrows, int nseg, int halo) {
     __shared__ double gend[kScanRows][kStates];
     const int gid = blockIdx.x / nseg, seg = blockIdx.x - gid * nseg;      // gid: (channel, filter) pair
     const int f = gid % nfilt;
     const int ord = order[f];                                 // uniform in the workgroup
     const bool live = (int)(threadIdx.x & 15) < ord;
-    if (ord <= 4) iir_scan_body<4>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, seg, f, live, nchunks, group, nrows, halo, gend);
-    else if (ord <= 12) iir_scan_body<12>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, seg, f, live, nchunks, group, nrows, halo, gend);
-    else iir_scan_body<16>(power_l, power_g, state, chunk_end, chunk_init, group_start, gid, seg, f, live, nchunks, group, nrows, halo, gend);
+    if (ord <= 4) iir_scan_body<4>(power_l, power_g, state, chunk_end, chunk_init, gid, seg, f, live, nchunks, group, nrows, halo, gend);
+    else if (ord <= 12) iir_scan_body<12>(power_l, power_g, state, chunk_end, chunk_init, gid, seg, f, live, nchunks, group, nrows, halo, gend);
+    else iir_scan_body<16>(power_l, power_g, state, chunk_end, chunk_init, gid, seg, f, live, nchunks, group, nrows, halo, gend);
 }
 
 // sp_blk = E_blk + sp_{blk-1} * (1-alpha)^n  (exp_smoothing.py:52-54), optional dB + weighting.
@@ -1264,7 +1295,7 @@ extern "C" void frt_octbank_destroy(frt_octbank* h) {
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     frt_ola_destroy(h);
-    DeviceBuffer* bufs[] = {&h->coef, &h->order, &h->state, &h->xin, &h->ypacked, &h->chunk_end, &h->chunk_init, &h->power, &h->zs_table, &h->zs_table_m, &h->zs_rowmap, &h->eseg, &h->gpow, &h->gstart,
+    DeviceBuffer* bufs[] = {&h->coef, &h->order, &h->state, &h->xin, &h->ypacked, &h->chunk_end, &h->chunk_init, &h->power, &h->zs_table, &h->zs_table_m, &h->zs_rowmap, &h->eseg,
                             &h->eblock, &h->alpha, &h->decay_n, &h->smooth, &h->weight, &h->eout};
     for (auto* b : bufs) b->release();
     for (auto& b : h->xbuf) b.release();
@@ -1395,47 +1426,6 @@ static int ensure_powers(frt_octbank* h, int n) {
     }
     int rc = upload(h->power, p);
     if (rc) return rc;
-    // (A^L)^i for i < group: a chunk's true initial state is its zero-start prefix + (A^L)^i x its scan row's initial state
-    // (iir_scan_kernel, iir_stage_body); successive products in long double
-    {
-        h->gpow_offset.assign(kNOctave, 0);
-        size_t total = 0;
-        for (int j = 0; j < kNOctave; ++j) {
-            const int cj = stage_chunk(h->chunk0, j);
-            h->gpow_offset[j] = total;
-            total += (size_t)h->nfilt * h->sgroup[j] * kStates * kStates;
-            (void)cj;
-        }
-        std::vector<double> gp(total, 0.0);
-        const int d = kStates;
-        std::vector<long double> A(d * d), R(d * d), T(d * d);
-        for (int j = 0; j < kNOctave; ++j) {
-            const int cj = stage_chunk(h->chunk0, j);
-            const int group = h->sgroup[j];
-            (void)cj;
-            for (int f = 0; f < h->nfilt; ++f) {
-                const double* AL = &p[((size_t)j * h->nfilt + f) * kStates * kStates];        // A^L, rounded to double: the matrix the scan applies
-                for (int i = 0; i < d * d; ++i) A[i] = (long double)AL[i];
-                std::fill(R.begin(), R.end(), 0.0L);
-                for (int i = 0; i < d; ++i) R[i * d + i] = 1.0L;
-                const int ord = h->h_order[f];                       // everything outside the leading ord x ord block is zero
-                for (int i = 0; i < group; ++i) {
-                    double* dst = &gp[h->gpow_offset[j] + ((size_t)f * group + i) * kStates * kStates];
-                    for (int e = 0; e < d * d; ++e) dst[e] = (double)R[e];
-                    std::fill(T.begin(), T.end(), 0.0L);
-                    for (int r = 0; r < ord; ++r)
-                        for (int c2 = 0; c2 < ord; ++c2) {
-                            long double acc = 0;
-                            for (int k = 0; k < ord; ++k) acc += A[r * d + k] * R[k * d + c2];
-                            T[r * d + c2] = acc;
-                        }
-                    for (int r = ord; r < d; ++r) T[r * d + r] = 0.0L;
-                    R = T;
-                }
-            }
-        }
-        if ((rc = upload(h->gpow, gp))) return rc;
-    }
     // zero-state response tables g[k][row] = (A^(L-1-k) B)[s], rows = the live states of every filter
     std::vector<int> rowmap;
     for (int f = 0; f < h->nfilt; ++f)
@@ -1494,7 +1484,7 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
         int rc = ensure_powers(h, n);
         if (rc) return rc;
         const size_t ws = (size_t)h->n_channels * h->nfilt * nchunks * kStates * sizeof(double);
-        if ((rc = h->chunk_end.reserve(ws * kMaxSlices)) || (rc = h->chunk_init.reserve(ws)) || (rc = h->gstart.reserve(ws)))      // rows <= chunks
+        if ((rc = h->chunk_end.reserve(ws * kMaxSlices)) || (rc = h->chunk_init.reserve(ws)))
             return rc;
     }
     for (int j = 1; j < kNOctave; ++j) {
@@ -1521,8 +1511,6 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
         a.nchunks = parallel ? (len[j] + a.chunk - 1) / a.chunk : 1;
         a.chunk_end = h->chunk_end.as<double>();
         a.chunk_init = h->chunk_init.as<double>();
-        a.group_start = h->gstart.as<double>();
-        a.group_pow = parallel ? h->gpow.as<double>() + h->gpow_offset[j] : nullptr;
         a.scan_group = parallel ? h->sgroup[j] : 1;
         a.scan_rows = (a.nchunks + a.scan_group - 1) / a.scan_group;
         a.y = d_y;
@@ -1597,7 +1585,7 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
             const int halo = h->shalo[j], nseg = (a.scan_rows + (kScanRows - halo) - 1) / (kScanRows - halo);
             hipLaunchKernelGGL(iir_scan_kernel, dim3((unsigned)(h->n_channels * h->nfilt * nseg)), dim3(kScanRows * 16), 0, h->stream,
                                h->power.as<double>() + off, h->power.as<double>() + per + off, a.state, h->chunk_end.as<double>(),
-                               h->order.as<int>(), h->chunk_init.as<double>(), h->gstart.as<double>(), h->nfilt, a.nchunks,
+                               h->order.as<int>(), h->chunk_init.as<double>(), h->nfilt, a.nchunks,
                                a.scan_group, a.scan_rows, nseg, halo);
             a.pass = 2;
             static const bool exact_ops = getenv("FRT_IIR_EXACT_OPS") != nullptr;      // A/B runs

@@ -46,8 +46,6 @@ struct frt_octbank {
     std::vector<int> h_order;
     frt::DeviceBuffer coef, order, state;        // state: [9][C][nfilt][16]
     frt::DeviceBuffer xin, ypacked, xbuf[frt::kNOctave], chunk_end, chunk_init, power;
-    frt::DeviceBuffer gpow, gstart;                       // (A^L)^i, i < chunks per scan row, per (stage, filter); the scan rows' true initial states
-    std::vector<size_t> gpow_offset;                      // per stage, in doubles
     std::vector<int> sgroup, shalo;                       // per stage: chunks per scan row, rows the filters' decay spans (iir_scan_kernel)
     frt::DeviceBuffer eseg;                               // per-split carries of the block-energy recurrence (long batches)
     frt::DeviceBuffer zs_table, zs_table_m, zs_rowmap;   // zero-state response tables of the time-parallel mode (iir.hip)
