@@ -255,7 +255,7 @@ def octave_legs(dev, world, rank, ch, bpo, log2n, tag, with_sequential):
                                                                "the 78.6 TFLOP/s float64 vector peak"}, **extra(dt))}
 
     iir = IirBank(t["bdec"], t["adec"], list(t[f"boct_{bpo}"]), list(t[f"aoct_{bpo}"]), ch)
-    chunk = 1024
+    chunk = 1024 if bpo <= 3 else 512      # measured 2048 / 1024 / 512 / 256 (tools/exp/chunk_sweep.sh): 0.74 / 0.62 / 0.64 / 0.76 ms at bpo 3, 0.82 / 0.66 / 0.64 / 0.75 at bpo 24
     iir.set_chunk(chunk)
     record("iir_time_parallel", iir, 5,
            f"exact IIR bank, time-parallel chunks of {chunk} samples: the same recurrences re-associated; output pass with one lane "

@@ -407,6 +407,11 @@ static int launch_iir_stage(IirStageArgs a, const int* orders, int n_channels, h
 #ifndef FRT_LANE_BANDS
 #define FRT_LANE_BANDS 3
 #endif
+#ifndef FRT_LANE_PREFETCH
+#define FRT_LANE_PREFETCH 1
+#endif
+constexpr int kLanePrefetch = FRT_LANE_PREFETCH;      // trips of 16 samples a lane's requests run ahead; measured 1 / 2 / 4: equal / equal / slower at 216 bands (registers)
+static_assert(kLanePrefetch == 1 || kLanePrefetch == 2 || kLanePrefetch == 4, "prefetch ring of 1, 2 or 4 trips");
 constexpr int kLaneBands = FRT_LANE_BANDS;      // measured: one band filter per wavefront re-reads the samples per filter and is 15-70 % slower (bpo 3 / 24)
 
 template <int NF, int ORD, bool DEC, bool F32>
@@ -462,33 +467,37 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0) {
     const bool energy = !DEC && a.eblock != nullptr;
     constexpr bool f32 = F32;
 
-    // Sixteen samples per trip (chunks are multiples of 64): the next sixteen — one 64-byte (float) or 128-byte (double)
-    // piece of the lane's own stream — are requested before these are filtered and converted only when their turn comes.
-    // Every lane walks its own cache lines (the chunks lie L samples apart), so a request is an L2 round trip, often an HBM
-    // one: with four samples per trip the 100 instructions in between did not cover it and every trip began with a wait.
-    constexpr int G = 16;
-    float4 rf[4];
-    double2 rd[8];
-    auto request = [&](int k) {
+    // Sixteen samples per trip (chunks are multiples of 64) — one 64-byte (float) or 128-byte (double) piece of the lane's own
+    // stream — requested kLanePrefetch trips before they are filtered and converted only when their turn comes.  Every lane walks
+    // its own cache lines (the chunks lie L samples apart), so a request is an L2 round trip, often an HBM one, and a wavefront is
+    // alone on its SIMD at the high-rate stages: with four samples per trip every trip began with a wait (round 3); one trip ahead
+    // (16 samples = ~2200 cycles of arithmetic) covers it — two or four trips ahead measure equal (round 4), the pass is not waiting
+    // for memory.
+    constexpr int G = 16, D = kLanePrefetch;
+    static_assert(64 % (G * D) == 0, "a chunk is whole rounds of the prefetch ring");
+    float4 rf[D][4];
+    double2 rd[D][8];
+    auto request = [&](auto slot, int k) {
+        constexpr int d = decltype(slot)::value;
         if (f32) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rf[i] = *(const float4*)(xf + k + 4 * i);
+            for (int i = 0; i < 4; ++i) rf[d][i] = *(const float4*)(xf + k + 4 * i);
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) rd[i] = *(const double2*)(xd + k + 2 * i);
+            for (int i = 0; i < 8; ++i) rd[d][i] = *(const double2*)(xd + k + 2 * i);
         }
     };
-    request(0);
-    for (int k0 = 0; k0 < L; k0 += G) {
+    auto trip = [&](auto slot, int k0) {
+        constexpr int d = decltype(slot)::value;
         double xg[G];
         if (f32) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { xg[4 * i] = rf[i].x; xg[4 * i + 1] = rf[i].y; xg[4 * i + 2] = rf[i].z; xg[4 * i + 3] = rf[i].w; }
+            for (int i = 0; i < 4; ++i) { xg[4 * i] = rf[d][i].x; xg[4 * i + 1] = rf[d][i].y; xg[4 * i + 2] = rf[d][i].z; xg[4 * i + 3] = rf[d][i].w; }
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { xg[2 * i] = rd[i].x; xg[2 * i + 1] = rd[i].y; }
+            for (int i = 0; i < 8; ++i) { xg[2 * i] = rd[d][i].x; xg[2 * i + 1] = rd[d][i].y; }
         }
-        if (k0 + G < L) request(k0 + G);
+        if (k0 + G * D < L) request(slot, k0 + G * D);
         double yd[G / 2];
 #pragma unroll
         for (int u4 = 0; u4 < G; u4 += 4) {
@@ -526,6 +535,20 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0) {
         if (DEC && xn && valid) {
 #pragma unroll
             for (int i = 0; i < G / 4; ++i) *(double2*)(xn + (k0 >> 1) + 2 * i) = double2{yd[2 * i], yd[2 * i + 1]};
+        }
+    };
+    request(std::integral_constant<int, 0>{}, 0);
+    if constexpr (D > 1) request(std::integral_constant<int, 1>{}, G);
+    if constexpr (D > 2) {
+        request(std::integral_constant<int, 2>{}, 2 * G);
+        request(std::integral_constant<int, 3>{}, 3 * G);
+    }
+    for (int k0 = 0; k0 < L; k0 += G * D) {
+        trip(std::integral_constant<int, 0>{}, k0);
+        if constexpr (D > 1) trip(std::integral_constant<int, 1>{}, k0 + G);
+        if constexpr (D > 2) {
+            trip(std::integral_constant<int, 2>{}, k0 + 2 * G);
+            trip(std::integral_constant<int, 3>{}, k0 + 3 * G);
         }
     }
     if (valid && q == a.nchunks - 1) {                          // the stage's carried state: end of the channel's last chunk

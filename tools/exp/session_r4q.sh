@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 echo "== parity: all GPU tests"; timeout 300 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-for v in "" r8 head; do
+for v in "" d1 d4; do
   for cfg in "8 3 22" "8 24 20" "64 24 20"; do
     set -- $cfg
     echo -n "variant '${v:-shipped}' ch $1 bpo $2 2^$3: "; FRT_LIB_VARIANT=$v timeout 120 python tools/bench_octbank.py --chunk 1024 --channels $1 --bpo $2 --log2-samples $3 --iters 40 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('%.4f ms  %.3e octave-bands/s' % (r['ms'], r['octave_bands_per_s']))"
