@@ -36,12 +36,22 @@ def shard_channels(n_channels: int, rank: int, world: int) -> range:
     return range(lo, lo + base + (1 if rank < extra else 0))
 
 
+def _solo() -> bool:
+    """True when no collective needs to run: no process group, or a group of one.  FRT_DIST_FORCE=1 makes a group of one go
+    through the collective library anyway (tests/test_rccl_single_rank_gpu.py: every call of this module on RCCL with device
+    tensors on the one GPU a test box has)."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("FRT_DIST_FORCE", "") != "1"
+
+
 def init_process_group(backend: str | None = None, device=None):
-    """Join the job's process group (RCCL on GPU, gloo on CPU).  No-op for single-process runs."""
+    """Join the job's process group (RCCL on GPU, gloo on CPU).  No-op for single-process runs (unless FRT_DIST_FORCE=1)."""
     import torch
     import torch.distributed as dist
     rank, local_rank, world = env_world()
-    if world == 1 or dist.is_initialized():
+    if (world == 1 and os.environ.get("FRT_DIST_FORCE", "") != "1") or dist.is_initialized():
         return rank, local_rank, world
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -58,7 +68,7 @@ def broadcast_tables(tables: dict, src: int = 0, device=None) -> dict:
     """Broadcast a dict of numpy arrays from `src` (shapes / dtypes must be known on all ranks)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _solo():
         return tables
     out = {}
     for key in sorted(tables):
@@ -78,7 +88,7 @@ def gather_channel_summaries(local, n_channels: int):
     shard (block partition of `n_channels`).  Returns [n_channels, K] on every rank."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _solo():
         return local
     world = dist.get_world_size()
     width = local.shape[1]
@@ -95,7 +105,7 @@ def gather_scalars(value: float, device=None) -> list:
     """One float from every rank, in rank order ([value] for a single process): per-rank step times next to the maximum."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _solo():
         return [float(value)]
     mine = torch.tensor([value], dtype=torch.float64, device=device)
     parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
@@ -117,15 +127,16 @@ class SlabGather:
         import torch
         import torch.distributed as dist
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.solo = _solo()
         self.recv = [torch.empty((self.world,) + tuple(like.shape), dtype=like.dtype, device=like.device) for _ in range(n_slots)] \
-            if self.world > 1 else [None] * n_slots
+            if not self.solo else [None] * n_slots
         self.work = [None] * n_slots
         self.bytes_per_gather = self.world * like.numel() * like.element_size()
 
     def start(self, slab, slot: int):
         import torch.distributed as dist
         self.wait(slot)
-        if self.world == 1:
+        if self.solo:
             self.recv[slot] = slab[None]
             return
         self.work[slot] = dist.all_gather_into_tensor(self.recv[slot].view(-1), slab.contiguous().view(-1), async_op=True)
@@ -147,7 +158,7 @@ def gather_ranks(device=None) -> list:
     collective library (RCCL on GPUs) saw every rank."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _solo():
         return [0]
     mine = torch.tensor([dist.get_rank()], dtype=torch.int64, device=device)
     parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
@@ -158,7 +169,7 @@ def gather_ranks(device=None) -> list:
 def max_over_ranks(value: float, device=None) -> float:
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _solo():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -167,7 +178,7 @@ def max_over_ranks(value: float, device=None) -> float:
 
 def barrier(device=None):
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if not _solo():
         if device is not None and getattr(device, "type", "cpu") == "cuda":
             dist.barrier(device_ids=[device.index])
         else:
