@@ -218,6 +218,40 @@ def test_band_energies_with_chunks_shorter_than_the_block(tabs, chunk, nblocks):
         bank.energies(x32[:, :n], 1024, alphas)                  # host arrays: not served with a chunk below the block
 
 
+def test_216_band_bank_with_chunks_of_1024_and_512(tabs):
+    """The 216-band bank as bench.py's configs[4] leg runs it (chunk 512: shorter than the energy block; the narrow filters' decay
+    spans hundreds of chunks, so scan rows are longer than the 16 chunks whose end states stay in registers) against the chunk
+    length the oracle test above uses and against the oracle itself on the first blocks."""
+    import torch
+    from friture_amd.filter import IirBank
+    bpo, C, nblocks = 24, 2, 128
+    n = 1024 * nblocks
+    boct, aoct = list(tabs[f"boct_{bpo}"]), list(tabs[f"aoct_{bpo}"])
+    alphas, kernels = dsp.band_smoothing_setup(bpo, 0.125)
+    x32 = np.stack([synth("noise", n, 31), synth("chirp", n, 32)])
+    xd = torch.from_numpy(x32).cuda()
+
+    def run(chunk):
+        b = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, C)
+        b.set_chunk(chunk)
+        return b.energies(xd, 1024, alphas).cpu().numpy().astype(np.float64)
+
+    ref = run(4096)
+    for chunk in (1024, 512):
+        e = run(chunk)
+        assert e.shape == (C, nblocks, 216)
+        assert np.all(np.abs(e - ref) <= 1e-5 * ref + 1e-14 * ref.max(axis=2, keepdims=True)), chunk
+    e = run(512)
+    zs = dsp.iir_bank_filtic(tabs["bdec"], tabs["adec"], boct, aoct)
+    prev = [0.0] * 216
+    for blk in range(6):
+        y, _, zs = dsp.iir_bank(tabs["bdec"], tabs["adec"], boct, aoct, x32[0, blk * 1024:(blk + 1) * 1024].astype(np.float64), zs)
+        prev = dsp.band_energies(y, kernels, alphas, prev)
+        r = np.array(prev)
+        assert np.all(np.abs(e[0, blk] - r) <= 1e-5 * r + 1e-14 * r.max()), blk
+
+
+
 def test_energy_recurrence_split_along_time_equals_tiled(tabs):
     """Long batches run the block-energy recurrence split along time (energy_local / energy_finish kernels, >= 256 blocks),
     short calls the one-workgroup-per-channel tile kernel: a 600-block batch (ten splits, the last one ragged) must carry
