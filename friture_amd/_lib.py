@@ -80,6 +80,7 @@ SIGNATURES = {
     "frt_screen_columns": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                    c_void_p, c_void_p]),
     "frt_exp_smooth_2d": (c_int, [c_void_p, c_int, c_double, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
+    "frt_exp_smooth_groups": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "frt_spectrum_post": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_int, c_double, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_int)]),
     "frt_pitch_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p, c_int, c_double,

@@ -123,6 +123,7 @@ class StageCall {
     int begin();                                         // capacity, host -> pinned, one async upload
     template <typename T>
     T* ptr(int id) const { return reinterpret_cast<T*>(arg_[id].dev); }
+    size_t offset(int id) const { return arg_[id].off; }   // of a staged input inside the call's input block (fixed at add_in)
     hipStream_t stream() const { return launch_stream_; }
     int finish();                                        // one async download of the outputs, one synchronisation, pinned -> host
   private:

@@ -1937,7 +1937,7 @@ extern "C" int frt_decimate_multiple(frt_octbank* h, int n_stages, const double*
 // (zero state / states not wanted).  The handle's own carried state is not touched.
 extern "C" int frt_decimate_multiple_state(frt_octbank* h, int n_stages, const double* x, int n, const double* zi, double* out, int* n_out,
                                            double* zf) {
-    FRT_REQUIRE(h && h->bpo == 0 && h->n_channels == 1, "frt_decimate_multiple_state: needs a one-channel handle created with bands_per_octave = 0");
+    FRT_REQUIRE(h && h->bpo == 0, "frt_decimate_multiple_state: needs a handle created with bands_per_octave = 0");
     FRT_REQUIRE(n_stages >= 1 && n_stages < kNOctave, "frt_decimate_multiple_state: n_stages %d not in [1, 8]", n_stages);
     FRT_REQUIRE(n >= 0, "frt_decimate_multiple_state: n < 0");
     int len[kNOctave];
@@ -1945,11 +1945,14 @@ extern "C" int frt_decimate_multiple_state(frt_octbank* h, int n_stages, const d
     if (n_out) *n_out = len[n_stages];
     if (n == 0) return FRT_OK;
     FRT_REQUIRE(x && out && !is_device_pointer(x) && !is_device_pointer(out), "frt_decimate_multiple_state: host arrays");
+    // every channel of the handle in the same launches (the delay estimator decimates its two channels chunk by chunk:
+    // delay_estimator.py:97-98 — two calls of two dependent launches each were two device round trips per chunk)
+    const int C = h->n_channels;
     const int ord = h->h_order[0];
-    const size_t xbytes = (size_t)n * sizeof(double), sbytes = (size_t)n_stages * kStates * sizeof(double);
-    const size_t obytes = (size_t)len[n_stages] * sizeof(double);
+    const size_t xbytes = (size_t)C * n * sizeof(double), sbytes = (size_t)n_stages * C * kStates * sizeof(double);
+    const size_t obytes = (size_t)C * len[n_stages] * sizeof(double);
     const size_t in_need = (xbytes + 255) / 256 * 256 + sbytes;
-    FRT_REQUIRE(in_need <= kZeroCopyMax && obytes <= kZeroCopyMax, "frt_decimate_multiple_state: %d samples exceed the in-place call", n);
+    FRT_REQUIRE(in_need <= kZeroCopyMax && obytes <= kZeroCopyMax, "frt_decimate_multiple_state: %d samples x %d channels exceed the in-place call", n, C);
     int rc;
     if (in_need > h->pin_in_bytes || obytes > h->pin_out_bytes) {
         FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -1972,12 +1975,14 @@ extern "C" int frt_decimate_multiple_state(frt_octbank* h, int n_stages, const d
         }
     }
     double* px = (double*)h->pin_in;
-    double* ps = (double*)((char*)h->pin_in + (xbytes + 255) / 256 * 256);
+    double* ps = (double*)((char*)h->pin_in + (xbytes + 255) / 256 * 256);      // [stage][channel][kStates]: the kernel's layout
     memcpy(px, x, xbytes);
     for (int j = 0; j < n_stages; ++j)
-        for (int s = 0; s < kStates; ++s) ps[j * kStates + s] = (zi && s < ord) ? zi[j * ord + s] : 0.0;
+        for (int c = 0; c < C; ++c)
+            for (int s = 0; s < kStates; ++s)
+                ps[((size_t)j * C + c) * kStates + s] = (zi && s < ord) ? zi[((size_t)c * n_stages + j) * ord + s] : 0.0;
     for (int j = 1; j < n_stages; ++j)
-        if ((rc = h->xbuf[j].reserve((size_t)len[j] * sizeof(double)))) return rc;
+        if ((rc = h->xbuf[j].reserve((size_t)C * len[j] * sizeof(double)))) return rc;
     for (int j = 0; j < n_stages; ++j) {
         IirStageArgs a{};
         a.x = j == 0 ? (const void*)px : h->xbuf[j].ptr;
@@ -1987,20 +1992,21 @@ extern "C" int frt_decimate_multiple_state(frt_octbank* h, int n_stages, const d
         a.order = h->order.as<int>();
         a.nfilt = 1;
         a.dec_filter = 0;
-        a.state = ps + (size_t)j * kStates;
+        a.state = ps + (size_t)j * C * kStates;
         a.chunk = (len[j] + 63) / 64 * 64;
         a.nchunks = 1;
         a.pass = 0;
         a.band_index[0] = -1;
         a.xnext = j + 1 == n_stages ? (double*)h->pin_out : h->xbuf[j + 1].as<double>();
         a.xnext_stride = len[j + 1];
-        if ((rc = launch_iir_stage(a, h->h_order.data(), 1, h->stream))) return rc;
+        if ((rc = launch_iir_stage(a, h->h_order.data(), C, h->stream))) return rc;
     }
     FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
     memcpy(out, h->pin_out, obytes);
     if (zf)
         for (int j = 0; j < n_stages; ++j)
-            for (int s = 0; s < ord; ++s) zf[j * ord + s] = ps[j * kStates + s];
+            for (int c = 0; c < C; ++c)
+                for (int s = 0; s < ord; ++s) zf[((size_t)c * n_stages + j) * ord + s] = ps[((size_t)j * C + c) * kStates + s];
     return FRT_OK;
 }
 

@@ -81,6 +81,35 @@ __global__ void __launch_bounds__(64) exp_smooth_kernel(const double* __restrict
     if (threadIdx.x == 0) out[r] = alpha * acc + previous[r] * decay;
 }
 
+// Ragged form: row r has its own length, taps, alpha — the octave-spectrum widget's bands (octavespectrum.py:103-112: one
+// exp_smoothed_value per band, bands of an octave sharing kernel, alpha and length).  desc[r] = {data offset, taps offset, n,
+// square}; the same products and the same summation order per row as exp_smooth_kernel, so a row equals its own call bit for bit.
+struct ExpSmoothRow {
+    long long data_off, kern_off;      // in doubles, into the call's packed data / taps
+    int n, square;                     // samples used; 1: the datum is squared first (the widget smooths y^2)
+    double alpha, decay;               // decay = (1 - alpha)^n, 0 when the row is longer than its kernel
+};
+__global__ void __launch_bounds__(64) exp_smooth_rows_kernel(const double* __restrict__ data, const double* __restrict__ taps,
+                                                             const ExpSmoothRow* __restrict__ desc, const double* __restrict__ previous,
+                                                             double* __restrict__ out, int rows) {
+    const int r = blockIdx.x;
+    if (r >= rows) return;
+    const ExpSmoothRow d = desc[r];
+    const double* row = data + d.data_off;
+    const double* kern = taps + d.kern_off;
+    double acc = 0.0;
+    if (d.square) {
+        for (int t = threadIdx.x; t < d.n; t += 64) {
+            const double v = row[t];
+            acc += (v * v) * kern[t];
+        }
+    } else {
+        for (int t = threadIdx.x; t < d.n; t += 64) acc += row[t] * kern[t];
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (threadIdx.x == 0) out[r] = d.n == 0 ? previous[r] : d.alpha * acc + previous[r] * d.decay;
+}
+
 // ---- Fourier resampling of a column (scipy_resample.py:51-141 as used by Online_Linear_2D_resampler.set_height,
 // online_linear_2D_resampler.py:45-55): X = fft(x); keep the N = min(n, m) lowest frequencies; y = ifft(Y) * m / n.
 // A resize event, n and m a few hundred to a few thousand and of any factorisation (screen heights): two direct DFT
@@ -226,6 +255,65 @@ extern "C" int frt_exp_smooth_2d(const double* kernel, int nk, double alpha, con
     if ((rc = st.begin())) return rc;
     hipLaunchKernelGGL(exp_smooth_kernel, dim3(nf), dim3(64), 0, st.stream(), st.ptr<const double>(i_data), (long long)row_stride, n,
                        st.ptr<const double>(i_k), alpha, decay, st.ptr<const double>(i_prev), st.ptr<double>(i_out), nf);
+    return st.finish();
+}
+
+extern "C" int frt_exp_smooth_groups(int n_groups, const double* const* kernels, const int* nk, const double* alphas,
+                                     const double* const* data, const int* nf, const int* nt, const int64_t* row_stride, int square,
+                                     const double* previous, double* out) {
+    FRT_REQUIRE(n_groups >= 0 && n_groups <= 64, "frt_exp_smooth_groups: %d groups (at most 64)", n_groups);
+    if (n_groups == 0) return FRT_OK;
+    FRT_REQUIRE(kernels && nk && alphas && data && nf && nt && row_stride && previous && out, "frt_exp_smooth_groups: null argument");
+    FRT_REQUIRE(!is_device_pointer(previous) && !is_device_pointer(out), "frt_exp_smooth_groups: host arrays (the widget's chunk)");
+    int rows = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        FRT_REQUIRE(nk[g] >= 0 && nf[g] >= 0 && nt[g] >= 0 && row_stride[g] >= nt[g], "frt_exp_smooth_groups: bad shape in group %d", g);
+        FRT_REQUIRE(kernels[g] && (nt[g] == 0 || nf[g] == 0 || data[g]), "frt_exp_smooth_groups: null buffer in group %d", g);
+        FRT_REQUIRE(!is_device_pointer(kernels[g]) && (nt[g] == 0 || nf[g] == 0 || !is_device_pointer(data[g])),
+                    "frt_exp_smooth_groups: host arrays (the widget's chunk)");
+        rows += nf[g];
+    }
+    if (rows == 0) return FRT_OK;
+    StageCall st;
+    std::vector<ExpSmoothRow> desc((size_t)rows);
+    std::vector<int> in_data(n_groups, -1), in_taps(n_groups, -1);
+    std::vector<int> used(n_groups);
+    for (int g = 0; g < n_groups; ++g) {
+        // exp_smoothing.py:94-101: more data than taps -> only the first Nk samples count and the previous value is forgotten
+        used[g] = nt[g] > nk[g] ? nk[g] : nt[g];
+        if (nf[g] == 0 || used[g] == 0) continue;
+        in_taps[g] = st.add_in(kernels[g] + (nk[g] - used[g]), (size_t)used[g] * sizeof(double));
+        in_data[g] = st.add_in(data[g], ((size_t)(nf[g] - 1) * row_stride[g] + nt[g]) * sizeof(double));
+    }
+    const int i_prev = st.add_in(previous, (size_t)rows * sizeof(double));
+    const int i_desc = st.add_in(desc.data(), desc.size() * sizeof(ExpSmoothRow));      // (filled below, before begin() copies it)
+    const int i_out = st.add_out(out, (size_t)rows * sizeof(double));
+    // every staged input lies in one block in registration order at offsets fixed by add_in: the rows carry their distances from
+    // the first one, the kernel gets its address
+    int first = -1;
+    for (int g = 0; g < n_groups && first < 0; ++g) first = in_taps[g];
+    if (first < 0) {          // every row is empty: exp_smoothing.py:103-104, a copy of previous
+        memcpy(out, previous, (size_t)rows * sizeof(double));
+        return FRT_OK;
+    }
+    int r = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        const double decay = nt[g] > nk[g] ? 0.0 : std::pow(1.0 - alphas[g], (double)used[g]);
+        for (int f = 0; f < nf[g]; ++f, ++r) {
+            ExpSmoothRow& d = desc[(size_t)r];
+            d.n = used[g];
+            d.square = square ? 1 : 0;
+            d.alpha = alphas[g];
+            d.decay = decay;
+            d.kern_off = d.n ? (long long)((st.offset(in_taps[g]) - st.offset(first)) / sizeof(double)) : 0;
+            d.data_off = d.n ? (long long)((st.offset(in_data[g]) - st.offset(first)) / sizeof(double)) + (long long)f * row_stride[g] : 0;
+        }
+    }
+    int rc;
+    if ((rc = st.begin())) return rc;
+    const double* base = st.ptr<const double>(first);
+    hipLaunchKernelGGL(exp_smooth_rows_kernel, dim3(rows), dim3(64), 0, st.stream(), base, base, st.ptr<const ExpSmoothRow>(i_desc),
+                       st.ptr<const double>(i_prev), st.ptr<double>(i_out), rows);
     return st.finish();
 }
 

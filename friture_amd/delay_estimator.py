@@ -14,7 +14,7 @@ from . import filter_design
 from .constants import SAMPLING_RATE
 from .ringbuffer import RingBuffer
 from .signal.correlation import GccPhat, generalized_cross_correlation
-from .signal.decimate import decimate_multiple, decimate_multiple_filtic
+from .signal.decimate import decimate_multiple, decimate_multiple_channels, decimate_multiple_filtic
 
 DEFAULT_DELAYRANGE = 1      # default delay range is 1 second (delay_estimator.py:31)
 
@@ -46,8 +46,10 @@ class DelayEstimator:
             self.two_channels = False
             return
         self.two_channels = True
-        x0_dec, self.zfs0 = decimate_multiple(self.Ndec, self.bdec, self.adec, floatdata[0, :], self.zfs0)
-        x1_dec, self.zfs1 = decimate_multiple(self.Ndec, self.bdec, self.adec, floatdata[1, :], self.zfs1)
+        # both channels in one device call (the reference decimates them one after the other, delay_estimator.py:97-98; the
+        # channels are independent slots of the same launches: bit for bit the two separate calls)
+        xdec, (self.zfs0, self.zfs1) = decimate_multiple_channels(self.Ndec, self.bdec, self.adec, floatdata[0:2, :], [self.zfs0, self.zfs1])
+        x0_dec, x1_dec = xdec[0], xdec[1]
         self.ringbuffer0.push(x0_dec.reshape(1, -1), 0)
         self.ringbuffer1.push(x1_dec.reshape(1, -1), 0)
 

@@ -1,13 +1,13 @@
 """The octave-spectrum widget's processing chain (friture/octavespectrum.py:91-156) without Qt:
 Octave_Filters.filter (FFT overlap-add bank on the GPU), per-band exponential smoothing of y^2
-(frt_exp_smooth_2d, one launch per decimation class) and 10 log10(sp + 1e-30) + weighting."""
+(frt_exp_smooth_groups: all bands of a chunk in one launch) and 10 log10(sp + 1e-30) + weighting."""
 from __future__ import annotations
 
 import numpy as np
 
 from .constants import NOCTAVE, SAMPLING_RATE
 from .octavefilters import Octave_Filters
-from .signal.exp_smoothing import exp_smoothed_value_2d
+from .signal.exp_smoothing import exp_smoothed_value_groups
 
 DEFAULT_BANDSPEROCTAVE = 3      # octavespectrum_settings.py:25-31
 DEFAULT_RESPONSE_TIME = 1.
@@ -40,12 +40,17 @@ class OctaveSpectrum:
             return None
         y, _ = self.filters.filter(floatdata[0, :])
         bpo = self.filters.bandsperoctave
-        sp = np.empty(len(y))
-        for octave in range(NOCTAVE):            # bands of one octave share kernel, alpha and length
+        # The reference smooths band by band (octavespectrum.py:103-112); bands of one octave share kernel, alpha and length and lie
+        # back to back in the bank's packed output, so the chunk's 9 x bpo values are ONE call (frt_exp_smooth_groups, y^2 formed on
+        # the device; until round 4: one call per octave, nine device round trips per chunk).
+        blocks = []
+        for octave in range(NOCTAVE):
             lo = octave * bpo
-            block = np.stack([band ** 2 for band in y[lo:lo + bpo]])
-            sp[lo:lo + bpo] = exp_smoothed_value_2d(self.kernels[lo], self.alphas[lo], block,
-                                                    np.asarray(self.dispbuffers[lo:lo + bpo], np.float64))
+            row, m = y[lo], y[lo].shape[0]
+            packed = all(y[lo + i].ctypes.data == row.ctypes.data + i * m * 8 and y[lo + i].shape[0] == m for i in range(1, bpo))
+            blocks.append((row, bpo) if packed and row.flags.c_contiguous else np.stack(y[lo:lo + bpo]))
+        sp = exp_smoothed_value_groups([self.kernels[o * bpo] for o in range(NOCTAVE)], [self.alphas[o * bpo] for o in range(NOCTAVE)],
+                                       blocks, np.asarray(self.dispbuffers, np.float64), square=True)
         self.dispbuffers = list(sp)
         w = {0: 0., 1: self.filters.A, 2: self.filters.B}.get(self.weighting, self.filters.C)
         db_spectrogram = 10 * np.log10(sp + 1e-30) + w

@@ -18,13 +18,13 @@ _handles: dict = {}
 _IN_PLACE_MAX = 30000         # samples per call that frt_decimate_multiple_state takes (256 KB in place)
 
 
-def _chain_handle(bdec, adec):
-    key = (bdec.tobytes(), adec.tobytes())
+def _chain_handle(bdec, adec, channels=1):
+    key = (bdec.tobytes(), adec.tobytes(), channels)
     h = _handles.get(key)
     if h is None:
         lib = _lib.init()
         h = ctypes.c_void_p()
-        _lib.check(lib.frt_octbank_create(ctypes.byref(h), 0, 1, 0, None, None, bdec.ctypes.data_as(_DP),
+        _lib.check(lib.frt_octbank_create(ctypes.byref(h), 0, channels, 0, None, None, bdec.ctypes.data_as(_DP),
                                           adec.ctypes.data_as(_DP), None, None))
         _handles[key] = h
     return h
@@ -78,6 +78,32 @@ def decimate_multiple(Ndec, bdec, adec, x, zis):
         return out, None
     _lib.check(lib.frt_octbank_get_state(h, state.ctypes.data_as(_DP)))
     return out, [state[12 * j:12 * (j + 1)].copy() for j in range(Ndec)]
+
+
+def decimate_multiple_channels(Ndec, bdec, adec, X, zis):
+    """decimate_multiple for the rows of X [channels, n] in ONE device call (frt_decimate_multiple_state on a handle with that
+    many channels): `zis` is a list, one entry per channel, of Ndec state vectors.  Returns (outs [channels, n_out], new zis) — every
+    row what its own decimate_multiple call returns, bit for bit (the channels are independent slots of the same launches)."""
+    X = np.ascontiguousarray(X, np.float64)
+    C, n = X.shape
+    bdec = np.ascontiguousarray(bdec, np.float64)
+    adec = np.ascontiguousarray(adec, np.float64)
+    if n == 0 or Ndec == 0 or len(bdec) != 13 or len(adec) != 13 or Ndec > 8 or C * n > _IN_PLACE_MAX:
+        res = [decimate_multiple(Ndec, bdec, adec, X[c], zis[c]) for c in range(C)]
+        return np.stack([r[0] for r in res]), [r[1] for r in res]
+    lib = _lib.init()
+    h = _chain_handle(bdec, adec, C)
+    n_out = ctypes.c_int(0)
+    n_up = n
+    for _ in range(Ndec):
+        n_up = (n_up + 1) // 2
+    out = np.empty((C, n_up), np.float64)
+    zi = np.ascontiguousarray(np.stack([np.stack([np.asarray(z, np.float64) for z in zis[c][:Ndec]]) for c in range(C)]))
+    zf = np.empty((C, Ndec, 12), np.float64)
+    _lib.check(lib.frt_decimate_multiple_state(h, int(Ndec), X.ctypes.data, n, zi.ctypes.data, out.ctypes.data, ctypes.byref(n_out),
+                                               zf.ctypes.data))
+    assert n_out.value == n_up
+    return out, [[zf[c, j].copy() for j in range(Ndec)] for c in range(C)]
 
 
 def decimate_multiple_filtic(Ndec, bdec, adec):

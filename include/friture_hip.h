@@ -151,10 +151,12 @@ int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, int block, c
  * decimations by 2 of x [n_channels][n] -> out [n_channels][*n_out].  Needs a bands_per_octave = 0 handle. */
 int frt_decimate_multiple(frt_octbank* h, int n_stages, const double* x, int n, double* out, int* n_out);
 /* the same with the reference's functional interface (the states are arguments and results, decimate.py:45-71) as ONE call
- * on HOST arrays of one channel: zi / zf [n_stages][order] (order = the handle's decimator order: 12 for the bank's) or
- * NULL (zero state / not wanted); the handle's carried state is not touched.  The samples are read and the result written
- * in place in page-locked memory: roundup(8 n, 256) + 128 n_stages bytes must fit 256 KB, i.e. n <= 32 639 for two stages
- * (FRT_ERR_INVALID above that: use frt_octbank_set_state + frt_decimate_multiple). */
+ * on HOST arrays: x [n_channels][n] -> out [n_channels][*n_out], zi / zf [n_channels][n_stages][order] (order = the handle's
+ * decimator order: 12 for the bank's) or NULL (zero state / not wanted); the handle's carried state is not touched.  Every
+ * channel of the handle rides in the same n_stages launches (the delay estimator's two channels, delay_estimator.py:97-98).
+ * The samples are read and the result written in place in page-locked memory: roundup(8 n channels, 256) + 128 n_stages
+ * channels bytes must fit 256 KB, i.e. n <= 32 639 for one channel and two stages (FRT_ERR_INVALID above that: use
+ * frt_octbank_set_state + frt_decimate_multiple). */
 int frt_decimate_multiple_state(frt_octbank* h, int n_stages, const double* x, int n, const double* zi, double* out, int* n_out,
                                 double* zf);
 /* lfilter_float64_1D (friture/signal/lfilter.py:85-147): direct form II transposed IIR of one host
@@ -275,6 +277,15 @@ int frt_screen_columns(const double* norm, int nb, int n_cols, const double* fre
  * (previous is dropped when nt > nk). */
 int frt_exp_smooth_2d(const double* kernel, int nk, double alpha, const double* data, int nf, int nt, int64_t row_stride,
                       const double* previous, double* out);
+/* The octave-spectrum widget's smoothing of one chunk in ONE call (friture/octavespectrum.py:103-112 calls exp_smoothed_value
+ * once per band, friture/signal/exp_smoothing.py:40-56): group g = the nf[g] bands of one octave, which share kernel
+ * (kernels[g], nk[g] taps), alpha and length nt[g]; data[g] points at the group's rows (row_stride[g] doubles apart — the packed
+ * band signals frt_octbank_filter returns are laid out like this).  square != 0: every datum is squared first (the widget smooths
+ * y^2).  previous / out: one value per row, groups concatenated.  Every row equals its own frt_exp_smooth_2d call bit for bit.
+ * Host arrays only (one chunk of the widget). */
+int frt_exp_smooth_groups(int n_groups, const double* const* kernels, const int* nk, const double* alphas,
+                          const double* const* data, const int* nf, const int* nt, const int64_t* row_stride, int square,
+                          const double* previous, double* out);
 
 /* ---- spectrum widget post-processing (Spectrum_Widget.handle_new_data, friture/spectrum.py:156-182) --
  * psd: the n_frames new PSD frames [n_frames][frame_stride] (float when psd_is_f32, else double; the

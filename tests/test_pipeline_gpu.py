@@ -154,3 +154,32 @@ def test_fused_transform_pipeline_equals_block_by_block(hip):
             for b in (fused, plain):
                 b[2].colors[:] = b[2].colors[::-1].copy()            # in place
                 b[0].xscaled[:] = b[0].xscaled * 0.999               # in place
+
+
+def test_exp_smoothing_groups_equal_their_own_calls(hip):
+    """frt_exp_smooth_groups (the octave-spectrum widget's chunk in one launch): every row bit for bit what its own
+    exp_smoothed_value_2d call returns — ragged lengths, a group longer than its kernel (previous forgotten), an empty group, the
+    packed-rows form, and the squared form against squaring on the host."""
+    from friture_amd.signal.exp_smoothing import exp_smoothed_value_2d, exp_smoothed_value_groups
+    rng = np.random.default_rng(5)
+    shapes = [(3, 512), (3, 256), (2, 64), (3, 2), (1, 1), (2, 0), (3, 40)]
+    nks = [8192, 4096, 512, 64, 16, 16, 24]                    # the last group has more data than taps
+    alphas = [0.01, 0.02, 0.05, 0.1, 0.2, 0.3, 0.15]
+    kernels = [(1.0 - a) ** np.arange(nk - 1, -1, -1) for a, nk in zip(alphas, nks)]
+    blocks = [rng.standard_normal(sh) for sh in shapes]
+    prev = rng.random(sum(sh[0] for sh in shapes))
+    for square in (False, True):
+        got = exp_smoothed_value_groups(kernels, alphas, blocks, prev, square=square)
+        pos = 0
+        for k, a, b in zip(kernels, alphas, blocks):
+            want = exp_smoothed_value_2d(k, a, b * b if square else b, prev[pos:pos + b.shape[0]])
+            assert np.array_equal(got[pos:pos + b.shape[0]], want), (square, b.shape)
+            pos += b.shape[0]
+    # rows back to back in one buffer, handed over as (first row, count)
+    packed = np.concatenate([b.ravel() for b in blocks])
+    tuples, off = [], 0
+    for (r, n), b in zip(shapes, blocks):
+        tuples.append((packed[off:off + n], r) if n else b)
+        off += r * n
+    assert np.array_equal(exp_smoothed_value_groups(kernels, alphas, tuples, prev, square=True),
+                          exp_smoothed_value_groups(kernels, alphas, blocks, prev, square=True))
