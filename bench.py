@@ -659,8 +659,8 @@ def main():
         print(f"bench.py: ranks_seen = {ranks_seen}, expected 0..{world - 1}", file=sys.stderr)
         exit_code = 4
 
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():                  # (a group of one exists under FRT_DIST_FORCE=1: RCCL exercised on a single GPU)
         dist.destroy_process_group()
     if exit_code:
         raise SystemExit(exit_code)
