@@ -64,3 +64,21 @@ def test_every_distributed_helper_on_rccl_with_one_rank():
                MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "RCCL_SINGLE_RANK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(400)
+def test_bench_under_torchrun_on_rccl_with_one_rank():
+    """bench.py launched the way the contract launches it for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), with
+    N = 1 and FRT_DIST_FORCE=1: the table broadcast, rank gather, barriers, max-over-ranks and the optional slab gather of the
+    bench all run on RCCL with the product's kernels between them; the line must carry ranks_seen = [0] and a verified gather."""
+    import json
+    env = dict(os.environ, FRT_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29673", str(ROOT / "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-legs",
+           "--cpu-budget", "0", "--log2-samples", "22", "--gather-slabs"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=380, cwd=str(ROOT))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == [0] and line["parity"]["gate"]["pass"]
+    assert line["slab_gather"]["enabled"] and line["slab_gather"]["slabs_verified"]
