@@ -53,26 +53,39 @@ class Transform_Pipeline:
     def push(self, data):
         if not self._fusable():
             return reduce(lambda columns, stage: stage.push(columns), self.blocks, data)
-        fr, tr, ct = self.blocks
         data = np.asarray(data, np.float64)
         if data.ndim != 2 or data.shape[1] == 0:
             return reduce(lambda columns, stage: stage.push(columns), self.blocks, data)
+        norm = data.T                                          # frame-major: a column of the block is a row here
+        if not norm.flags.c_contiguous:
+            norm = np.ascontiguousarray(norm)
+        return self._push_frames(norm.ctypes.data, data.shape[0], data.shape[1])
+
+    def push_frames_device(self, norm_ptr, n_bins, n_cols):
+        """push() for a block that is already on the device, frame-major [n_cols][n_bins] float64 (what the STFT kernel writes):
+        the widget's chunk handler then costs ONE wait — transform enqueued, columns computed behind it (frt_screen_columns
+        launches on the null stream, which is ordered behind the blocking stream the transform ran on).  Only for the fusable
+        chain; the caller checks `fusable()`."""
+        return self._push_frames(norm_ptr, n_bins, n_cols)
+
+    def fusable(self):
+        return self._fusable()
+
+    def _push_frames(self, norm_ptr, n_bins, n_cols):
+        fr, tr, ct = self.blocks
         freq, targets, lut, p_freq, p_targets, p_lut = self._constant_tables(fr, ct)
-        if data.shape[0] != freq.size:
+        if n_bins != freq.size:
             raise ValueError("fp and xp are not of the same length.")          # numpy.interp's complaint
-        height, n_cols = targets.size, data.shape[1]
+        height = targets.size
         tr.set_height(height)                                  # Fourier-resamples the carried column on a resize
         total, src, a = tr.advance(n_cols)                     # the scalar index recurrence of Online_Linear_2D_resampler.push
         old_in = tr.old_data
         if old_in.dtype != np.float64 or not old_in.flags.c_contiguous:
             old_in = np.ascontiguousarray(old_in, np.float64)
-        norm = data.T                                          # frame-major: a column of the block is a row here
-        if not norm.flags.c_contiguous:
-            norm = np.ascontiguousarray(norm)
         n_out = len(src)
         pix = np.empty((height, max(n_out, 1)), np.uint32)
         old_out = np.empty(height)
-        rc = fr._lib.frt_screen_columns(norm.ctypes.data, freq.size, n_cols, p_freq, p_targets, height, old_in.ctypes.data,
+        rc = fr._lib.frt_screen_columns(norm_ptr, freq.size, n_cols, p_freq, p_targets, height, old_in.ctypes.data,
                                         src.ctypes.data if n_out else None, a.ctypes.data if n_out else None, n_out, p_lut,
                                         pix.ctypes.data if n_out else None, old_out.ctypes.data)
         if rc:

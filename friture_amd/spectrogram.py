@@ -63,13 +63,39 @@ class Spectrogram:
         last = self.old_index + (realizable - 1) * self.hop
         window = self.ringbuffer.data_indexed(last, span)
         self.old_index += realizable * self.hop
-        # (dB + w - min)/(max - min) per frame, reference layout (bins, frames)
-        norm_spectrogram = self._engine.norm(window[0:1, :].copy())[0].T
         self.screen_resampler.set_height(self.screen_height)
         screen_rate_frac = Fraction(max(self.screen_width, 1), int(self.timerange_s * 1000))
         self.screen_resampler.set_ratio(self.sfft_rate_frac, screen_rate_frac)
         self.frequency_resampler.setnsamples(self.screen_height)
+        if self.audio_pipeline.fusable():
+            # one wait per chunk: the frames' (dB + w - min)/(max - min) stay on the device, frame-major as the kernel writes them
+            # (enqueued, not waited for), and the fused pipeline call reads them there (until round 4: two host round trips)
+            return self.audio_pipeline.push_frames_device(self._norm_dev(window[0], realizable), len(self.freq), realizable)
+        # (dB + w - min)/(max - min) per frame, reference layout (bins, frames)
+        norm_spectrogram = self._engine.norm(window[0:1, :].copy())[0].T
         return self.audio_pipeline.push(norm_spectrogram)
+
+    def _norm_dev(self, samples, n_frames):
+        """Normalised dB frames [n_frames, bins] of a host window, left on the device.  frt_screen_columns launches on the null
+        stream, which is ordered behind blocking streams only (friture_hip.h): the engine is put on the null stream first."""
+        import ctypes
+
+        import torch
+
+        from . import _lib
+        from ._lib import FRT_STFT_NORM
+        x = np.ascontiguousarray(samples, np.float64)
+        nb = len(self.freq)
+        d = getattr(self, "_d_norm", None)
+        if d is None or d.shape[0] < n_frames or d.shape[1] != nb:
+            d = self._d_norm = torch.empty((max(n_frames, 8), nb), dtype=torch.float64, device="cuda")
+        nf = ctypes.c_int64(0)
+        e = self._engine
+        _lib.check(e._lib.frt_stft_set_stream(e._h, None))
+        _lib.check(e._lib.frt_stft_run(e._h, FRT_STFT_NORM, x.ctypes.data, x.shape[0], x.shape[0], ctypes.c_void_p(d.data_ptr()),
+                                       ctypes.byref(nf)))
+        assert nf.value == n_frames
+        return ctypes.c_void_p(d.data_ptr())
 
 
 class SpectrogramStream:
