@@ -70,6 +70,9 @@ class Octave_Filters:
             m = lens[NOCTAVE - 1 - k // self.bandsperoctave]
             y.append(packed[pos:pos + m])
             pos += m
+        # the band signals lie back to back in `packed`, the bands of an octave equally long: kept for callers that hand whole
+        # octaves on (OctaveSpectrum: one smoothing call per chunk) — valid until the next call
+        self._packed, self._packed_lens = packed, lens
         return y, list(dec)
 
     def get_decs(self):

@@ -44,11 +44,14 @@ class OctaveSpectrum:
         # back to back in the bank's packed output, so the chunk's 9 x bpo values are ONE call (frt_exp_smooth_groups, y^2 formed on
         # the device; until round 4: one call per octave, nine device round trips per chunk).
         blocks = []
-        for octave in range(NOCTAVE):
-            lo = octave * bpo
-            row, m = y[lo], y[lo].shape[0]
-            packed = all(y[lo + i].ctypes.data == row.ctypes.data + i * m * 8 and y[lo + i].shape[0] == m for i in range(1, bpo))
-            blocks.append((row, bpo) if packed and row.flags.c_contiguous else np.stack(y[lo:lo + bpo]))
+        if getattr(self.filters, "_packed", None) is not None and y[0].base is self.filters._packed:
+            blocks = [(y[octave * bpo], bpo) for octave in range(NOCTAVE)]      # this call's packed output: octaves are [bpo, m] blocks
+        else:
+            for octave in range(NOCTAVE):
+                lo = octave * bpo
+                row, m = y[lo], y[lo].shape[0]
+                packed = all(y[lo + i].ctypes.data == row.ctypes.data + i * m * 8 and y[lo + i].shape[0] == m for i in range(1, bpo))
+                blocks.append((row, bpo) if packed and row.flags.c_contiguous else np.stack(y[lo:lo + bpo]))
         sp = exp_smoothed_value_groups([self.kernels[o * bpo] for o in range(NOCTAVE)], [self.alphas[o * bpo] for o in range(NOCTAVE)],
                                        blocks, np.asarray(self.dispbuffers, np.float64), square=True)
         self.dispbuffers = list(sp)
