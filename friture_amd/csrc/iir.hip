@@ -1582,7 +1582,11 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
                 // traffic and, from 2 slices on, a launch that sums them: 2048 -> 256 took configs[4]'s 216-band bank from
                 // 0.90 to 0.72 ms and configs[2]'s from 0.72 to 0.70, profiles/r04_zero_state_slices.txt)
                 static const int wave_goal = getenv("FRT_ZS_WAVE_GOAL") ? atoi(getenv("FRT_ZS_WAVE_GOAL")) : device_cu_count();
-                while (n_slices < max_slices && colwaves * n_slices < wave_goal && a.chunk % (2 * n_slices * slice_min) == 0) n_slices *= 2;      // whole K-blocks per slice
+                // (a slice is at least 64 samples: below that the product is launch-bound whatever its grid, and the launch that
+                // sums the slices costs its ~5 us — the 64-sample chunks of the low-rate stages are not sliced: -1 % at 8 ch x 27 bands)
+                while (n_slices < max_slices && colwaves * n_slices < wave_goal && a.chunk % (2 * n_slices * slice_min) == 0 &&
+                       a.chunk / (2 * n_slices) >= 64)
+                    n_slices *= 2;      // whole K-blocks per slice
                 ZeroStateArgs z{};
                 z.x = a.x; z.x_stride = a.x_stride; z.n = a.n; z.in_f32 = a.in_f32;
                 z.chunk = a.chunk; z.nchunks = a.nchunks; z.n_channels = h->n_channels; z.nfilt = h->nfilt;
