@@ -174,3 +174,38 @@ def test_bench_stub_single_process():
     assert r.returncode == 0, r.stderr[-2000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert rec["n_gpus"] == 1 and rec["ranks_seen"] == [0] and rec["roofline"]["traffic"] is None
+
+
+def _forced_solo_worker(port, q):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FRT_DIST_FORCE="1")
+    import torch
+    import torch.distributed as dist
+    r, lr, w = distributed.init_process_group(backend="gloo")
+    assert (r, w) == (0, 1) and dist.is_initialized()          # a group of one exists only because it was forced
+    tabs = {"weight": np.linspace(-3, 1, 33), "lut": np.arange(256, dtype=np.uint32) | 0xFF000000}
+    got = distributed.broadcast_tables(tabs)
+    assert np.array_equal(got["weight"], tabs["weight"]) and got["lut"].dtype == np.uint32 and np.array_equal(got["lut"], tabs["lut"])
+    local = torch.arange(6, dtype=torch.float64).reshape(3, 2)
+    assert torch.equal(distributed.gather_channel_summaries(local, 3), local)
+    assert distributed.gather_scalars(0.25) == [0.25] and distributed.gather_ranks() == [0] and distributed.max_over_ranks(2.5) == 2.5
+    slab = torch.arange(24, dtype=torch.float32).reshape(2, 3, 4)
+    sg = distributed.SlabGather(slab, n_slots=2)
+    assert not sg.solo                                          # the collective really runs
+    sg.start(slab, 1)
+    g = sg.wait(1)
+    assert tuple(g.shape) == (1, 2, 3, 4) and torch.equal(g[0], slab)
+    distributed.barrier()
+    dist.destroy_process_group()
+    q.put("ok")
+
+
+def test_forced_group_of_one_runs_the_collectives():
+    """FRT_DIST_FORCE=1 (what tests/test_rccl_single_rank_gpu.py uses on the GPU box for RCCL): with a world of one the helpers
+    normally short-cut; forced, they go through the collective library — here gloo."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_solo_worker, args=(_free_port(), q))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0 and q.get(timeout=5) == "ok"
