@@ -415,6 +415,11 @@ class StubEngine:
         out[:] = (x[:, :1, None] * 1000).to(out.dtype)
         return out
 
+    def run_split(self, kind, x, rows, nyq):
+        rows[:] = (x[:, :1, None] * 1000).to(rows.dtype)
+        nyq[:] = (x[:, :1] * 1000).to(nyq.dtype)
+        return rows, nyq
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -426,6 +431,9 @@ def main():
     ap.add_argument("--log2-samples", type=int, default=26)
     ap.add_argument("--channels-per-gpu", type=int, default=1)
     ap.add_argument("--kind", choices=["image", "psd", "db"], default="image")
+    ap.add_argument("--layout", choices=["split", "packed"], default="split",
+                    help="output rows: split = [F][N/2] rows on 64-byte boundaries + a Nyquist plane [F] (frt_stft_run_split, the batch "
+                         "layout); packed = [F][N/2+1] (frt_stft_run, what the drop-in classes hand on).  Same values, same byte counts")
     ap.add_argument("--batches", type=int, default=3, help="distinct input batches the steps rotate over (1 = same batch every step)")
     ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed launches before the warm-up steps (GPU clock ramp)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for cpu_baseline (0 = skip)")
@@ -494,8 +502,17 @@ def main():
     eng.set_epilogue(consts["weight"], -140.0, 0.0, consts["lut"])
     kind = {"image": 3, "psd": 0, "db": 1}[args.kind]
     F = eng.frames_for(T)
-    outs = [torch.empty((len(my_channels), F, n_fft // 2 + 1), dtype=torch.int32 if kind == 3 else torch.float32, device=dev)
-            for _ in range(nbatch)]
+    split = args.layout == "split" and n_fft <= 1024 and not args.gather_slabs      # (the slab gather's check is written for packed slabs)
+    odt = torch.int32 if kind == 3 else torch.float32
+    if split:
+        # one allocation per batch: the rows (whole 64-byte lines each), then the Nyquist plane
+        slabs = [torch.empty((len(my_channels) * F * (n_fft // 2 + 1),), dtype=odt, device=dev) for _ in range(nbatch)]
+        nrow = len(my_channels) * F * (n_fft // 2)
+        rows = [sl[:nrow].view(len(my_channels), F, n_fft // 2) for sl in slabs]
+        nyqs = [sl[nrow:].view(len(my_channels), F) for sl in slabs]
+        outs = slabs
+    else:
+        outs = [torch.empty((len(my_channels), F, n_fft // 2 + 1), dtype=odt, device=dev) for _ in range(nbatch)]
 
     gather = None
     if args.gather_slabs:
@@ -503,11 +520,16 @@ def main():
             raise SystemExit("--gather-slabs needs --batches >= 2 (a slab is gathered while the next batch is computed)")
         gather = distributed.SlabGather(outs[0], n_slots=nbatch)
 
+    vdt = [odt]                                   # element type the buffers are viewed as (the PSD pass re-uses the image buffers)
+
     def step(k, rotate=True):
         b = k % nbatch if rotate else 0
         if gather is not None:
             gather.wait(b)                        # the previous gather of this buffer has read it
-        eng.run(kind, xs[b], outs[b])             # one kernel launch on torch's current stream
+        if split:
+            eng.run_split(kind, xs[b], rows[b].view(vdt[0]), nyqs[b].view(vdt[0]))      # one kernel launch on torch's current stream
+        else:
+            eng.run(kind, xs[b], outs[b].view(vdt[0]))
         if gather is not None:
             gather.start(outs[b], b)              # behind the launch above, beside the next step's
 
@@ -542,15 +564,17 @@ def main():
     # the same transform with its plain PSD output (no dB / weighting / colour epilogue), for reference
     psd_ms = None
     if kind == 3 and not stub:
-        image_outs, kind = outs, 0
-        outs = [o.view(torch.float32) for o in image_outs]
+        kind, vdt[0] = 0, torch.float32
         for k in range(args.warmup):
             step(k)
         psd_ms = distributed.max_over_ranks(timed(step, args.steps, dev, distributed, torch)[1], dev)
-        outs, kind = image_outs, 3
+        kind, vdt[0] = 3, odt
         for b in range(nbatch):
             step(b)                               # the images back in place (digest, parity)
-    out = outs[0]
+    if split:                                     # the timed batch's image in the packed shape the checks below are written for
+        out = torch.cat([rows[0], nyqs[0][..., None]], dim=2)
+    else:
+        out = outs[0]
 
     # post-batch summary gather (outside the timed region): per-channel mean pixel/PSD digest
     digest = out.to(torch.float64).mean(dim=(1, 2)).reshape(-1, 1)
@@ -558,12 +582,16 @@ def main():
 
     parity = None
     if rank == 0 and kind == 3 and not stub:
-        parity = image_parity_report(eng, xs[0], outs[0], n_fft, hop, consts["weight"], consts["lut"])
+        parity = image_parity_report(eng, xs[0], out, n_fft, hop, consts["weight"], consts["lut"])
+        parity["layout"] = "split rows + Nyquist plane of the timed launches, reassembled" if split else "packed"
+
 
     exit_code = 0
     legs = {}
     if not stub and not args.no_legs and n_fft == 1024:
         del xs, outs, out
+        if split:
+            del slabs, rows, nyqs
         torch.cuda.empty_cache()
         legs.update(stft1024_f64_leg(dev, world, rank, consts))
         legs.update(octave_legs(dev, world, rank, 8, 3, 22, "configs2_bank", True))
@@ -602,7 +630,9 @@ def main():
             "config": {"workload": f"rolling spectrogram: {n_fft}-pt Hann STFT, hop {hop}, "
                                    f"{'dB + A-weighting + colour LUT -> u32 pixels' if kind == 3 else args.kind}, "
                                    f"{cpg} ch/GPU x 2^{args.log2_samples} samples @ 48 kHz "
-                                   f"(BASELINE configs[1])",
+                                   f"(BASELINE configs[1]); output rows "
+                                   f"{'split: [F][N/2] on 64-byte boundaries + Nyquist plane [F] (frt_stft_run_split)' if split else 'packed [F][N/2+1] (frt_stft_run)'}",
+                       "layout": "split" if split else "packed",
                        "channels": n_channels, "spectra_per_step": spectra_per_step, "batches_rotated": nbatch,
                        "parallelism": f"channel-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "stft_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -42,6 +42,7 @@ SIGNATURES = {
     "frt_stft_set_stream": (c_int, [c_void_p, c_void_p]),
     "frt_stft_set_epilogue": (c_int, [c_void_p, POINTER(c_double), c_double, c_double, POINTER(c_uint32)]),
     "frt_stft_run": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_void_p, POINTER(c_int64)]),
+    "frt_stft_run_split": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p, POINTER(c_int64)]),
     "frt_stft_psd": (c_int, [c_void_p, POINTER(c_float), c_int64, POINTER(c_float), POINTER(c_int64)]),
     "frt_stft_image": (c_int, [c_void_p, POINTER(c_float), c_int64, POINTER(c_uint32), POINTER(c_int64)]),
     "frt_stft_analyzelive_f64": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double)]),

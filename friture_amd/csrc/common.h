@@ -33,6 +33,14 @@ void set_last_error(const char* fmt, ...);
         }                                          \
     } while (0)
 
+#define FRT_REQUIRE_CODE(cond, code, ...)          \
+    do {                                           \
+        if (!(cond)) {                             \
+            frt::set_last_error(__VA_ARGS__);      \
+            return (code);                         \
+        }                                          \
+    } while (0)
+
 // true when `p` points to device (or managed) memory usable by kernels directly.
 bool is_device_pointer(const void* p);
 

@@ -178,6 +178,15 @@ template <typename TIN, typename T, int LOG2M, int SHIFT>
 static int launch_one(const StftArgs& a, int blocks, hipStream_t stream) {
     using P = Pow2Plan<LOG2M>;
     constexpr int BLOCK = P::TPF < 256 ? 256 : P::TPF;
+    if (a.out_nyq) {                            // split rows (frt_stft_run_split): N <= 1024
+        if constexpr (LOG2M <= 9) {
+            hipLaunchKernelGGL((stft_kernel<TIN, T, LOG2M, SHIFT, true>), dim3(blocks), dim3(BLOCK), 0, stream, a);
+            FRT_HIP_CHECK(hipGetLastError());
+            return FRT_OK;
+        }
+        set_last_error("split output rows need fft_size <= 1024");
+        return FRT_ERR_UNSUPPORTED;
+    }
     hipLaunchKernelGGL((stft_kernel<TIN, T, LOG2M, SHIFT>), dim3(blocks), dim3(BLOCK), 0, stream, a);
     FRT_HIP_CHECK(hipGetLastError());
     return FRT_OK;
@@ -407,12 +416,13 @@ extern "C" int64_t frt_stft_frames_for(const frt_stft* h, int64_t T) {
     return (T - h->fft_size) / h->hop + 1;
 }
 
-static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride, void* d_out, int64_t F,
+static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride, void* d_out, void* d_nyq, int64_t F,
                        hipStream_t stream) {
     const int N = h->fft_size, M = N / 2;
     StftArgs a{};
     a.x = d_x;
     a.out = d_out;
+    a.out_nyq = d_nyq;
     a.window = h->window.ptr;
     a.tw = h->tw.ptr;
     a.twn = h->twn.ptr;
@@ -423,7 +433,7 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     a.lut = h->has_lut ? h->lut.as<uint32_t>() : nullptr;
     a.x_stride = x_stride;
     a.n_frames = F;
-    a.out_cstride = F * (M + 1);
+    a.out_cstride = F * (d_nyq ? M : M + 1);
     a.hop = h->hop;
     a.kind = kind;
     const size_t esz = h->precision == 32 ? 4 : 8;
@@ -468,11 +478,13 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
         if (run > 64) run = 64;
     }
     if (run > F) run = (int)F;
+    if (d_nyq && run > 64) run = 64;            // a run's Nyquist values ride in one register, a lane per frame
     a.run = run;
     a.frame_base = 0;
 
     // N >= 2048, aligned even hop: the radix-16 + wave-local instances (stft_big.h)
     const bool big_ok = h->log2m >= 10;
+    FRT_REQUIRE_CODE(!(big_ok && d_nyq), FRT_ERR_UNSUPPORTED, "frt_stft_run_split: split output rows need fft_size <= 1024 (got %d)", N);
     if (big_ok && a.vec2 && !h->force_generic) {
         int brun = h->run_length;
         if (brun <= 0) {
@@ -519,8 +531,8 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     return launch_size<double, double>(h->log2m, a, shift, blocks, stream);
 }
 
-extern "C" int frt_stft_run(frt_stft* h, int kind, const void* x, int64_t T, int64_t x_stride, void* out,
-                            int64_t* n_frames_out) {
+static int stft_run(frt_stft* h, int kind, const void* x, int64_t T, int64_t x_stride, void* out, void* nyq, bool split,
+                    int64_t* n_frames_out) {
     FRT_REQUIRE(h, "frt_stft_run: null handle");
     FRT_REQUIRE(kind >= FRT_STFT_PSD && kind <= FRT_STFT_IMAGE, "frt_stft_run: unknown output kind %d", kind);
     FRT_REQUIRE(kind != FRT_STFT_IMAGE || h->has_lut, "frt_stft_run: IMAGE output needs a colour LUT");
@@ -529,12 +541,14 @@ extern "C" int frt_stft_run(frt_stft* h, int kind, const void* x, int64_t T, int
     if (n_frames_out) *n_frames_out = F;
     if (F == 0) return FRT_OK;
     FRT_REQUIRE(x && out, "frt_stft_run: null buffer");
+    FRT_REQUIRE(!split || nyq, "frt_stft_run_split: null Nyquist plane");
     const bool dx = is_device_pointer(x), dout = is_device_pointer(out);
     FRT_REQUIRE(dx == dout || dout, "frt_stft_run: device samples need a device output");
-    const int nb = h->fft_size / 2 + 1;
+    FRT_REQUIRE(!split || is_device_pointer(nyq) == dout, "frt_stft_run_split: rows and Nyquist plane must live on the same side");
+    const int nb = split ? h->fft_size / 2 : h->fft_size / 2 + 1;        // values per row
     const size_t in_esz = h->precision == 32 ? 4 : 8;
     const size_t out_esz = (kind == FRT_STFT_IMAGE) ? 4 : in_esz;
-    if (dx) return stft_launch(h, kind, x, x_stride, out, F, h->stream);
+    if (dx) return stft_launch(h, kind, x, x_stride, out, nyq, F, h->stream);
     if (h->pin_pending) {                        // an earlier host -> device call may still be reading the pinned block
         FRT_HIP_CHECK(hipEventSynchronize(h->pin_done));
         h->pin_pending = false;
@@ -560,7 +574,7 @@ extern "C" int frt_stft_run(frt_stft* h, int kind, const void* x, int64_t T, int
             FRT_HIP_CHECK(hipMemcpyAsync(h->stage_in.ptr, h->pin, in_bytes, hipMemcpyHostToDevice, h->stream));
             src = h->stage_in.ptr;
         }
-        if ((rc = stft_launch(h, kind, src, x_stride, out, F, h->stream))) return rc;
+        if ((rc = stft_launch(h, kind, src, x_stride, out, nyq, F, h->stream))) return rc;
         if (!h->pin_done) FRT_HIP_CHECK(hipEventCreateWithFlags(&h->pin_done, hipEventDisableTiming));
         FRT_HIP_CHECK(hipEventRecord(h->pin_done, h->stream));
         h->pin_pending = true;
@@ -571,7 +585,8 @@ extern "C" int frt_stft_run(frt_stft* h, int kind, const void* x, int64_t T, int
     // time: audioproc.analyzelive) go through the handle's pinned block — from pageable memory the runtime stages every
     // copy itself and blocks the caller twice; large ones are copied in place.
     const size_t in_bytes = (size_t)h->n_channels * x_stride * in_esz;
-    const size_t out_bytes = (size_t)h->n_channels * F * nb * out_esz;
+    const size_t row_bytes = (size_t)h->n_channels * F * nb * out_esz;                       // split: the Nyquist plane follows the rows
+    const size_t out_bytes = row_bytes + (split ? (size_t)h->n_channels * F * out_esz : 0);
     int rc;
     if ((rc = h->stage_in.reserve(in_bytes))) return rc;
     if ((rc = h->stage_out.reserve(out_bytes))) return rc;
@@ -589,17 +604,38 @@ extern "C" int frt_stft_run(frt_stft* h, int kind, const void* x, int64_t T, int
     if (pinned && in_pad + out_bytes <= kZeroCopyMax) {
         // one frame or a few (audioproc.analyzelive): the kernel reads the pinned block and writes the spectrum into it — no
         // copy engine on either side, one launch and one synchronisation per call
-        if ((rc = stft_launch(h, kind, h->pin, x_stride, h->pin + in_pad, F, h->stream))) return rc;
+        if ((rc = stft_launch(h, kind, h->pin, x_stride, h->pin + in_pad, split ? h->pin + in_pad + row_bytes : nullptr, F, h->stream))) return rc;
         FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
-        memcpy(out, h->pin + in_pad, out_bytes);
+        memcpy(out, h->pin + in_pad, row_bytes);
+        if (split) memcpy(nyq, h->pin + in_pad + row_bytes, out_bytes - row_bytes);
         return FRT_OK;
     }
     FRT_HIP_CHECK(hipMemcpyAsync(h->stage_in.ptr, pinned ? (const void*)h->pin : x, in_bytes, hipMemcpyHostToDevice, h->stream));
-    if ((rc = stft_launch(h, kind, h->stage_in.ptr, x_stride, h->stage_out.ptr, F, h->stream))) return rc;
-    FRT_HIP_CHECK(hipMemcpyAsync(pinned ? (void*)(h->pin + in_pad) : out, h->stage_out.ptr, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    if ((rc = stft_launch(h, kind, h->stage_in.ptr, x_stride, h->stage_out.ptr, split ? (char*)h->stage_out.ptr + row_bytes : nullptr, F, h->stream))) return rc;
+    if (pinned) {
+        FRT_HIP_CHECK(hipMemcpyAsync(h->pin + in_pad, h->stage_out.ptr, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    } else {
+        FRT_HIP_CHECK(hipMemcpyAsync(out, h->stage_out.ptr, row_bytes, hipMemcpyDeviceToHost, h->stream));
+        if (split) FRT_HIP_CHECK(hipMemcpyAsync(nyq, (char*)h->stage_out.ptr + row_bytes, out_bytes - row_bytes, hipMemcpyDeviceToHost, h->stream));
+    }
     FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
-    if (pinned) memcpy(out, h->pin + in_pad, out_bytes);
+    if (pinned) {
+        memcpy(out, h->pin + in_pad, row_bytes);
+        if (split) memcpy(nyq, h->pin + in_pad + row_bytes, out_bytes - row_bytes);
+    }
     return FRT_OK;
+}
+
+extern "C" int frt_stft_run(frt_stft* h, int kind, const void* x, int64_t T, int64_t x_stride, void* out,
+                            int64_t* n_frames_out) {
+    return stft_run(h, kind, x, T, x_stride, out, nullptr, false, n_frames_out);
+}
+
+extern "C" int frt_stft_run_split(frt_stft* h, int kind, const void* x, int64_t T, int64_t x_stride, void* out_rows,
+                                  void* out_nyquist, int64_t* n_frames_out) {
+    FRT_REQUIRE(h, "frt_stft_run_split: null handle");
+    FRT_REQUIRE_CODE(h->fft_size <= 1024, FRT_ERR_UNSUPPORTED, "frt_stft_run_split: split output rows need fft_size <= 1024 (got %d)", h->fft_size);
+    return stft_run(h, kind, x, T, x_stride, out_rows, out_nyquist, true, n_frames_out);
 }
 
 extern "C" int frt_stft_psd(frt_stft* h, const float* x, int64_t T, float* psd_out, int64_t* n_frames_out) {

@@ -13,7 +13,8 @@ namespace frt {
 
 struct StftArgs {
     const void* x;         // [C][x_stride] samples
-    void* out;             // [C][F][M+1]
+    void* out;             // [C][F][M+1]; split layout: [C][F][M], bins 0..M-1 (every row a whole number of 64-byte lines)
+    void* out_nyq;         // split layout: [C][F], bin M of every frame; null = packed rows
     const void* window;    // [N] T
     const void* tw;        // [M] cpx<T>: exp(-2 pi i n / M)
     const void* twn;       // [M] cpx<T>: exp(-2 pi i k / N)
@@ -117,7 +118,23 @@ __device__ __forceinline__ void stream_store(T* p, T v) {
 #endif
 }
 
+// acc[lane] = the first active lane's v, other lanes of acc untouched (`lane` wave-uniform, `me` this lane's index)
+__device__ __forceinline__ uint32_t lane_insert(uint32_t acc, uint32_t v, int lane, int me) {
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    return me == lane ? b : acc;
+}
+__device__ __forceinline__ uint32_t value_bits_lo(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ uint32_t value_bits_lo(uint32_t v) { return v; }
+__device__ __forceinline__ uint32_t value_bits_lo(double v) { return (uint32_t)__double2loint(v); }
+__device__ __forceinline__ uint32_t value_bits_hi(float) { return 0u; }
+__device__ __forceinline__ uint32_t value_bits_hi(uint32_t) { return 0u; }
+__device__ __forceinline__ uint32_t value_bits_hi(double v) { return (uint32_t)__double2hiint(v); }
+
 // TIN: sample type in HBM; T: arithmetic type; SHIFT: register slots a hop advances (0 = reload all)
+// SPLIT: the split output layout (frt_stft_run_split): rows of M values, bins 0..M-1, so that every row is a whole number of
+// 64-byte lines and every wave-wide store of one-wavefront frames covers four whole lines (the packed layout's rows of M + 1
+// values start on 4-byte boundaries: a 256-byte store touches five lines, TCP_TCC_WRITE_REQ x1.25 of the lines written);
+// bin M (the Nyquist bin) of every frame goes to a plane of its own, collected in a register across the run
 // three waves per SIMD for the one-wave-per-frame instances: the float64 fix-up of the IMAGE kind would otherwise push the
 // N = 512 / 1024 instances two registers over the 168 that three waves allow (no spills at hop N/2 and N/4)
 #ifndef FRT_WAVE_MIN_WAVES
@@ -144,7 +161,7 @@ __device__ __forceinline__ void stream_store(T* p, T v) {
 #ifndef FRT_RING_WEIGHTS_IN_LDS
 #define FRT_RING_WEIGHTS_IN_LDS 0
 #endif
-template <typename TIN, typename T, int LOG2M, int SHIFT>
+template <typename TIN, typename T, int LOG2M, int SHIFT, bool SPLIT = false>
 __global__ void
 #if defined(FRT_WAVE_MIN_WAVES)
 __launch_bounds__((Pow2Plan<LOG2M>::TPF < 256 ? 256 : Pow2Plan<LOG2M>::TPF),
@@ -240,6 +257,10 @@ stft_kernel(const StftArgs a) {
     }
 
     const T norm_off = (T)a.norm_off, norm_scale = (T)a.norm_scale;
+    static_assert(!SPLIT || WAVE, "split rows: N <= 1024");
+    constexpr int PITCH = SPLIT ? M : M + 1;            // values per output row
+    constexpr bool NYQ_REG = SPLIT && TPF == 64;        // lane g of these registers holds frame g's Nyquist value until the run ends
+    uint32_t nyq_lo = 0, nyq_hi = 0;
 
     typedef T tv2 __attribute__((ext_vector_type(2)));     // a slot stays ONE 64-bit register pair from the load to the window multiply
     auto load_slot = [&](long long f, int j) -> tv2 {
@@ -464,17 +485,40 @@ stft_kernel(const StftArgs a) {
         if (valid) {
             // element offsets of the 8 (+1) bins inside the row
             const int klo = i, khi = M - i;
-            T* row = outc + (f0 + g) * (M + 1);
-            auto store_all = [&](auto* r, auto conv) {
+            T* row = outc + (f0 + g) * PITCH;
+            // the frame's nine values: vals[j] = bin klo + j TPF, vals[4 + j] = bin khi - j TPF, mid = bin M/2 (lane 0 of the group)
+            auto store_row = [&](auto* r, const auto* vals, auto mid) {
+                if constexpr (!SPLIT) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    stream_store(r + klo + j * TPF, conv(res[j]));
-                    stream_store(r + khi - j * TPF, conv(res[4 + j]));
+                    for (int j = 0; j < 4; ++j) {
+                        stream_store(r + klo + j * TPF, vals[j]);
+                        stream_store(r + khi - j * TPF, vals[4 + j]);
+                    }
+                    if (i == 0) stream_store(r + M / 2, mid);
+                } else {
+                    // descending side: lanes 1..TPF-1 hold bins M - j TPF - i; lane 0 holds M - j TPF, which belongs to the
+                    // 64-value block ABOVE — it stores the value it holds for that block's lowest bin instead (slot j + 1, or
+                    // the self-paired bin M/2 for j = 3), so that every store covers [M - (j + 1) TPF, M - j TPF) exactly
+                    const int ihi = i == 0 ? TPF : i;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        stream_store(r + klo + j * TPF, vals[j]);
+                        auto hv = vals[4 + j];
+                        if (i == 0) hv = j < 3 ? vals[5 + (j < 3 ? j : 0)] : mid;
+                        stream_store(r + M - ihi - j * TPF, hv);
+                    }
+                    // bin M (lane 0, slot 4)
+                    if constexpr (NYQ_REG) {
+                        nyq_lo = lane_insert(nyq_lo, value_bits_lo(vals[4]), g & 63, i);
+                        if constexpr (sizeof(*vals) == 8) nyq_hi = lane_insert(nyq_hi, value_bits_hi(vals[4]), g & 63, i);
+                    } else if (i == 0) {
+                        typedef std::remove_cv_t<std::remove_pointer_t<decltype(vals)>> V;
+                        stream_store((V*)a.out_nyq + chan * a.n_frames + (f0 + g), vals[4]);
+                    }
                 }
-                if (i == 0) stream_store(r + M / 2, conv(res_mid));
             };
             if (a.kind == FRT_STFT_PSD) {
-                store_all(row, [](T x) { return x; });
+                store_row(row, res, res_mid);
             } else {
                 T wl[4], wh[4];
 #pragma unroll
@@ -493,7 +537,7 @@ stft_kernel(const StftArgs a) {
                 if constexpr (WLDS) wdb_mid = wgt_lds[M / 2];
                 if (a.kind == FRT_STFT_IMAGE) {
                     // colour words are 4 bytes whatever the arithmetic type
-                    uint32_t* prow = (uint32_t*)a.out + chan * a.out_cstride + (f0 + g) * (M + 1);
+                    uint32_t* prow = (uint32_t*)a.out + chan * a.out_cstride + (f0 + g) * PITCH;
                     // float32: with the dB floor below the LUT's range everywhere, P + 1e-30 rounds to P for every P that
                     // is not clamped to index 0 anyway, and the add is left out (eps_free, frt_stft_set_epilogue)
                     auto colour_row = [&](auto eps_free) {
@@ -560,12 +604,7 @@ stft_kernel(const StftArgs a) {
                                 }
                             }
                         }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            stream_store(prow + klo + j * TPF, colour[j]);
-                            stream_store(prow + khi - j * TPF, colour[4 + j]);
-                        }
-                        if (i == 0) stream_store(prow + M / 2, colour[8]);
+                        store_row(prow, colour, colour[8]);
                     };
                     if (a.eps_free) colour_row(std::true_type{});
                     else colour_row(std::false_type{});
@@ -581,7 +620,7 @@ stft_kernel(const StftArgs a) {
                         for (int j = 0; j < 8; ++j) res[j] = (res[j] + norm_off) * norm_scale;
                         res_mid = (res_mid + norm_off) * norm_scale;
                     }
-                    store_all(row, [](T x) { return x; });
+                    store_row(row, res, res_mid);
                 }
             }
         }
@@ -597,6 +636,14 @@ stft_kernel(const StftArgs a) {
             if constexpr (NSETS > 3) {
                 if (!frame(std::integral_constant<int, 3>{}, g + 3)) break;
             }
+        }
+    }
+    if constexpr (NYQ_REG) {
+        // the run's Nyquist values: lane g holds frame g's (runs are at most 64 frames, stft_launch)
+        if (i < nfr) {
+            const long long at = chan * a.n_frames + f0 + i;
+            if (a.kind == FRT_STFT_IMAGE || sizeof(T) == 4) ((uint32_t*)a.out_nyq)[at] = nyq_lo;
+            else ((double*)a.out_nyq)[at] = __hiloint2double((int)nyq_hi, (int)nyq_lo);
         }
     }
 }

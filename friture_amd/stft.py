@@ -111,6 +111,52 @@ class StftEngine:
                                           ctypes.c_void_p(out.data_ptr()), ctypes.byref(nf)))
         return out
 
+    def run_split(self, kind: int, x, out_rows=None, out_nyquist=None):
+        """The same transform with split output rows (frt_stft_run_split, fft_size <= 1024): returns
+        (rows [C, F, N/2] = bins 0..N/2-1, nyquist [C, F] = bin N/2).  Bit-identical values to run(); rows are whole
+        64-byte lines, which is what the batch path's row stores want."""
+        in_dtype = np.float32 if self.precision == 32 else np.float64
+        half = self.fft_size // 2
+        nf = ctypes.c_int64(0)
+        if _is_torch(x):
+            import torch
+            want = torch.float32 if self.precision == 32 else torch.float64
+            if not x.is_cuda or x.dtype != want or not x.is_contiguous():
+                raise ValueError(f"expected a contiguous CUDA (HIP) {want} tensor")
+            if x.dim() == 1:
+                x = x[None, :]
+            if x.shape[0] != self.n_channels:
+                raise ValueError(f"expected {self.n_channels} channels, got {x.shape[0]}")
+            T = x.shape[1]
+            F = self.frames_for(T)
+            xstride = x.stride(0) if x.shape[0] > 1 else T
+            odt = torch.int32 if kind == FRT_STFT_IMAGE else want
+            if out_rows is None:
+                out_rows = torch.empty((self.n_channels, F, half), dtype=odt, device=x.device)
+            if out_nyquist is None:
+                out_nyquist = torch.empty((self.n_channels, F), dtype=odt, device=x.device)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _lib.check(self._lib.frt_stft_set_stream(self._h, ctypes.c_void_p(stream)))
+            _lib.check(self._lib.frt_stft_run_split(self._h, kind, ctypes.c_void_p(x.data_ptr()), T, xstride,
+                                                    ctypes.c_void_p(out_rows.data_ptr()), ctypes.c_void_p(out_nyquist.data_ptr()),
+                                                    ctypes.byref(nf)))
+            return out_rows, out_nyquist
+        x = np.ascontiguousarray(x, in_dtype)
+        if x.ndim == 1:
+            x = x[None, :]
+        if x.shape[0] != self.n_channels:
+            raise ValueError(f"expected {self.n_channels} channels, got {x.shape[0]}")
+        T = x.shape[1]
+        F = self.frames_for(T)
+        out_dtype = np.uint32 if kind == FRT_STFT_IMAGE else in_dtype
+        if out_rows is None:
+            out_rows = np.empty((self.n_channels, F, half), out_dtype)
+        if out_nyquist is None:
+            out_nyquist = np.empty((self.n_channels, F), out_dtype)
+        _lib.check(self._lib.frt_stft_run_split(self._h, kind, x.ctypes.data, T, T, out_rows.ctypes.data,
+                                                out_nyquist.ctypes.data, ctypes.byref(nf)))
+        return out_rows, out_nyquist
+
     def psd(self, x, out=None):
         return self.run(FRT_STFT_PSD, x, out)
 

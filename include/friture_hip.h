@@ -81,6 +81,17 @@ int frt_stft_set_epilogue(frt_stft* h, const double* weight_db, double spec_min,
  * device (the samples go up through page-locked memory, the call returns without waiting: order consumers on the stream). */
 int frt_stft_run(frt_stft* h, int kind, const void* x, int64_t T, int64_t x_stride, void* out,
                  int64_t* n_frames_out);
+/* The same transform with SPLIT output rows (fft_size <= 1024; FRT_ERR_UNSUPPORTED above): out_rows[c][f][k] holds
+ * bins k = 0..fft_size/2-1 — rows of fft_size/2 values, so that every row is a whole number of 64-byte lines when
+ * out_rows is 64-byte aligned — and out_nyquist[c][f] holds bin fft_size/2 of every frame (element types as for
+ * frt_stft_run).  Values are bit-identical to frt_stft_run's; only their addresses differ.  The reference's own array is
+ * (N/2+1, frames), frequency-major (friture/spectrogram.py:149-159, friture/spectrum.py:144-155), so neither layout is
+ * its transpose-free image: the packed rows of frt_stft_run are what the drop-in classes hand on, the split rows are for
+ * batch consumers — a row store of the packed layout starts on a 4-byte boundary and touches five 64-byte lines where
+ * this one touches four.  Same host / device pointer rules as frt_stft_run; out_rows and out_nyquist
+ * on the same side. */
+int frt_stft_run_split(frt_stft* h, int kind, const void* x, int64_t T, int64_t x_stride, void* out_rows,
+                       void* out_nyquist, int64_t* n_frames_out);
 /* survey-named conveniences (precision-32 handles): */
 int frt_stft_psd(frt_stft* h, const float* x, int64_t T, float* psd_out, int64_t* n_frames_out);
 int frt_stft_image(frt_stft* h, const float* x, int64_t T, uint32_t* rgba_out, int64_t* n_frames_out);

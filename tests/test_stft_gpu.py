@@ -459,3 +459,83 @@ def test_randomised_shapes_against_oracle(engine_cls):
         for c in range(C):
             ref = dsp.stft_psd(x[c].astype(np.float64), n_fft, hop)
             assert per_frame_err(got[c], ref) <= tol, (trial, n_fft, hop, C, frames, precision, run, c)
+
+
+# ---- split output rows (frt_stft_run_split): rows of N/2 values on 64-byte boundaries + a Nyquist plane -------------------
+
+def _packed_from_split(rows, nyq):
+    return np.concatenate([np.asarray(rows), np.asarray(nyq)[..., None]], axis=-1)
+
+
+@pytest.mark.parametrize("n_fft", [32, 64, 128, 256, 512, 1024])
+@pytest.mark.parametrize("precision", [32, 64])
+def test_split_rows_equal_packed_rows_bit_for_bit(engine_cls, n_fft, precision):
+    """Every N <= 1024 instance (hop N/2, N/4: register window / ring; generic even and odd hops: reload path), every output
+    kind, host buffers and device tensors, several run lengths: the split layout holds the packed layout's values at other
+    addresses — and the packed layout is what the oracle / golden tests above pin."""
+    import torch
+    from friture_amd import palette, tables
+    weight = tables.weighting_db(tables.rfft_frequencies(n_fft), 1e-50)[0]
+    lut = palette.cmr_lut()
+    dt = np.float32 if precision == 32 else np.float64
+    for hop in (n_fft // 2, n_fft // 4, 3 * n_fft // 8, n_fft // 2 + 1):
+        for C, frames, run in ((1, 1, 0), (2, 67, 0), (3, 130, 64), (1, 23, 3), (2, 200, 100)):
+            T = n_fft + hop * (frames - 1) + 4
+            x = np.stack([synth(("noise", "tone", "chirp")[c % 3], T, 11 + c) for c in range(C)]).astype(dt)
+            e = engine_cls(n_fft, hop, C, precision)
+            e.set_epilogue(weight, -140.0, 0.0, lut)
+            e.set_run_length(run)
+            xd = torch.from_numpy(x).cuda()
+            for kind in (0, 1, 2, 3):
+                packed = e.run(kind, x)
+                rows, nyq = e.run_split(kind, x)
+                assert rows.shape == (C, frames, n_fft // 2) and nyq.shape == (C, frames)
+                assert np.array_equal(_packed_from_split(rows, nyq).view(np.uint8), packed.view(np.uint8)), (hop, C, frames, run, kind, "host")
+                drows, dnyq = e.run_split(kind, xd)
+                torch.cuda.synchronize()
+                got = _packed_from_split(drows.cpu().numpy(), dnyq.cpu().numpy())
+                assert np.array_equal(got.view(np.uint8), packed.view(np.uint8)), (hop, C, frames, run, kind, "device")
+
+
+def test_split_rows_against_oracle_and_golden(golden, engine_cls):
+    """The split layout against the reference-recorded golden PSD and the oracle directly (not only through the packed rows)."""
+    g = golden("psd")
+    for key, n_fft, hop in (("N1024_hop512_noise", 1024, 512), ("N1024_hop256_tone", 1024, 256), ("N256_hop64_tone", 256, 64)):
+        x, ref = g[key + "_x"], g[key + "_psd"]
+        rows, nyq = engine_cls(n_fft, hop, 1, 32).run_split(0, x)
+        assert per_frame_err(_packed_from_split(rows, nyq)[0], ref) <= TOL32
+        rows, nyq = engine_cls(n_fft, hop, 1, 64).run_split(0, x.astype(np.float64))
+        assert per_frame_err(_packed_from_split(rows, nyq)[0], ref) <= TOL64
+    x = synth("noise", 1024 + 512 * 99, 5)
+    rows, nyq = engine_cls(1024, 512, 1, 32).run_split(0, x)
+    assert per_frame_err(_packed_from_split(rows, nyq)[0], dsp.stft_psd(x.astype(np.float64), 1024, 512)) <= TOL32
+
+
+def test_split_rows_edge_cases(engine_cls):
+    from friture_amd._lib import FritureHipError
+    e = engine_cls(1024, 512, 2, 32)
+    rows, nyq = e.run_split(0, np.zeros((2, 1023), np.float32))            # fewer samples than a frame: no spectra
+    assert rows.shape == (2, 0, 512) and nyq.shape == (2, 0)
+    with pytest.raises(FritureHipError) as err:
+        engine_cls(2048, 1024, 1, 32).run_split(0, np.zeros((1, 8192), np.float32))
+    assert err.value.status == -4                                          # FRT_ERR_UNSUPPORTED: split rows are an N <= 1024 layout
+
+
+def test_split_rows_full_size_headline_image(engine_cls):
+    """BASELINE configs[1] at full size in the layout bench.py times (split rows, colour kind): every one of the 131 071 x 513
+    pixels equals the packed-layout image, whose every pixel is accounted for against the float64 reference by
+    test_full_size_headline_every_frame_against_the_float64_instance; the rows lie on 64-byte boundaries."""
+    import torch
+    from friture_amd import palette, tables
+    T, n_fft, hop = 1 << 26, 1024, 512
+    x = torch.from_numpy((0.25 * np.random.default_rng(42).standard_normal(T, dtype=np.float32))[None]).cuda()
+    weight = tables.weighting_db(tables.rfft_frequencies(n_fft), 1e-50)[0]
+    e = engine_cls(n_fft, hop, 1, 32)
+    e.set_epilogue(weight, -140.0, 0.0, palette.cmr_lut())
+    for kind in (3, 0):
+        packed = e.run(kind, x)
+        rows, nyq = e.run_split(kind, x)
+        torch.cuda.synchronize()
+        assert rows.shape == (1, 131071, 512) and rows.data_ptr() % 64 == 0 and rows.stride(1) * rows.element_size() % 64 == 0
+        assert torch.equal(rows.view(torch.int32), packed[..., :512].view(torch.int32))
+        assert torch.equal(nyq.view(torch.int32), packed[..., 512].view(torch.int32))

@@ -3,7 +3,7 @@
 //   stft_selftest check            parity of every FFT size / hop class / output kind against a
 //                                  double-precision host FFT (not the oracle: a quick sanity gate
 //                                  that runs without Python)
-//   stft_selftest bench [N hop C log2T kind run iters]
+//   stft_selftest bench [N hop C log2T kind run iters precision split]
 //                                  HIP-event timing of frt_stft_run on device-resident input
 #include <hip/hip_runtime.h>
 
@@ -179,7 +179,8 @@ static int do_check() {
     return fails ? 1 : 0;
 }
 
-static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int iters, int precision) {
+static int64_t nf_g;
+static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int iters, int precision, int split) {
     const int64_t T = 1ll << log2T;
     frt_stft* h = nullptr;
     CK(frt_stft_create(&h, N, hop, C, precision));
@@ -203,6 +204,11 @@ static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int ite
     char* dx0;
     char* dout0;
     const size_t out_bytes = (size_t)C * F * nb * oesz, in_bytes = x.size() * esz;
+    const size_t row_bytes = (size_t)C * F * (nb - 1) * oesz;        // split layout: the rows, then the Nyquist plane, in the same allocation
+    auto run_once = [&](const void* xin, char* o) {
+        if (split) CK(frt_stft_run_split(h, kind, xin, T, T, o, o + row_bytes, &nf_g));
+        else CK(frt_stft_run(h, kind, xin, T, T, o, &nf_g));
+    };
     HK(hipMalloc(&dx0, in_bytes * sets));
     HK(hipMalloc(&dout0, out_bytes * sets));
     for (int k = 0; k < sets; ++k) HK(hipMemcpy(dx0 + in_bytes * k, xhost, in_bytes, hipMemcpyHostToDevice));
@@ -221,18 +227,18 @@ static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int ite
         clock_gettime(CLOCK_MONOTONIC, &t0);
         int k = 0;
         for (;;) {
-            for (int i = 0; i < 64; ++i, ++k) CK(frt_stft_run(h, kind, dx0 + in_bytes * (k % sets), T, T, dout0 + out_bytes * (k % sets), &nf));
+            for (int i = 0; i < 64; ++i, ++k) run_once(dx0 + in_bytes * (k % sets), dout0 + out_bytes * (k % sets));
             HK(hipStreamSynchronize(s));
             clock_gettime(CLOCK_MONOTONIC, &t1);
             if ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 >= prewarm_ms) break;
         }
     }
-    for (int i = 0; i < 3; ++i) CK(frt_stft_run(h, kind, dx, T, T, dout, &nf));
+    for (int i = 0; i < 3; ++i) run_once(dx, (char*)dout);
     hipEvent_t e0, e1;
     HK(hipEventCreate(&e0));
     HK(hipEventCreate(&e1));
     HK(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) CK(frt_stft_run(h, kind, dx0 + in_bytes * (i % sets), T, T, dout0 + out_bytes * (i % sets), &nf));
+    for (int i = 0; i < iters; ++i) run_once(dx0 + in_bytes * (i % sets), dout0 + out_bytes * (i % sets));
     HK(hipEventRecord(e1, s));
     HK(hipEventSynchronize(e1));
     float ms = 0;
@@ -245,7 +251,7 @@ static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int ite
         struct timespec ts = {0, 300000};
         nanosleep(&ts, nullptr);
         HK(hipEventRecord(e0, s));
-        CK(frt_stft_run(h, kind, dx, T, T, dout, &nf));
+        run_once(dx, (char*)dout);
         HK(hipEventRecord(e1, s));
         HK(hipEventSynchronize(e1));
         float m1 = 0;
@@ -256,8 +262,8 @@ static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int ite
     const double per = ms / iters * 1e-3;
     const double spectra = (double)C * F / per;
     const double bytes = (double)C * F * ((double)esz * hop + (double)oesz * nb);
-    printf("bench p%d N=%d hop=%d C=%d T=2^%d F=%lld kind=%d run=%d sets=%d: %.3f ms/launch  %.4e spectra/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)  [isolated launch: %.3f ms]\n",
-           precision, N, hop, C, log2T, (long long)F, kind, run, sets, per * 1e3, spectra, bytes / per * 1e-9, bytes / per / 8e12 * 100, iso_ms);
+    printf("bench p%d N=%d hop=%d C=%d T=2^%d F=%lld kind=%d run=%d sets=%d %s: %.3f ms/launch  %.4e spectra/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)  [isolated launch: %.3f ms]\n",
+           precision, N, hop, C, log2T, (long long)F, kind, run, sets, split ? "split" : "packed", per * 1e3, spectra, bytes / per * 1e-9, bytes / per / 8e12 * 100, iso_ms);
     frt_stft_destroy(h);
     HK(hipFree(dx0));
     HK(hipFree(dout0));
@@ -279,8 +285,9 @@ int main(int argc, char** argv) {
         int run = argc > 7 ? atoi(argv[7]) : 0;
         int iters = argc > 8 ? atoi(argv[8]) : 20;
         int precision = argc > 9 ? atoi(argv[9]) : 32;
-        return do_bench(N, hop, C, log2T, kind, run, iters, precision);
+        int split = argc > 10 ? atoi(argv[10]) : 0;
+        return do_bench(N, hop, C, log2T, kind, run, iters, precision, split);
     }
-    fprintf(stderr, "usage: stft_selftest check | bench [N hop C log2T kind run iters precision]\n");
+    fprintf(stderr, "usage: stft_selftest check | bench [N hop C log2T kind run iters precision split]\n");
     return 2;
 }
