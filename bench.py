@@ -77,6 +77,51 @@ def kernel_source_digest() -> str:
     return h.hexdigest()[:16]
 
 
+# Keys whose values are prose: they say how a figure was obtained, which DESIGN.md §6 and this file's docstrings also say.  They
+# stay in the full record (--full-json) and leave the printed line, which the driver keeps only the last ~8 KB of.
+PROSE_KEYS = frozenset({"mode", "model", "f64_note", "note", "traffic_note"})
+LINE_BUDGET = 7000
+
+
+def compact_line(result: dict) -> dict:
+    """The record as printed: no prose keys, floats at 5 significant digits, `octave_bands` as a pointer to its leg plus the
+    contract-style figures (the leg itself is in `legs`).  Everything numeric survives; tests/test_bench_line.py holds the
+    printed line of a full run (every leg) under LINE_BUDGET characters."""
+    def walk(o):
+        if isinstance(o, dict):
+            return {k: walk(v) for k, v in o.items() if k not in PROSE_KEYS}
+        if isinstance(o, (list, tuple)):
+            return [walk(v) for v in o]
+        if isinstance(o, float):
+            return float(f"{o:.5g}")
+        return o
+    out = walk(result)
+    for k in ("value", "ms_per_step"):              # the contract's own figures keep their digits (value x ms_per_step is checked)
+        if k in result:
+            out[k] = result[k]
+    roof_keys = ("bound", "kernel", "achieved", "frac", "kernel_ms", "hbm_frac", "f64_frac")      # (unit and peak follow from `bound`)
+    parity_keys = ("frames_checked", "pixels_mismatched", "mismatch_unaccounted", "epilogue_mismatch_outside_edge",
+                   "psd_rel_max", "gate")
+
+    def base(b):
+        short = {k: b[k] for k in ("value", "cores", "sample") if k in b}          # (unit = the leg's, kind = the headline's)
+        if isinstance(b.get("all_cores"), dict):
+            short["all_cores"] = {k: b["all_cores"][k] for k in ("value", "cores") if k in b["all_cores"]}
+        return short
+    for lg in (out.get("legs") or {}).values():
+        if isinstance(lg.get("roofline"), dict):
+            lg["roofline"] = {k: lg["roofline"][k] for k in roof_keys if k in lg["roofline"]}
+        if isinstance(lg.get("parity"), dict):
+            lg["parity"] = {k: lg["parity"][k] for k in parity_keys if k in lg["parity"]}
+        if isinstance(lg.get("cpu_baseline"), dict):
+            lg["cpu_baseline"] = base(lg["cpu_baseline"])
+    ob = out.get("octave_bands")
+    if isinstance(ob, dict) and "legs" in out:
+        out["octave_bands"] = {"leg": "configs2_bank_iir_time_parallel", "value": ob.get("value"), "unit": ob.get("unit"),
+                               "ms_per_step": ob.get("ms_per_step")}
+    return out
+
+
 def cpu_baseline(x: np.ndarray, n_fft: int, hop: int, weight, lut, budget_s: float, with_legs: bool = True):
     """Oracle timed on the host over a bounded sample of the same channel: on one core (about 60 % of
     budget_s seconds of CPU work: a prefix of the channel, repeated when the whole channel is shorter),
@@ -98,11 +143,9 @@ def cpu_baseline(x: np.ndarray, n_fft: int, hop: int, weight, lut, budget_s: flo
         dsp.spectrogram_image(xs, n_fft, hop, weight, -140.0, 0.0, lut)
     dt = time.perf_counter() - t0
     result = {"value": frames * passes / dt, "unit": "spectra/s", "cores": 1, "kind": "port",
-              "sample": f"{passes} pass(es) over the first {frames} of {frames_total} spectra of channel 0 (same input), {dt:.1f} s; "
-                        f"timed code: oracle/dsp.py, the numpy float64 restatement of audioproc.analyzelive + dB + A-weighting + "
-                        f"colour LUT that is bit-exact against the reference (tests/golden) — the reference checkout itself is not "
-                        f"present on this box, hence kind = port; the restatement is the faster of the two (no per-frame Python "
-                        f"object overhead), so this baseline is conservative",
+              # kind = port: the reference checkout is not on the bench box; oracle/dsp.py is its numpy float64 restatement
+              # (analyzelive + dB + A-weighting + colour LUT), bit-exact against it (tests/golden) and the faster of the two
+              "sample": f"{passes} pass(es) x first {frames} of {frames_total} spectra of ch 0 (same input), {dt:.1f} s, oracle/dsp.py",
               "host_cpus": os.cpu_count()}
     # every core: one spawned worker per core (workers import numpy + the oracle only, never the GPU runtime); the same pool
     # then times the other halves of the metric — the octave banks (both variants, bpo 3 and 24) and GCC-PHAT — whose
@@ -115,15 +158,14 @@ def cpu_baseline(x: np.ndarray, n_fft: int, hop: int, weight, lut, budget_s: flo
                  "octave_iir_bpo24": (cpu_bench.octave_blocks, (0, 24, nb24, "iir"), "octave-bands/s"),
                  "octave_ola_bpo24": (cpu_bench.octave_blocks, (0, 24, nb24, "ola"), "octave-bands/s"),
                  "gcc_phat": (cpu_bench.gcc_windows, (4242, 24000, nwin), "windows/s")} if with_legs else {}
-    what = {"iir": "exact IIR bank (friture/filter.py:86-118) through oracle/iir_ref.c", "ola": "FFT overlap-add bank "
-            "(friture/octavefilters.py:49-58) in numpy"}
     for name, (fn, job, unit) in side_jobs.items():
         t0 = time.perf_counter()
         units, _ = fn(job)
         dt1 = time.perf_counter() - t0
-        sample = (f"{job[2]} blocks of 1024 samples of one channel, bpo {job[1]}: {what[job[3]]} + smoothed band energies + dB per block, {dt1:.2f} s"
-                  if fn is cpu_bench.octave_blocks else
-                  f"{job[2]} window pairs of L = {job[1]} (numpy rfft/irfft float64, friture/signal/correlation.py:24-43) + arg-max, {dt1:.2f} s")
+        # octave legs: the exact IIR bank through oracle/iir_ref.c or the FFT overlap-add bank in numpy, + smoothed band energies
+        # + dB per block; GCC-PHAT: numpy rfft / irfft float64 (friture/signal/correlation.py:24-43) + arg-max
+        sample = (f"{job[2]} blocks x 1024 samples, 1 ch, bpo {job[1]}, {job[3]}, {dt1:.2f} s" if fn is cpu_bench.octave_blocks else
+                  f"{job[2]} window pairs, L = {job[1]}, {dt1:.2f} s")
         side[name] = {"value": units / dt1, "unit": unit, "cores": 1, "kind": "port", "sample": sample}
     try:
         import multiprocessing as mp
@@ -139,14 +181,14 @@ def cpu_baseline(x: np.ndarray, n_fft: int, hop: int, weight, lut, budget_s: flo
             done = list(pool.map(cpu_bench.spectrogram_passes, [job] * cores))
             wall = time.perf_counter() - t0
             result["all_cores"] = {"value": sum(d[0] for d in done) / wall, "unit": "spectra/s", "cores": cores,
-                                   "sample": f"{cores} worker processes x {wframes} spectra of the same prefix, {wall:.1f} s"}
+                                   "sample": f"{cores} processes x {wframes} spectra, {wall:.1f} s"}
             for name, (fn, sjob, unit) in side_jobs.items():
                 sjob = (sjob[0], sjob[1], max(8, sjob[2] // 4), *sjob[3:])
                 t0 = time.perf_counter()
                 done = list(pool.map(fn, [sjob] * cores))
                 wall = time.perf_counter() - t0
                 side[name]["all_cores"] = {"value": sum(d[0] for d in done) / wall, "unit": unit, "cores": cores,
-                                           "sample": f"{cores} worker processes x {sjob[2]} of the same units each, {wall:.2f} s"}
+                                           "sample": f"{cores} processes x {sjob[2]} units, {wall:.2f} s"}
     except Exception as exc:                                                     # a reported extra, never fatal
         result.setdefault("all_cores", {"error": repr(exc)})
     result["_side"] = side
@@ -243,8 +285,7 @@ def octave_legs(dev, world, rank, ch, bpo, log2n, tag, with_sequential):
     def record(name, bank, steps, mode, extra):
         dt, ev_ms = leg(lambda k: bank.energies(x, 1024, alphas, out=out), steps, dev, distributed, torch)
         legs[f"{tag}_{name}"] = {"value": units / dt, "unit": "octave-bands/s", "ms_per_step": dt * 1e3, "mode": mode,
-                                 "config": f"{ch} ch/GPU x 2^{log2n} samples @ 48 kHz, {9 * bpo} bands (bpo {bpo}), smoothed "
-                                           f"energies per 1024-sample block",
+                                 "config": f"{ch} ch x 2^{log2n}, {9 * bpo} bands, energies / 1024 samples",
                                  "roofline": dict({"algorithmic_bytes_per_step": alg_bytes,
                                                    "hbm_frac": alg_bytes / dt / 1e9 / HBM_PEAK_GBS,
                                                    "algorithmic_flops_per_step": survey_flops,
@@ -271,7 +312,7 @@ def octave_legs(dev, world, rank, ch, bpo, log2n, tag, with_sequential):
         dt, _ = leg(lambda k: seq.energies(xs, 1024, alphas, out=outs), 3, dev, distributed, torch)
         legs[f"{tag}_iir_sequential"] = {"value": world * ch * 64 * 9 * bpo / dt, "unit": "octave-bands/s", "ms_per_step": dt * 1e3,
                                          "mode": "exact IIR bank, sequential in time: bit-identical to the reference's recurrence",
-                                         "config": f"{ch} ch/GPU x 2^16 samples"}
+                                         "config": f"{ch} ch x 2^16"}
     fir = FirBank(bpo, ch, t)
     nfilt = bpo + 1
     tiles = sum(-(-(n >> j) // 3072) for j in range(9)) * ch
@@ -308,8 +349,7 @@ def stft16384_leg(dev, world, rank, consts):
             dt, ev_ms = leg(lambda k: eng.run(kind, xs[k % 3], outs[k % 3]), 30, dev, distributed, torch)
             legs[f"configs3_stft16384{tag}_{name}"] = {
                 "value": world * ch * F / dt, "unit": "spectra/s", "ms_per_step": dt * 1e3,
-                "config": f"{ch} ch/GPU x 2^20 samples, N = {n_fft}, hop {hop}, "
-                          f"{'dB + A-weighting + colour LUT -> u32 pixels' if kind == 3 else 'PSD'}, three batches rotated",
+                "config": f"{ch} ch x 2^20, N {n_fft}, hop {hop}, {'pixels' if kind == 3 else 'PSD'}",
                 "roofline": {"bound": "hbm", "kernel": "stft_pk16_kernel", "unit": "GB/s", "achieved": bytes_per_launch / (ev_ms * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "frac": bytes_per_launch / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": ev_ms}}
@@ -339,8 +379,7 @@ def stft1024_f64_leg(dev, world, rank, consts):
         dt, ev_ms = leg(lambda k: eng.run(kind, xs[k % 3], outs[k % 3]), 30, dev, distributed, torch)
         bytes_per_launch = F * (8 * hop + out_bytes * nb)
         rec = {"value": world * F / dt, "unit": "spectra/s", "ms_per_step": dt * 1e3, "dtype": "f64",
-               "config": f"1 ch/GPU x 2^25 samples, N = {n_fft}, hop {hop}, float64 in, "
-                         f"{'dB + A-weighting + colour LUT -> u32 pixels' if kind == 3 else 'float64 PSD out'}, three batches rotated",
+               "config": f"1 ch x 2^25, N {n_fft}, hop {hop}, f64 -> {'pixels' if kind == 3 else 'f64 PSD'}",
                "roofline": {"bound": "hbm", "kernel": "stft_kernel<double>", "unit": "GB/s", "achieved": bytes_per_launch / (ev_ms * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "frac": bytes_per_launch / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_spectrum": 8 * hop + out_bytes * nb,
@@ -387,8 +426,7 @@ def gcc_leg(dev, world, rank):
         # real transforms of 24000 samples as complex transforms of 12000: 3 per pair (two forward, one inverse), 5 n log2 n
         flops = pairs * 3 * 5.0 * 12000 * np.log2(12000.0)
         out[name] = {"value": world * pairs / dt, "unit": "windows/s", "ms_per_step": dt * 1e3,
-                     "config": f"{pairs} window pairs/GPU, L = {L}, float64, device resident; delay 37 samples found: "
-                               f"{bool(int(am[0]) == 37)}",
+                     "config": f"{pairs} pairs, L {L}, f64", "delay_37_found": bool(int(am[0]) == 37),
                      "roofline": {"bound": "hbm", "kernel": "gcc_fwd/cross/pack/inv kernels" if pairs <= 160 else "gcc_phat_kernel",
                                   "unit": "GB/s", "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBS, "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS,
                                   "algorithmic_bytes_per_step": nbytes, "algorithmic_flops_per_step": flops,
@@ -441,6 +479,7 @@ def main():
     ap.add_argument("--gather-slabs", action="store_true", help="all-gather every step's output slab over the job's process group, "
                     "asynchronously behind the step and overlapped with the next one (SURVEY.md §8e; optional: nobody needs "
                     "every channel's slab on every GPU by default)")
+    ap.add_argument("--full-json", default="", help="also write the uncompacted record (prose notes, full-precision floats) to this file")
     ap.add_argument("--stub-engine", action="store_true", help="tests only: CPU stand-in engine over gloo, see StubEngine")
     args = ap.parse_args()
 
@@ -630,8 +669,8 @@ def main():
             "config": {"workload": f"rolling spectrogram: {n_fft}-pt Hann STFT, hop {hop}, "
                                    f"{'dB + A-weighting + colour LUT -> u32 pixels' if kind == 3 else args.kind}, "
                                    f"{cpg} ch/GPU x 2^{args.log2_samples} samples @ 48 kHz "
-                                   f"(BASELINE configs[1]); output rows "
-                                   f"{'split: [F][N/2] on 64-byte boundaries + Nyquist plane [F] (frt_stft_run_split)' if split else 'packed [F][N/2+1] (frt_stft_run)'}",
+                                   f"(BASELINE configs[1]); rows "
+                                   f"{'split [F][N/2] (64-byte lines) + Nyquist plane [F]: frt_stft_run_split' if split else 'packed [F][N/2+1]: frt_stft_run'}",
                        "layout": "split" if split else "packed",
                        "channels": n_channels, "spectra_per_step": spectra_per_step, "batches_rotated": nbatch,
                        "parallelism": f"channel-sharded x{world}, no data-path collective"},
@@ -677,7 +716,12 @@ def main():
                     legs[leg_name]["cpu_baseline"] = side[side_name]
             if stub:
                 result["cpu_baseline_legs"] = side
-        print(json.dumps(result), flush=True)
+        if args.full_json:
+            Path(args.full_json).write_text(json.dumps(result, indent=1) + "\n")
+        line = json.dumps(compact_line(result), separators=(",", ":"))
+        if len(line) > LINE_BUDGET:
+            print(f"bench.py: the JSON line is {len(line)} characters (budget {LINE_BUDGET}): the driver's tail may cut it", file=sys.stderr)
+        print(line, flush=True)
         gates = [result.get("parity", {}).get("gate", {}).get("pass", True)]
         gates += [lg.get("parity", {}).get("gate", {}).get("pass", True) for lg in legs.values() if isinstance(lg, dict)]
         if slab_check is not None:

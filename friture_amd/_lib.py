@@ -37,6 +37,8 @@ SIGNATURES = {
     "frt_last_error": (c_char_p, []),
     "frt_version": (c_char_p, []),
     "frt_is_device_pointer": (c_int, [c_void_p]),
+    "frt_set_option": (c_int, [c_char_p, c_int]),
+    "frt_get_option": (c_int, [c_char_p, POINTER(c_int)]),
     "frt_stft_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int]),
     "frt_stft_destroy": (None, [c_void_p]),
     "frt_stft_set_stream": (c_int, [c_void_p, c_void_p]),
@@ -159,6 +161,18 @@ def init(device: int | None = None) -> ctypes.CDLL:
         check(lib.frt_init(device, None, None))
         _initialised = True
     return lib
+
+
+def set_option(name: str, value: int) -> None:
+    """frt_set_option: force one of two product code paths of an entry point (tests, A/B runs); value < 0 restores the
+    shape rule.  The library never reads the environment."""
+    check(load().frt_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = c_int(0)
+    check(load().frt_get_option(name.encode(), ctypes.byref(v)))
+    return v.value
 
 
 def device_info(device: int = 0) -> tuple[int, int]:

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -40,6 +41,26 @@ void set_last_error(const char* fmt, ...);
             return (code);                         \
         }                                          \
     } while (0)
+
+// ---- path selection ---------------------------------------------------------------------------------------------------
+// The library never reads the environment: no variable can change what a call computes.  Product code paths that are
+// normally chosen by the shape of a call can be forced through frt_set_option (include/friture_hip.h) — explicit, per
+// process, visible in the caller's code; tests use it to reach both sides of a shape rule on one input.
+enum Option {
+    kOptGccOneWorkgroup,      // GCC-PHAT: 1 = one workgroup per pair whatever the batch, 0 = a pair as launches of its phases
+    kOptGccAnyLength,         // GCC-PHAT: 1 = the chirp-z path even for lengths the mixed-radix plan serves (at frt_gcc_create)
+    kOptOlaChunkKernels,      // FFT overlap-add bank, one block of <= 1024 host samples: 0 = the per-stage transform launches
+    kOptPitchGridTwoPass,     // pitch tracker: 1 = the two-pass log-grid kernel on the widget's grid too
+    kOptCount
+};
+int option(Option o);         // -1 = not set: the shape rule decides
+// Experiment switches of tools/exp (A/B of kernel generations, ablations) exist only in -DFRT_EXPERIMENTS builds
+// (tools/exp/build_variant.sh); in the shipped library the switch and the code behind it fold away at compile time.
+#ifdef FRT_EXPERIMENTS
+inline const char* exp_env(const char* name) { return getenv(name); }
+#else
+constexpr const char* exp_env(const char*) { return nullptr; }
+#endif
 
 // true when `p` points to device (or managed) memory usable by kernels directly.
 bool is_device_pointer(const void* p);

@@ -1088,7 +1088,7 @@ extern "C" int frt_gcc_create(frt_gcc** out, int length, int n_pairs) {
     h->n_pairs = n_pairs;
     int R = 1;
     while (h->M / R > kGccMaxM2 && R < kGccMaxR && h->M % (2 * R) == 0) R *= 2;
-    if (const char* fr = getenv("FRT_GCC_FORCE_R")) {           // experiments: a deeper split than LDS requires
+    if (const char* fr = exp_env("FRT_GCC_FORCE_R")) {           // experiments: a deeper split than LDS requires
         const int want = atoi(fr);
         while (R < want && R < kGccMaxR && h->M % (2 * R) == 0) R *= 2;
     }
@@ -1099,7 +1099,7 @@ extern "C" int frt_gcc_create(frt_gcc** out, int length, int n_pairs) {
     const double pi = 3.14159265358979323846;
     for (int n = 0; n < length; ++n) win[n] = 0.5 - 0.5 * std::cos(2.0 * pi * n / (length - 1));
     int rc;
-    if (h->M2 > kGccMaxM2 || !make_mixed_plan(h->M2, &h->plan) || getenv("FRT_GCC_FORCE_ANY")) {
+    if (h->M2 > kGccMaxM2 || !make_mixed_plan(h->M2, &h->plan) || option(kOptGccAnyLength) > 0) {
         // any other length (numpy's rfft takes them all): chirp-z on a four-step power-of-two transform
         FRT_REQUIRE(length <= (1 << 25), "frt_gcc_create: length %d above 2^25 samples", length);
         h->any = true;
@@ -1160,7 +1160,7 @@ extern "C" int frt_gcc_create(frt_gcc** out, int length, int n_pairs) {
         return FRT_ERR_HIP;
     }
     h->lds_bytes = (size_t)h->M2 * 16 + 16 * sizeof(double) + 16 * sizeof(int);
-    h->static_plan = h->M2 == kGccStaticM2 && getenv("FRT_GCC_NO_STATIC_PLAN") == nullptr;
+    h->static_plan = h->M2 == kGccStaticM2 && exp_env("FRT_GCC_NO_STATIC_PLAN") == nullptr;
     if (h->static_plan && (rc = upload(h->tws, make_static_twiddles<double>({6, 10, 10, 10})))) {
         frt_gcc_destroy(h);
         return rc;
@@ -1252,15 +1252,15 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
     a.R = h->R;
     a.tws = h->tws.as<double>();
     a.dw = h->dw.as<double>();
-    static const bool profile = getenv("FRT_GCC_PROFILE") != nullptr;
+    static const bool profile = exp_env("FRT_GCC_PROFILE") != nullptr;
     if (profile) {
         if ((rc = h->prof.reserve(16 * sizeof(long long)))) return rc;
         a.prof = h->prof.as<long long>();
     }
     a.vec = ((uintptr_t)a.d0 % 16 == 0) && ((uintptr_t)a.d1 % 16 == 0) && ((uintptr_t)a.xcorr % 16 == 0);
     const bool st = h->static_plan;
-    const char* force = getenv("FRT_GCC_ONE_WORKGROUP");
-    const bool split = force ? force[0] == '0' : (long long)h->n_pairs * 8 <= 5ll * device_cu_count();
+    const int force = option(kOptGccOneWorkgroup);
+    const bool split = force >= 0 ? force == 0 : (long long)h->n_pairs * 8 <= 5ll * device_cu_count();
     if (split) {
         // up to 5/8 of a workgroup per CU (160 pairs on 256 CUs; measured crossover between 100 and 256): a pair as launches of its own phases
         if ((rc = h->gmax.reserve((size_t)h->n_pairs * 8))) return rc;

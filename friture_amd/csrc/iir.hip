@@ -584,7 +584,7 @@ static bool lane_kernel_serves(const IirStageArgs& a, const int* orders) {
     if (a.eblock && (a.eblock_len < 4 || a.chunk % a.eblock_len != 0)) return false;
     const bool vec_x = ((uintptr_t)a.x % 16 == 0) && (a.x_stride % (a.in_f32 ? 4 : 2) == 0);
     const bool vec_xn = !a.xnext || (((uintptr_t)a.xnext % 16 == 0) && (a.xnext_stride % 2 == 0));
-    static const bool off = getenv("FRT_IIR_NO_LANE_KERNEL") != nullptr;      // A/B runs
+    static const bool off = exp_env("FRT_IIR_NO_LANE_KERNEL") != nullptr;      // A/B runs
     return vec_x && vec_xn && !off;
 }
 
@@ -1275,7 +1275,7 @@ extern "C" int frt_octbank_create(frt_octbank** out, int bands_per_octave, int n
     h->mode = mode;
     h->nbands = kNOctave * bands_per_octave;
     h->nfilt = bands_per_octave + 1;
-    h->use_graph = getenv("FRT_NO_GRAPH") == nullptr;
+    h->use_graph = exp_env("FRT_NO_GRAPH") == nullptr;
     h->h_coef.assign((size_t)h->nfilt * kCoefStride, 0.0);
     h->h_order.assign(h->nfilt, 0);
     for (int i = 0; i < bands_per_octave; ++i) {       // 4th-order band-passes, 5 + 5 coefficients
@@ -1439,8 +1439,8 @@ static int ensure_powers(frt_octbank* h, int n) {
         const int g = scan_group_for(h, cj, nj);
         int rg = kScanRowMax;
         while ((2 * g + rg - 1) / rg > kScanRows / 2) rg *= 2;              // at most half of a workgroup's rows are halo
-        h->sgroup[j] = g <= rg || getenv("FRT_IIR_LONG_SCAN_ROWS") ? g : rg;
-        h->shalo[j] = g <= rg || getenv("FRT_IIR_LONG_SCAN_ROWS") ? 2 : (2 * g + rg - 1) / rg;
+        h->sgroup[j] = g <= rg || exp_env("FRT_IIR_LONG_SCAN_ROWS") ? g : rg;
+        h->shalo[j] = g <= rg || exp_env("FRT_IIR_LONG_SCAN_ROWS") ? 2 : (2 * g + rg - 1) / rg;
         for (int f = 0; f < h->nfilt; ++f) {
             const double* ac = &h->h_coef[(size_t)f * kCoefStride + kMaxOrder + 1];
             transition_power(ac, h->h_order[f], cj, &p[((size_t)j * h->nfilt + f) * kStates * kStates]);
@@ -1492,8 +1492,10 @@ static int ensure_powers(frt_octbank* h, int n) {
 
 // Runs the nine octave stages on device buffers.  d_x: stage-0 input; d_y (nullable): packed band
 // outputs; energies (nullable eblock): zero-state block energies for blocks of `eblock0` input samples.
+// `esub`: every esub-th entry of the block axis is one the caller reads (frt_octbank_energies: 1 unless the time-parallel chunk
+// is shorter than the caller's block).
 static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_stride, int n, double* d_y, int64_t y_cstride,
-                      double* d_eblock, int eblock0, int nblocks) {
+                      double* d_eblock, int eblock0, int nblocks, int esub = 1) {
     int len[kNOctave];
     stage_lengths(n, len);
     const bool parallel = h->chunk0 > 0 && n >= 2 * h->chunk0;
@@ -1549,14 +1551,22 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
         a.xnext = j + 1 < kNOctave ? h->xbuf[j + 1].as<double>() : nullptr;
         a.xnext_stride = j + 1 < kNOctave ? len[j + 1] : 0;
         a.eblock = d_eblock;
-        a.eblock_len = d_eblock ? (eblock0 >> j) : 1;
-        a.eblock_mul = 1;
-        while (d_eblock && a.eblock_len < 4) {                  // (only when the block axis is finer than 1024 samples: see frt_octbank_energies)
-            a.eblock_len <<= 1;
-            a.eblock_mul <<= 1;
-        }
-        a.eblock_shift = 0;
-        while ((1 << a.eblock_shift) < a.eblock_len) ++a.eblock_shift;
+        // An energy block of this stage is eblock0 / 2^j of its samples: 1 or 2 at the lowest rates when the block axis is finer
+        // than 1024 samples.  The lane kernel works in groups of 4 samples: it may take a block of 4 that spans `mul` entries of
+        // the block axis (zeros in the first mul - 1, the group's energy in the last — the smoothing recurrence then lands on
+        // the right value at every mul-th entry) ONLY when every entry the caller reads is such a last one, i.e. mul divides
+        // esub.  Everything else — the sequential mode, the slot kernel, a caller that reads every entry — keeps the true
+        // block length (the slot kernel's short-block loop serves 1 and 2).
+        auto set_eblock = [&](int len, int mul) {
+            a.eblock_len = len;
+            a.eblock_mul = mul;
+            a.eblock_shift = 0;
+            while ((1 << a.eblock_shift) < a.eblock_len) ++a.eblock_shift;
+        };
+        const int elen_true = d_eblock ? (eblock0 >> j) : 1;
+        FRT_REQUIRE(elen_true >= 1, "octave bank: energy block of %d samples is shorter than one sample of stage %d", eblock0, j);
+        set_eblock(elen_true, 1);
+        if (d_eblock && parallel && elen_true < 4 && esub % (4 / elen_true) == 0) set_eblock(4, 4 / elen_true);
         a.nblocks = nblocks;
         a.nbands = h->nbands;
         a.alpha = h->alpha.as<double>();
@@ -1573,15 +1583,15 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
                 if ((rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream))) return rc;
             } else {
                 // K-slices: enough wavefronts to fill the chip when the columns alone do not
-                static const bool use_vector_alu = getenv("FRT_ZS_VECTOR") != nullptr;      // A/B runs: the vector-ALU kernel
+                static const bool use_vector_alu = exp_env("FRT_ZS_VECTOR") != nullptr;      // A/B runs: the vector-ALU kernel
                 const int cols_per_wave = use_vector_alu ? 64 * kZsCols : 16;
                 const int slice_min = use_vector_alu ? 8 : 16;
                 const long long colwaves = ((long long)h->n_channels * a.nchunks + cols_per_wave - 1) / cols_per_wave;
-                static const int max_slices = getenv("FRT_ZS_MAX_SLICES") ? atoi(getenv("FRT_ZS_MAX_SLICES")) : kMaxSlices;      // A/B runs
+                static const int max_slices = exp_env("FRT_ZS_MAX_SLICES") ? atoi(exp_env("FRT_ZS_MAX_SLICES")) : kMaxSlices;      // A/B runs
                 // (round 4: one wavefront per CU is where splitting K stops paying — every doubling adds the partial sums'
                 // traffic and, from 2 slices on, a launch that sums them: 2048 -> 256 took configs[4]'s 216-band bank from
                 // 0.90 to 0.72 ms and configs[2]'s from 0.72 to 0.70, profiles/r04_zero_state_slices.txt)
-                static const int wave_goal = getenv("FRT_ZS_WAVE_GOAL") ? atoi(getenv("FRT_ZS_WAVE_GOAL")) : device_cu_count();
+                static const int wave_goal = exp_env("FRT_ZS_WAVE_GOAL") ? atoi(exp_env("FRT_ZS_WAVE_GOAL")) : device_cu_count();
                 // (a slice is at least 64 samples: below that the product is launch-bound whatever its grid, and the launch that
                 // sums the slices costs its ~5 us — the 64-sample chunks of the low-rate stages are not sliced: -1 % at 8 ch x 27 bands)
                 while (n_slices < max_slices && colwaves * n_slices < wave_goal && a.chunk % (2 * n_slices * slice_min) == 0 &&
@@ -1615,12 +1625,12 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
                                h->order.as<int>(), h->chunk_init.as<double>(), h->nfilt, a.nchunks,
                                a.scan_group, a.scan_rows, nseg, halo);
             a.pass = 2;
-            static const bool exact_ops = getenv("FRT_IIR_EXACT_OPS") != nullptr;      // A/B runs
+            static const bool exact_ops = exp_env("FRT_IIR_EXACT_OPS") != nullptr;      // A/B runs
             a.fused = (d_y == nullptr && d_eblock != nullptr && !exact_ops) ? 1 : 0;
             a.n_channels = h->n_channels;
             if (lane_kernel_serves(a, h->h_order.data())) rc = launch_iir_lane(a, h->n_channels, h->stream);
             else {
-                FRT_REQUIRE(a.eblock_mul == 1, "octave bank: a chunk shorter than the energy block needs 16-byte aligned device input in whole chunks");
+                set_eblock(elen_true, 1);            // the slot kernel writes every entry of the block axis itself
                 rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream);
             }
             if (rc) return rc;
@@ -1673,7 +1683,7 @@ static int filter_host(frt_octbank* h, const double* x, int n, double* y_packed,
     if (!h->gstream) FRT_HIP_CHECK(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
     FRT_HIP_CHECK(hipStreamSynchronize(h->stream));        // order after earlier work on the caller's stream
     memcpy(h->pin_in, x, in_bytes);
-    const bool no_chunk = getenv("FRT_OLA_NO_CHUNK_KERNELS") != nullptr;       // A/B and tests: the transform path
+    const bool no_chunk = option(kOptOlaChunkKernels) == 0;       // tests: the transform path on a call the chunk kernels would serve
     if (h->mode == 1 && n <= 1024 && in_bytes <= kZeroCopyMax && out_bytes <= kZeroCopyMax && !no_chunk) {
         // the production bank's block (Octave_Filters.filter): running convolutions, two launches, samples read and band
         // signals written in place in the page-locked blocks (ola.hip, chunk path) instead of nine transform launches
@@ -1766,7 +1776,7 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
     FRT_REQUIRE(h && h->bpo >= 1, "frt_octbank_energies: needs a handle with bands");
     // mode 1, ONE block of any length up to 1024 = the octave-spectrum widget's chunk handler (octavespectrum.py:91-122)
     const bool chunk_call = h->mode == 1 && n == block && block >= 1 && block <= 1024;
-    const bool chunk_kernels = chunk_call && getenv("FRT_OLA_NO_CHUNK_KERNELS") == nullptr;      // A/B and tests: the transform path
+    const bool chunk_kernels = chunk_call;
     FRT_REQUIRE(chunk_call || (block >= 256 && (block & (block - 1)) == 0), "frt_octbank_energies: block %d must be a power of two >= 256", block);
     FRT_REQUIRE(h->mode == 0 || block <= 1024, "frt_octbank_energies: the FFT bank's cadence is blocks of at most 1024 samples");
     FRT_REQUIRE(n > 0 && n % block == 0 && n < (1ll << 31), "frt_octbank_energies: n must be a positive multiple of block");
@@ -1863,7 +1873,7 @@ extern "C" int frt_octbank_energies(frt_octbank* h, const float* x, int64_t n, i
         return FRT_OK;
     }
     if (h->mode == 1) rc = frt_ola_filter_batch(h, d_x, 1, n, nullptr, 0, h->eblock.as<double>(), block, nblocks, alphas);
-    else rc = run_stages(h, d_x, 1, n, (int)n, nullptr, 0, h->eblock.as<double>(), eb, nblocks);
+    else rc = run_stages(h, d_x, 1, n, (int)n, nullptr, 0, h->eblock.as<double>(), eb, nblocks, sub);
     if (rc) return rc;
     if (nblocks >= 4 * kEnergySplit) {
         const int nsplit = (nblocks + kEnergySplit - 1) / kEnergySplit, threads = (h->nbands + 63) / 64 * 64;

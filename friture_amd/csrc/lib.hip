@@ -1,4 +1,5 @@
 // lib.hip — library-level entry points of libfriture_hip.so (init, errors, pointer queries).
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -17,11 +18,15 @@ void set_last_error(const char* fmt, ...) {
 }
 
 namespace {
+std::atomic<int> g_options[kOptCount] = {{-1}, {-1}, {-1}, {-1}};
+const char* const kOptionNames[kOptCount] = {"gcc_one_workgroup", "gcc_any_length", "ola_chunk_kernels", "pitch_grid_two_pass"};
 std::mutex g_retired_mutex;
 std::vector<void*> g_retired;
 size_t g_retired_bytes = 0;
 thread_local int g_capture_depth = 0;
 }  // namespace
+
+int option(Option o) { return g_options[o].load(std::memory_order_relaxed); }
 
 void retire_allocation(void* p, size_t bytes) {
     std::lock_guard<std::mutex> lock(g_retired_mutex);
@@ -172,6 +177,28 @@ extern "C" const char* frt_last_error(void) { return g_last_error; }
 extern "C" const char* frt_version(void) { return "friture_hip 0.1 (gfx950)"; }
 
 extern "C" int frt_is_device_pointer(const void* p) { return is_device_pointer(p) ? 1 : 0; }
+
+extern "C" int frt_set_option(const char* name, int value) {
+    FRT_REQUIRE(name, "frt_set_option: null name");
+    for (int o = 0; o < kOptCount; ++o)
+        if (!strcmp(name, kOptionNames[o])) {
+            g_options[o].store(value < 0 ? -1 : value, std::memory_order_relaxed);
+            return FRT_OK;
+        }
+    set_last_error("frt_set_option: unknown option '%s'", name);
+    return FRT_ERR_INVALID;
+}
+
+extern "C" int frt_get_option(const char* name, int* value_out) {
+    FRT_REQUIRE(name && value_out, "frt_get_option: null argument");
+    for (int o = 0; o < kOptCount; ++o)
+        if (!strcmp(name, kOptionNames[o])) {
+            *value_out = option((Option)o);
+            return FRT_OK;
+        }
+    set_last_error("frt_get_option: unknown option '%s'", name);
+    return FRT_ERR_INVALID;
+}
 
 extern "C" int frt_device_properties(int device, int* n_cus_out, int64_t* hbm_bytes_out) {
     int n = 0;

@@ -336,6 +336,8 @@ __device__ __forceinline__ double group_sum(double acc, int w) {
     if (w >= 64) acc += __shfl_xor(acc, 32, 64);
     return acc;
 }
+#ifdef FRT_EXPERIMENTS          // round 2's kernel (one real 4096-point transform per workgroup): superseded by ola_pair_kernel
+                                // (ola_wave.h), kept for the A/B builds of tools/exp (FRT_OLA_NO_WAVE)
 // The 2048-point forward transform of fft_core.h (radix 8, 8, 8, 4; v[j] = z[i + 256 j] in, Z[i + 256 j] out) with its three
 // exchanges alternating between two LDS buffers, first -> second -> first: the barrier that would keep a pass's scatter from
 // overtaking the previous pass's gathers is not needed when the scatter goes to the other buffer (whose last readers all
@@ -580,6 +582,8 @@ __global__ void __launch_bounds__(kObThreads, FRT_OB_MIN_WAVES) ola_batch_kernel
     }
 }
 
+#endif  // FRT_EXPERIMENTS
+
 #include "ola_wave.h"
 #if FRT_OW_TIMING
 extern "C" int frt_ow_timing_read(unsigned long long* out) {
@@ -589,9 +593,8 @@ extern "C" int frt_ow_timing_read(unsigned long long* out) {
 
 static int ola_batch_tables(frt_octbank* h) {
     frt_ola_state* o = h->ola;
-    if (o->bH.ptr) return FRT_OK;
+    if (o->bHw.ptr) return FRT_OK;
     int rc;
-    if ((rc = upload(o->btw, make_twiddles<double>(kObM))) || (rc = upload(o->btwl, make_twiddles<double>(kObF, kObM + 1)))) return rc;
     // H_f[k] = sum_t h_f[t] exp(-2 pi i k t / F): the rfft of the zero-padded taps (filter_design.py computes the same
     // with numpy at the reference's own sizes)
     const int nfilt = h->nfilt;
@@ -601,6 +604,9 @@ static int ola_batch_tables(frt_octbank* h) {
         ct[t] = cosl(pi2 * t / kObF);
         st[t] = sinl(pi2 * t / kObF);
     }
+    if ((rc = upload(o->btw, make_twiddles<double>(kObM)))) return rc;          // exp(-2 pi i t / 2048): both kernels' transforms
+#ifdef FRT_EXPERIMENTS
+    if ((rc = upload(o->btwl, make_twiddles<double>(kObF, kObM + 1)))) return rc;
     std::vector<double> Hh((size_t)nfilt * (kObM + 1) * 2);
     for (int f = 0; f < nfilt; ++f) {
         const double* taps = &o->h_taps[(size_t)f * kFirLength];
@@ -616,6 +622,7 @@ static int ola_batch_tables(frt_octbank* h) {
         }
     }
     if ((rc = upload(o->bH, Hh))) return rc;
+#endif
     // ola_pair_kernel: every bin of the 2048-point transform (H[k] = H4096[2 k]), conjugated and scaled for the inverse
     std::vector<double> Hw((size_t)nfilt * kOwN * 2);
     for (int f = 0; f < nfilt; ++f) {
@@ -667,8 +674,13 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
     frt_ola_state* o = h->ola;
     // one energy block = the whole call (the widget's chunk, any length): a band's block is its stage's whole output
     const bool whole = d_eblock && nblocks == 1 && eblock0 == n;
-    // ola_pair_kernel (ola_wave.h) for everything but that A/B path; FRT_OLA_NO_WAVE: the round-2 kernel
-    const bool use_wave = !whole && getenv("FRT_OLA_NO_WAVE") == nullptr;
+    // (served by the chunk kernels below; -DFRT_EXPERIMENTS builds keep round 2's kernel for it and for FRT_OLA_NO_WAVE)
+#ifdef FRT_EXPERIMENTS
+    const bool use_wave = !whole && exp_env("FRT_OLA_NO_WAVE") == nullptr;
+#else
+    FRT_REQUIRE(!whole, "frt_ola_filter_batch: a call of one block belongs to the chunk kernels (frt_ola_chunk_energies)");
+    constexpr bool use_wave = true;
+#endif
     int rc;
     if ((rc = ola_batch_tables(h))) return rc;
     long long len[kNOctave];
@@ -734,6 +746,7 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
             FRT_HIP_CHECK(hipGetLastError());
             continue;
         }
+#ifdef FRT_EXPERIMENTS
         const long long nblk = (len[j] + kObL - 1) / kObL;
         // filter groups: every workgroup repeats the forward transform of its window, so as few groups as still fill the chip
         int groups = 1;
@@ -742,6 +755,7 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
         groups = (h->nfilt + a.gsize - 1) / a.gsize;
         hipLaunchKernelGGL(ola_batch_kernel, dim3((unsigned)nblk, groups, h->n_channels), dim3(kObThreads), 0, h->stream, a);
         FRT_HIP_CHECK(hipGetLastError());
+#endif
     }
     std::swap(o->pending.ptr, o->pending_next.ptr);             // equal sizes; the streaming path and the graphs follow `pending`
     return FRT_OK;

@@ -589,7 +589,7 @@ extern "C" int frt_pitch_track(frt_pitch* h, const double* x, int64_t T, int64_t
         const unsigned groups = (unsigned)((total + kFramesPerGroup - 1) / kFramesPerGroup);
         const unsigned blocks = (unsigned)((total + kFramesPerBlock - 1) / kFramesPerBlock);
         // the strength kernel reads whole 8-frame groups: have the grid kernel fill every group a block touches
-        if (h->Lp == 1024 && !getenv("FRT_PITCH_GRID_2PASS"))
+        if (h->Lp == 1024 && option(kOptPitchGridTwoPass) <= 0)
             hipLaunchKernelGGL(pitch_loggrid_reg_kernel<32>, dim3(blocks * (kFramesPerBlock / kFramesPerGroup)), dim3(256), 0, h->stream, a);
         else
             hipLaunchKernelGGL(pitch_loggrid_kernel, dim3(blocks * (kFramesPerBlock / kFramesPerGroup)), dim3(256), 0, h->stream, a);

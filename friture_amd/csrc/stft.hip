@@ -20,7 +20,7 @@
 #include "stft_wave.h"
 
 #include "stft_big.h"
-#include "stft_pk.h"
+#include "stft_pk.h"          // packed-arithmetic helpers; round 3's N = 16384 instance itself only in -DFRT_EXPERIMENTS builds
 #include "stft_pk16.h"
 #include "stft_pk16h.h"
 #include "stft_pk16q.h"
@@ -28,6 +28,7 @@
 
 namespace frt {
 
+#ifdef FRT_EXPERIMENTS
 // N = 16384, hop N/2 or N/4, rows on 16-byte boundaries: the packed-arithmetic instance (stft_pk.h)
 template <int HS>
 static int launch_pk(const StftArgs& a, hipStream_t stream) {
@@ -43,6 +44,7 @@ static int launch_pk(const StftArgs& a, hipStream_t stream) {
     FRT_HIP_CHECK(hipGetLastError());
     return FRT_OK;
 }
+#endif
 
 // the same with the sub-transforms factored 16 x 16 x 2 (stft_pk16.h)
 template <int HS>
@@ -114,46 +116,47 @@ template <typename T, int LOG2M>
 static int launch_big_one(const StftArgs& a, hipStream_t stream) {
     using B = BigPlan<LOG2M>;
     const int blocks = (a.n_groups + B::GPB - 1) / B::GPB;
-    if constexpr (sizeof(T) == 4 && LOG2M == Pk16wPlan::LOG2M) {
-        static const bool pk16w = getenv("FRT_STFT_NO_PK16W") == nullptr;        // A/B runs: stft_big_kernel
-        if (pk16w && ((uintptr_t)a.x % 16 == 0) && (a.x_stride % 4 == 0) && (a.hop % 4 == 0)) {
-            if (a.hop == B::M) return launch_pk16w<8>(a, stream);
-            if (a.hop == B::M / 2) return launch_pk16w<4>(a, stream);
-        }
-    }
-    if constexpr (sizeof(T) == 4 && LOG2M >= FRT_BIG_DMA_MIN_LOG2M) {
-        // rows on 16-byte boundaries (the library's own staging buffers and torch tensors are): the LDS-DMA variant
-        const bool aligned16 = ((uintptr_t)a.x % 16 == 0) && (a.x_stride % 4 == 0) && (a.hop % 4 == 0);
-        if constexpr (LOG2M == PkPlan::LOG2M) {
-            static const bool no_pk = getenv("FRT_STFT_NO_PK") != nullptr;       // A/B runs: round 3's instance
-            static const bool pk16 = getenv("FRT_STFT_NO_PK16") == nullptr;      // A/B runs: stft_pk_kernel (8 x 8 x 8 sub-transforms)
-            if (aligned16 && !no_pk && !getenv("FRT_STFT_NO_DMA")) {
-                if (pk16) {
-                    if (a.hop == B::M) return launch_pk16<8>(a, stream);
-                    if (a.hop == B::M / 2) return launch_pk16<4>(a, stream);
+    // rows on 16-byte boundaries (the library's own staging buffers and torch tensors are): the instances that take their
+    // samples by LDS-DMA.  (-DFRT_EXPERIMENTS builds can step back a kernel generation per size: tools/exp A/B runs.)
+    const bool aligned16 = ((uintptr_t)a.x % 16 == 0) && (a.x_stride % 4 == 0) && (a.hop % 4 == 0);
+    if constexpr (sizeof(T) == 4) {
+        if (aligned16 && !exp_env("FRT_STFT_NO_DMA")) {
+            const bool half = a.hop == B::M, quarter = a.hop == B::M / 2;        // hop N/2, N/4
+            if constexpr (LOG2M == Pk16wPlan::LOG2M) {
+                if (!exp_env("FRT_STFT_NO_PK16W")) {
+                    if (half) return launch_pk16w<8>(a, stream);
+                    if (quarter) return launch_pk16w<4>(a, stream);
                 }
-                if (a.hop == B::M) return launch_pk<8>(a, stream);
-                if (a.hop == B::M / 2) return launch_pk<4>(a, stream);
             }
-        }
-        if constexpr (LOG2M == Pk16qPlan::LOG2M) {
-            static const bool pk16q = getenv("FRT_STFT_NO_PK16Q") == nullptr;    // A/B runs: stft_big_kernel
-            if (aligned16 && pk16q && !getenv("FRT_STFT_NO_DMA")) {
-                if (a.hop == B::M) return launch_pk16q<8>(a, stream);
-                if (a.hop == B::M / 2) return launch_pk16q<4>(a, stream);
+            if constexpr (LOG2M == Pk16qPlan::LOG2M) {
+                if (!exp_env("FRT_STFT_NO_PK16Q")) {
+                    if (half) return launch_pk16q<8>(a, stream);
+                    if (quarter) return launch_pk16q<4>(a, stream);
+                }
             }
-        }
-        if constexpr (LOG2M == Pk16hPlan::LOG2M) {
-            static const bool pk16h = getenv("FRT_STFT_NO_PK16H") == nullptr;    // A/B runs: stft_big_kernel
-            if (aligned16 && pk16h && !getenv("FRT_STFT_NO_DMA")) {
-                if (a.hop == B::M) return launch_pk16h<8>(a, stream);
-                if (a.hop == B::M / 2) return launch_pk16h<4>(a, stream);
+            if constexpr (LOG2M == Pk16hPlan::LOG2M) {
+                if (!exp_env("FRT_STFT_NO_PK16H")) {
+                    if (half) return launch_pk16h<8>(a, stream);
+                    if (quarter) return launch_pk16h<4>(a, stream);
+                }
             }
-        }
-        if (aligned16 && !getenv("FRT_STFT_NO_DMA")) {
-            hipLaunchKernelGGL((stft_big_kernel<T, LOG2M, true>), dim3(blocks), dim3(B::BLOCK), 0, stream, a);
-            FRT_HIP_CHECK(hipGetLastError());
-            return FRT_OK;
+            if constexpr (LOG2M == Pk16Plan::LOG2M) {
+                if (!exp_env("FRT_STFT_NO_PK16") && !exp_env("FRT_STFT_NO_PK")) {
+                    if (half) return launch_pk16<8>(a, stream);
+                    if (quarter) return launch_pk16<4>(a, stream);
+                }
+#ifdef FRT_EXPERIMENTS
+                if (!exp_env("FRT_STFT_NO_PK")) {                 // round 3's instance (8 x 8 x 8 sub-transforms)
+                    if (half) return launch_pk<8>(a, stream);
+                    if (quarter) return launch_pk<4>(a, stream);
+                }
+#endif
+            }
+            if constexpr (LOG2M >= FRT_BIG_DMA_MIN_LOG2M) {
+                hipLaunchKernelGGL((stft_big_kernel<T, LOG2M, true>), dim3(blocks), dim3(B::BLOCK), 0, stream, a);
+                FRT_HIP_CHECK(hipGetLastError());
+                return FRT_OK;
+            }
         }
     }
     hipLaunchKernelGGL((stft_big_kernel<T, LOG2M, false>), dim3(blocks), dim3(B::BLOCK), 0, stream, a);
@@ -444,7 +447,9 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     a.bin_pow = h->bin_pow.as<double>();
     a.edge2 = h->edge2;
     a.image_thr = h->image_thr;
-    if (const char* e = getenv("FRT_EDGE_SCALE")) a.edge2 *= (float)atof(e);      // experiments only (tools/exp)
+#ifdef FRT_EXPERIMENTS
+    if (const char* e = exp_env("FRT_EDGE_SCALE")) a.edge2 *= (float)atof(e);      // tools/exp: how wide must the float64 zone be?
+#endif
     a.rising = h->spec_max > h->spec_min;
     a.eps_free = h->eps_free;
 #ifdef FRT_ABLATE
@@ -458,10 +463,10 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
         if (s == 2 || s == 4) shift = s;
     }
     // N = 1024, hop 512, rows on 16-byte boundaries: the ring instance (samples through a per-wavefront LDS ring filled by LDS-DMA)
-    static const bool no_ring = getenv("FRT_STFT_NO_RING") != nullptr;       // A/B runs: the register-window instance
+    static const bool no_ring = exp_env("FRT_STFT_NO_RING") != nullptr;       // A/B runs: the register-window instance
     // (PSD / dB kinds: +4 % over the register window, 60-61 % of HBM peak; the colour kind, whose epilogue adds its own LDS
     // gathers, measures equal or 0.5 % behind and keeps the register window unless FRT_STFT_RING_IMAGE is set)
-    static const bool ring_image = getenv("FRT_STFT_RING_IMAGE") != nullptr;
+    static const bool ring_image = exp_env("FRT_STFT_RING_IMAGE") != nullptr;
     if (shift == 4 && h->log2m == 9 && h->precision == 32 && ((uintptr_t)d_x % 16 == 0) && (x_stride % 4 == 0) && !no_ring &&
         (kind != FRT_STFT_IMAGE || ring_image))
         shift = -1;

@@ -226,6 +226,7 @@ typedef __attribute__((address_space(3))) pk2 lds_pk2;
 __device__ __forceinline__ pk2 lds_rd(uint32_t addr) { return *(const volatile lds_pk2*)addr; }
 __device__ __forceinline__ void lds_wr(uint32_t addr, pk2 v) { *(volatile lds_pk2*)addr = v; }
 
+#ifdef FRT_EXPERIMENTS   // round 3's kernel: superseded by stft_pk16_kernel (stft_pk16.h), kept for A/B builds of tools/exp
 // slot of element e inside a 512-element region
 __device__ __forceinline__ int pk_sigma(int e) { return e ^ ((e >> 4) & 7) ^ (((e >> 6) & 1) << 3); }
 
@@ -653,4 +654,5 @@ __global__ void __launch_bounds__(PkPlan::BLOCK, 2) stft_pk_kernel(const StftArg
 #undef PK_STEP
 }
 
+#endif  // FRT_EXPERIMENTS
 }  // namespace frt

@@ -184,8 +184,13 @@ stft_kernel(const StftArgs a) {
     __shared__ uint32_t lut_lds[256];                // colour words: gathered per bin, keep them on-chip
     constexpr int NH = FRT_RING_HALVES;
     __shared__ __attribute__((aligned(16))) C ring_lds[RING ? GPB * NH * (M / 2) : 1];      // per lane group: NH half-frames of M/2 complex
-    constexpr bool WLDS = RING && FRT_RING_WEIGHTS_IN_LDS;                       // dB / colour-index offsets read from LDS per frame
+#ifndef FRT_WAVE_TABLES_IN_LDS        // experiment: one-wavefront float32 frames read their per-bin weights AND unpack twiddles from LDS
+#define FRT_WAVE_TABLES_IN_LDS 0      // (17 registers fewer: four waves per SIMD without spills?)
+#endif
+    constexpr bool TLDS = FRT_WAVE_TABLES_IN_LDS && TPF == 64 && sizeof(T) == 4;
+    constexpr bool WLDS = (RING && FRT_RING_WEIGHTS_IN_LDS) || TLDS;             // dB / colour-index offsets read from LDS per frame
     __shared__ T wgt_lds[WLDS ? M + 1 : 1];                                      // instead of nine registers held for the run
+    __shared__ C twn_lds[TLDS ? M / 2 : 1];                                      // unpack twiddles of bins 0..M/2-1
 
     const int tid = threadIdx.x;
     // a lane group that is a whole wavefront: its index — and with it channel, run, frame range, row and sample bases — is
@@ -212,6 +217,11 @@ stft_kernel(const StftArgs a) {
     if constexpr (WLDS) {
         const T* wsrc = (const T*)(a.kind == FRT_STFT_IMAGE ? a.wimage : a.weight);
         for (int t = threadIdx.x; t <= M; t += BLOCK) wgt_lds[t] = wsrc ? wsrc[t] : (T)0;
+        __syncthreads();
+    }
+
+    if constexpr (TLDS) {
+        for (int t = threadIdx.x; t < M / 2; t += BLOCK) twn_lds[t] = ((const C*)a.twn)[t];
         __syncthreads();
     }
 
@@ -244,7 +254,7 @@ stft_kernel(const StftArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                 // bins i + j TPF and M - i - j TPF (see the unpack)
-            twu[j] = twn[i + j * TPF];
+            if constexpr (!TLDS) twu[j] = twn[i + j * TPF];
             if constexpr (!WLDS) {
                 wdb[j] = wgt ? wgt[i + j * TPF] : (T)0;
                 wdb[4 + j] = wgt ? wgt[M - i - j * TPF] : (T)0;
@@ -347,14 +357,23 @@ stft_kernel(const StftArgs a) {
         // RING: the copy this frame's second half arrives by was issued a frame ago, in front of that frame's nine row
         // stores — the only younger vector-memory operations (the counter retires in order): at most nine outstanding
         // means the copy has landed.  (The first frame's two copies are drained before the loop.)
+        // (split rows: EIGHT stores per frame — bin M/2 rides in lane 0's last descending store and the Nyquist bin waits in a
+        // register for the end of the run; tests/test_ring_waitcnt.py counts both instances' stores in the generated code)
         if constexpr (RING) {
+            static_assert(!SPLIT || NYQ_REG, "the ring instance counts its row stores");
             if constexpr (NH == 2) {
-                __builtin_amdgcn_s_waitcnt(0x0F79);          // vmcnt(9), other counters untouched
+                if constexpr (SPLIT) __builtin_amdgcn_s_waitcnt(0x0F78);     // vmcnt(8), other counters untouched
+                else __builtin_amdgcn_s_waitcnt(0x0F79);                     // vmcnt(9)
             } else {
                 // three halves: the copy was issued two frames ago; younger are two frames' stores and, if the previous
                 // frame issued one, its copy (2 instructions)
-                if (g + 1 < nfr) __builtin_amdgcn_s_waitcnt(0x4F74);      // vmcnt(20)
-                else __builtin_amdgcn_s_waitcnt(0x4F72);                  // vmcnt(18)
+                if constexpr (SPLIT) {
+                    if (g + 1 < nfr) __builtin_amdgcn_s_waitcnt(0x4F72);      // vmcnt(18)
+                    else __builtin_amdgcn_s_waitcnt(0x4F70);                  // vmcnt(16)
+                } else {
+                    if (g + 1 < nfr) __builtin_amdgcn_s_waitcnt(0x4F74);      // vmcnt(20)
+                    else __builtin_amdgcn_s_waitcnt(0x4F72);                  // vmcnt(18)
+                }
             }
         }
 
@@ -454,7 +473,8 @@ stft_kernel(const StftArgs a) {
             C S = A + B, D = A - B;
             C tu;
             if constexpr (HOIST) {
-                tu = twu[j];
+                if constexpr (TLDS) tu = twn_lds[i + j * TPF];
+                else tu = twu[j];
             } else {
                 tu = twn[i + j * TPF + zero];
             }
@@ -500,6 +520,7 @@ stft_kernel(const StftArgs a) {
                     // 64-value block ABOVE — it stores the value it holds for that block's lowest bin instead (slot j + 1, or
                     // the self-paired bin M/2 for j = 3), so that every store covers [M - (j + 1) TPF, M - j TPF) exactly
                     const int ihi = i == 0 ? TPF : i;
+                    typedef std::remove_cv_t<std::remove_pointer_t<decltype(vals)>> V;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         stream_store(r + klo + j * TPF, vals[j]);
@@ -512,7 +533,6 @@ stft_kernel(const StftArgs a) {
                         nyq_lo = lane_insert(nyq_lo, value_bits_lo(vals[4]), g & 63, i);
                         if constexpr (sizeof(*vals) == 8) nyq_hi = lane_insert(nyq_hi, value_bits_hi(vals[4]), g & 63, i);
                     } else if (i == 0) {
-                        typedef std::remove_cv_t<std::remove_pointer_t<decltype(vals)>> V;
                         stream_store((V*)a.out_nyq + chan * a.n_frames + (f0 + g), vals[4]);
                     }
                 }

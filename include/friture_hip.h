@@ -45,6 +45,18 @@ const char* frt_last_error(void);
 const char* frt_version(void);
 /* 1 if `p` is device memory, 0 if host memory. */
 int frt_is_device_pointer(const void* p);
+/* Path selection for tests and A/B runs.  The library never reads the environment; where one entry point has two product
+ * code paths chosen by the shape of the call, this forces one of them for the whole process (value < 0: back to the shape
+ * rule).  Both paths of every option compute the same reference function and are held to the same parity bar:
+ *   "gcc_one_workgroup"    frt_gcc_phat: 1 = one workgroup per window pair whatever the batch size, 0 = a pair as launches
+ *                          of its phases (default: by batch size)
+ *   "gcc_any_length"       frt_gcc_create: 1 = the chirp-z transform also for lengths the mixed-radix plan serves
+ *   "ola_chunk_kernels"    frt_octbank_filter (mode 1, one block of <= 1024 host samples): 0 = per-stage transform launches
+ *                          instead of the two running-convolution launches
+ *   "pitch_grid_two_pass"  frt_pitch_track: 1 = the two-pass log-grid kernel also on the widget's 1023-point grid
+ * Unknown names: FRT_ERR_INVALID. */
+int frt_set_option(const char* name, int value);
+int frt_get_option(const char* name, int* value_out);
 
 /* ---- K1: STFT -> power spectrum ( -> dB / normalised / colour pixels) -------------------------
  * Replaces audioproc.analyzelive + norm_square (friture/audioproc.py:42-50) looped by the STFT

@@ -30,6 +30,21 @@ def hip():
     return _lib.init()
 
 
+@pytest.fixture
+def option():
+    """frt_set_option for the duration of a test (the library never reads the environment): option(name, value) forces one of
+    two product code paths of an entry point; every option is back on its shape rule when the test ends."""
+    from friture_amd import _lib
+    touched = []
+
+    def set_option(name, value):
+        touched.append(name)
+        _lib.set_option(name, value)
+    yield set_option
+    for name in touched:
+        _lib.set_option(name, -1)
+
+
 def rel_max(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))

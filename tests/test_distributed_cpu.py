@@ -123,7 +123,7 @@ def test_bench_two_ranks_gloo_with_slab_gather():
     assert sg["enabled"] and sg["slabs_verified"] is True and sg["bytes_per_step_per_rank"] == 2 * F * 513 * 4
     pr = rec["per_rank"]
     assert len(pr["ms_per_step"]) == 2 and pr["ms_per_step_min"] <= pr["ms_per_step_max"]
-    assert abs(pr["ms_per_step_max"] - rec["ms_per_step"]) <= 1e-9 * rec["ms_per_step"]
+    assert abs(pr["ms_per_step_max"] - rec["ms_per_step"]) <= 1e-4 * rec["ms_per_step"]      # (per-rank figures are printed at 5 digits)
 
 
 def _slab_worker(rank, world, port, q):

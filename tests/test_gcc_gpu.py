@@ -55,13 +55,13 @@ def test_gcc_lengths_against_oracle(hip, L):
 
 @pytest.mark.parametrize("L", [540, 24000, 49152])
 @pytest.mark.parametrize("one_workgroup", ["0", "1"])
-def test_gcc_signals_with_a_large_mean(hip, L, one_workgroup, monkeypatch):
+def test_gcc_signals_with_a_large_mean(hip, L, one_workgroup, option):
     """The one-workgroup kernel takes the means while the samples pass into the sub-transforms and removes them in the spectrum
     (mean x rfft(window), csrc/gcc.hip); the launch shape with sub-transforms as workgroups of their own subtracts them in time.
     Signals whose mean is 10-20 times their deviation (the leakage of the mean's window spectrum reaches every bin), both shapes,
     R = 1 / 2 / 4: same tolerance, same means as numpy."""
     from friture_amd.signal.correlation import GccPhat
-    monkeypatch.setenv("FRT_GCC_ONE_WORKGROUP", one_workgroup)
+    option("gcc_one_workgroup", int(one_workgroup))
     rng = np.random.default_rng(7 * L)
     d0 = 0.25 * rng.standard_normal((2, L)) + 2.5
     d1 = np.roll(d0, 9, axis=1) - 2.5 - 4.0 + 0.02 * rng.standard_normal((2, L))
@@ -91,14 +91,14 @@ def test_gcc_any_window_length(hip, L):
         assert am[p] == int(np.argmax(np.abs(ref))) == 41
 
 
-def test_gcc_chirp_path_equals_one_workgroup_path(hip, monkeypatch):
+def test_gcc_chirp_path_equals_one_workgroup_path(hip, option):
     """L = 24000 (the widget's default window) through both implementations."""
     from friture_amd.signal.correlation import GccPhat
     rng = np.random.default_rng(5)
     d0 = 0.25 * rng.standard_normal((2, 24000))
     d1 = np.roll(d0, 37, axis=1) + 0.05 * rng.standard_normal((2, 24000))
     x_fast, am_fast = GccPhat(24000, 2).correlate(d0, d1)
-    monkeypatch.setenv("FRT_GCC_FORCE_ANY", "1")
+    option("gcc_any_length", 1)
     x_any, am_any = GccPhat(24000, 2).correlate(d0, d1)
     assert list(am_fast) == list(am_any) == [37, 37]
     assert rel_max(x_any, x_fast) <= 1e-10
@@ -345,7 +345,7 @@ def test_delay_object_argument_checks(hip):
     assert b.offset == 128
 
 
-def test_gcc_small_batch_path_equals_one_workgroup_path(hip, monkeypatch):
+def test_gcc_small_batch_path_equals_one_workgroup_path(hip, option):
     """Batches that would leave most CUs idle run a pair's phases as launches of their own (forward per signal, cross
     spectrum, packing, inverse per sub-transform); the one-workgroup kernel keeps the cross spectrum in registers and the
     last sub-spectrum / the packed inverse input in LDS.  Same arithmetic up to the order of the means' block sums and the
@@ -355,11 +355,11 @@ def test_gcc_small_batch_path_equals_one_workgroup_path(hip, monkeypatch):
         rng = np.random.default_rng(L)
         d0 = 0.25 * rng.standard_normal((3, L))
         d1 = np.roll(d0, 17, axis=1) + 0.05 * rng.standard_normal((3, L))
-        monkeypatch.setenv("FRT_GCC_ONE_WORKGROUP", "0")
+        option("gcc_one_workgroup", 0)
         x_multi, am_multi = GccPhat(L, 3).correlate(d0, d1)
-        monkeypatch.setenv("FRT_GCC_ONE_WORKGROUP", "1")
+        option("gcc_one_workgroup", 1)
         x_one, am_one = GccPhat(L, 3).correlate(d0, d1)
-        monkeypatch.delenv("FRT_GCC_ONE_WORKGROUP")
+        option("gcc_one_workgroup", -1)
         ref, _, _ = dsp.gcc_phat(d0[1].copy(), d1[1].copy())
         for x in (x_multi, x_one):
             assert np.max(np.abs(x[1] - ref)) <= 1e-9 * np.max(np.abs(ref)), L

@@ -237,6 +237,41 @@ def test_band_energies_with_chunks_shorter_than_the_block(tabs, chunk, nblocks):
         bank.energies(x32[:, :n], 1024, alphas)                  # host arrays: not served with a chunk below the block
 
 
+@pytest.mark.parametrize("block,chunk,device", [(256, 0, False), (512, 0, False), (256, 0, True), (256, 256, True), (256, 1024, True), (512, 1024, True),
+                                                (512, 512, False), (512, 256, True), (1024, 256, True), (256, 2048, False)])
+def test_band_energies_with_blocks_shorter_than_1024(tabs, block, chunk, device):
+    """Energy blocks of 256 / 512 samples: the two lowest-rate stages then have blocks of 1 or 2 of their samples.  Sequential
+    mode, time-parallel chunks of at least a block (every entry of the block axis is the caller's: the slot kernel's short-block
+    loop), and chunks shorter than the block (chunk 256 under block 512: stage 7's blocks of 2 samples ride in the lane
+    kernel's groups of 4, stage 8's blocks of 1 cannot — they would span 4 entries where the caller reads every 2nd) — each
+    against the oracle fed block by block."""
+    import torch
+    from friture_amd.filter import IirBank
+    bpo, C = 3, 2
+    boct, aoct = list(tabs[f"boct_{bpo}"]), list(tabs[f"aoct_{bpo}"])
+    nblocks = 8192 // block * 3
+    n = block * nblocks
+    x32 = np.stack([synth("noise", n, 31), synth("chirp", n, 32)])
+    alphas, kernels = dsp.band_smoothing_setup(bpo, 0.125)
+    bank = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, C)
+    bank.set_chunk(chunk)
+    half = n // 2 // max(block, chunk, 1) * max(block, chunk, 1)
+    if device:
+        xd = torch.from_numpy(x32).cuda()
+        got = torch.cat([bank.energies(xd[:, :half].contiguous(), block, alphas), bank.energies(xd[:, half:].contiguous(), block, alphas)], dim=1).cpu().numpy()
+    else:
+        got = np.concatenate([bank.energies(x32[:, :half], block, alphas), bank.energies(x32[:, half:], block, alphas)], axis=1)
+    assert got.shape == (C, nblocks, 27)
+    for c in range(C):
+        zs = dsp.iir_bank_filtic(tabs["bdec"], tabs["adec"], boct, aoct)
+        prev = [0.0] * 27
+        for blk in range(nblocks):
+            y, _, zs = dsp.iir_bank(tabs["bdec"], tabs["adec"], boct, aoct, x32[c, blk * block:(blk + 1) * block].astype(np.float64), zs)
+            prev = dsp.band_energies(y, kernels, alphas, prev)
+            ref = np.array(prev)
+            assert np.all(np.abs(got[c, blk] - ref) <= 1e-5 * ref + 1e-14 * ref.max()), (c, blk, np.max(np.abs(got[c, blk] / ref - 1)))
+
+
 def test_216_band_bank_with_chunks_of_1024_and_512(tabs):
     """The 216-band bank as bench.py's configs[4] leg runs it (chunk 512: shorter than the energy block; the narrow filters' decay
     spans hundreds of chunks, so scan rows are longer than the 16 chunks whose end states stay in registers) against the chunk

@@ -160,49 +160,19 @@ def test_batched_bank_energies(hip, bpo, block):
             assert np.all(np.abs(got[c, b] - want) <= 1e-5 * want + 1e-20 * want.max()), (c, b)
 
 
-@pytest.mark.parametrize("bpo,block", [(3, 1024), (24, 512)])
-def test_pair_kernel_equals_round2_kernel_on_a_long_batch(hip, bpo, block, monkeypatch):
-    """ola_pair_kernel (two real windows per complex transform, csrc/ola_wave.h) against the round-2 kernel (one real 4096-point
-    transform per workgroup; FRT_OLA_NO_WAVE=1) on a batch long enough for interior sets at every octave stage (2^18 samples,
-    an odd tail length in the second call): band signals to 1e-11 of each band's maximum, the float32 band energies to 1e-6, the
-    carried tails compared through a third call."""
-    from friture_amd.filter import FirBank
-    C, n = 2, 1 << 18
-    x = np.stack([synth("noise", n + 5000, 11 + c) for c in range(C)]).astype(np.float64)
-    alphas, _ = dsp.band_smoothing_setup(bpo, 0.125)
-    out = {}
-    for name in ("pair", "round2"):
-        if name == "round2":
-            monkeypatch.setenv("FRT_OLA_NO_WAVE", "1")
-        fb, eb = FirBank(bpo, C), FirBank(bpo, C)
-        out[name] = (fb.filter(x[:, :n])[0], fb.filter(x[:, n:n + 4097])[0], fb.filter(x[:, n + 4097:n + 5000])[0],
-                     eb.energies(x[:, :n].astype(np.float32), block, alphas))
-    monkeypatch.delenv("FRT_OLA_NO_WAVE")
-    for call in range(3):
-        for c in range(C):
-            for k in range(9 * bpo):
-                a, b = out["pair"][call][c][k], out["round2"][call][c][k]
-                assert a.shape == b.shape
-                assert np.max(np.abs(a - b)) <= 1e-11 * max(np.max(np.abs(b)), 1e-3), (call, c, k)
-    ea, eb_ = out["pair"][3], out["round2"][3]
-    assert ea.shape == (C, n // block, 9 * bpo)
-    assert np.all(np.abs(ea - eb_) <= 1e-6 * eb_ + 1e-20 * eb_.max())
-
-
 @pytest.mark.parametrize("bpo", [1, 3, 24])
-def test_chunk_energies_against_oracle_and_transform_path(hip, bpo, monkeypatch):
+def test_chunk_energies_against_oracle(hip, bpo):
     """One chunk = one energy block (the octave-spectrum widget's handler): the two-launch running-convolution path of
     frt_octbank_energies against the oracle's OlaBank + exp smoothing chunk by chunk (1e-5, the north star's band-energy
-    tolerance; float32 out), for the widget's 512, the extremes 1 and 1024, odd and ragged lengths, two channels; against
-    the transform path (FRT_OLA_NO_CHUNK_KERNELS) to float32 rounding; and interleaved with a batched call: both paths
-    carry the same tails."""
+    tolerance; float32 out), for the widget's 512, the extremes 1 and 1024, odd and ragged lengths, two channels; and
+    interleaved with a batched call (ola_pair_kernel): both paths carry the same tails."""
     from friture_amd.filter import FirBank
     C = 2
     sizes = [512, 512, 1, 1024, 333, 7, 512, 2, 640, 1023, 512, 100, 512]
     total = sum(sizes) + 4096
     x = np.stack([synth("noise", total, 300 + c) for c in range(C)])
     alphas, kernels = dsp.band_smoothing_setup(bpo, 0.125)
-    bank, other = FirBank(bpo, C), FirBank(bpo, C)
+    bank = FirBank(bpo, C)
     refs = [(dsp.OlaBank(bpo), [0.0] * (9 * bpo)) for _ in range(C)]
     pos = 0
 
@@ -217,19 +187,14 @@ def test_chunk_energies_against_oracle_and_transform_path(hip, bpo, monkeypatch)
         chunk = x[:, pos:pos + n]
         pos += n
         got = bank.energies(chunk, n, alphas)[:, 0]
-        monkeypatch.setenv("FRT_OLA_NO_CHUNK_KERNELS", "1")
-        via_fft = other.energies(chunk, n, alphas)[:, 0]
-        monkeypatch.delenv("FRT_OLA_NO_CHUNK_KERNELS")
         for c in range(C):
             want = oracle(c, chunk[c])
             assert np.all(np.abs(got[c] - want) <= 1e-5 * want + 1e-20 * want.max()), (bpo, i, n, c)
-        assert np.all(np.abs(got - via_fft) <= 3e-7 * np.abs(via_fft) + 1e-25), (bpo, i, n)
         if i == 6:
             # a batched call in between (four blocks of 1024): the transform kernels read and leave the same tails
             blk = x[:, pos:pos + 4096]
             pos += 4096
             gb = bank.energies(blk, 1024, alphas)
-            other.energies(blk, 1024, alphas)
             for c in range(C):
                 for b in range(4):
                     want = oracle(c, blk[c, b * 1024:(b + 1) * 1024])
@@ -255,9 +220,9 @@ def test_chunk_energies_device_pointers_and_db(hip):
 
 
 @pytest.mark.parametrize("bpo", [3, 24])
-def test_chunk_filter_equals_transform_path(hip, bpo, monkeypatch):
+def test_chunk_filter_equals_transform_path(hip, bpo, option):
     """Octave_Filters.filter on one block: the running-convolution launches (default for blocks of up to 1024 samples) against
-    the per-stage transform launches (FRT_OLA_NO_CHUNK_KERNELS) — the same sums in another order: 1e-12 of each band's scale,
+    the per-stage transform launches (frt_set_option("ola_chunk_kernels", 0)) — the same sums in another order: 1e-12 of each band's scale,
     equal shapes and decimation factors, tails shared when the two alternate, two channels' worth of state kept apart."""
     from friture_amd.octavefilters import Octave_Filters
     a, b, mixed = Octave_Filters(bpo), Octave_Filters(bpo), Octave_Filters(bpo)
@@ -267,11 +232,11 @@ def test_chunk_filter_equals_transform_path(hip, bpo, monkeypatch):
         chunk = x[pos:pos + n]
         pos += n
         ya, da = a.filter(chunk)
-        monkeypatch.setenv("FRT_OLA_NO_CHUNK_KERNELS", "1")
+        option("ola_chunk_kernels", 0)
         yb, db = b.filter(chunk)
         if i % 2:
             ym, _ = mixed.filter(chunk)
-        monkeypatch.delenv("FRT_OLA_NO_CHUNK_KERNELS")
+        option("ola_chunk_kernels", -1)
         if not i % 2:
             ym, _ = mixed.filter(chunk)
         assert da == db and len(ya) == len(yb) == 9 * bpo

@@ -193,9 +193,9 @@ def test_streaming_tracker_mirror(golden, pt):
         assert (np.isnan(w) and np.isnan(got2[f])) or abs(got2[f] - w) <= TOL_F0 * w, f
 
 
-def test_other_grids_and_both_log_grid_kernels(pt, monkeypatch):
+def test_other_grids_and_both_log_grid_kernels(pt, option):
     """The widget's grid (1023 points) runs the register-resident log-grid kernel; any other grid, and
-    FRT_PITCH_GRID_2PASS=1, the two-pass one.  Both are the same arithmetic: identical bits on the widget's
+    frt_set_option("pitch_grid_two_pass", 1), the two-pass one.  Both are the same arithmetic: identical bits on the widget's
     grid, oracle parity on a coarser and a finer grid (pitch_tracker.py:334-355 with other min_freq / cres)."""
     n_fft, hop, frames = 2048, 512, 48
     n = n_fft + hop * (frames - 1)
@@ -203,9 +203,9 @@ def test_other_grids_and_both_log_grid_kernels(pt, monkeypatch):
     phase = 2 * np.pi * np.cumsum(180.0 * 2 ** (1.0 * t / n)) / 48000.0
     x = 0.2 * (np.sin(phase) + 0.5 * np.sin(2 * phase) + 0.25 * np.sin(3 * phase)) + 1e-3 * np.random.default_rng(5).standard_normal(n)
     fast, fast_raw = pt.PitchEngine(n_fft, hop).track(x, with_raw=True)
-    monkeypatch.setenv("FRT_PITCH_GRID_2PASS", "1")
+    option("pitch_grid_two_pass", 1)
     slow, slow_raw = pt.PitchEngine(n_fft, hop).track(x, with_raw=True)
-    monkeypatch.delenv("FRT_PITCH_GRID_2PASS")
+    option("pitch_grid_two_pass", -1)
     assert np.array_equal(fast, slow, equal_nan=True) and np.array_equal(fast_raw, slow_raw, equal_nan=True)
     window = dsp.hann_symmetric(n_fft)
     for min_freq, max_freq, cres in [(100, 800, 20), (65, 1047, 7)]:

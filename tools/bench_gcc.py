@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 def main():
     import torch
 
+    from friture_amd import _lib
     from friture_amd.signal.correlation import GccPhat
     ap = argparse.ArgumentParser()
     ap.add_argument("--length", type=int, default=24000)
@@ -31,11 +32,8 @@ def main():
         d1 = np.roll(d0, 37, axis=1) + 0.025 * rng.standard_normal((pairs, L))
         a0, a1 = torch.from_numpy(d0).to(dev), torch.from_numpy(d1).to(dev)
         row = {}
-        for shape, env in (("default", None), ("one_workgroup", "1"), ("split", "0")):
-            if env is None:
-                os.environ.pop("FRT_GCC_ONE_WORKGROUP", None)
-            else:
-                os.environ["FRT_GCC_ONE_WORKGROUP"] = env
+        for shape, opt in (("default", -1), ("one_workgroup", 1), ("split", 0)):
+            _lib.set_option("gcc_one_workgroup", opt)
             g = GccPhat(L, pairs)
             for _ in range(3):
                 _, am = g.correlate(a0, a1)
@@ -48,7 +46,7 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.iters
             row[shape] = {"ms": ms, "windows_per_s": pairs / ms * 1e3, "delay_found": bool(int(am[0]) == 37)}
-        os.environ.pop("FRT_GCC_ONE_WORKGROUP", None)
+        _lib.set_option("gcc_one_workgroup", -1)
         res[str(pairs)] = row
         print(pairs, {k: (round(v["ms"], 4), round(v["windows_per_s"])) for k, v in row.items()}, flush=True)
     print(json.dumps(res))

@@ -203,7 +203,8 @@ static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int ite
     const void* xhost = precision == 32 ? (const void*)x.data() : (const void*)xd.data();
     char* dx0;
     char* dout0;
-    const size_t out_bytes = (size_t)C * F * nb * oesz, in_bytes = x.size() * esz;
+    // (each set's buffers start on 4 KB boundaries: the split rows are 64-byte lines only if their base is)
+    const size_t out_bytes = ((size_t)C * F * nb * oesz + 4095) / 4096 * 4096, in_bytes = (x.size() * esz + 4095) / 4096 * 4096;
     const size_t row_bytes = (size_t)C * F * (nb - 1) * oesz;        // split layout: the rows, then the Nyquist plane, in the same allocation
     auto run_once = [&](const void* xin, char* o) {
         if (split) CK(frt_stft_run_split(h, kind, xin, T, T, o, o + row_bytes, &nf_g));
@@ -211,7 +212,7 @@ static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int ite
     };
     HK(hipMalloc(&dx0, in_bytes * sets));
     HK(hipMalloc(&dout0, out_bytes * sets));
-    for (int k = 0; k < sets; ++k) HK(hipMemcpy(dx0 + in_bytes * k, xhost, in_bytes, hipMemcpyHostToDevice));
+    for (int k = 0; k < sets; ++k) HK(hipMemcpy(dx0 + in_bytes * k, xhost, x.size() * esz, hipMemcpyHostToDevice));
     char* dx = dx0;
     void* dout = dout0;
     hipStream_t s;
