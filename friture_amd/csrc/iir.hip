@@ -414,12 +414,12 @@ constexpr int kLanePrefetch = FRT_LANE_PREFETCH;      // trips of 16 samples a l
 static_assert(kLanePrefetch == 1 || kLanePrefetch == 2 || kLanePrefetch == 4, "prefetch ring of 1, 2 or 4 trips");
 constexpr int kLaneBands = FRT_LANE_BANDS;      // measured: one band filter per wavefront re-reads the samples per filter and is 15-70 % slower (bpo 3 / 24)
 
+// (bx, lane): the wavefront's index along the launch's first axis — channel x 64-chunk group — and the lane inside it
 template <int NF, int ORD, bool DEC, bool F32>
-__device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0) {
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0, int bx, int lane) {
     const int nblk = (a.nchunks + 63) / 64;
-    const int c = blockIdx.x / nblk;
-    const int q = (blockIdx.x - c * nblk) * 64 + lane;
+    const int c = bx / nblk;
+    const int q = (bx - c * nblk) * 64 + lane;
     const bool valid = q < a.nchunks;
     const int qc = valid ? q : a.nchunks - 1;                  // lanes past the end shadow the last chunk, store nothing
     const int L = a.chunk;
@@ -561,16 +561,34 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0) {
 
 // grid: x = n_channels * ceil(nchunks / 64), y = filter groups (band filters kLaneBands at a time, then the decimator)
 template <bool F32>
-__global__ void __launch_bounds__(64) iir_lane_kernel(const IirStageArgs a, int n_band, int n_band_groups) {
-    const int g = blockIdx.y;
+__device__ __forceinline__ void iir_lane_wave(const IirStageArgs& a, int n_band, int n_band_groups, int bx, int g, int lane) {
     if (g < n_band_groups) {
         const int f0 = g * kLaneBands, left = n_band - f0;
-        if (left >= 3) iir_lane_body<3, 4, false, F32>(a, f0);
-        else if (left == 2) iir_lane_body<2, 4, false, F32>(a, f0);
-        else iir_lane_body<1, 4, false, F32>(a, f0);
+        if (left >= 3) iir_lane_body<3, 4, false, F32>(a, f0, bx, lane);
+        else if (left == 2) iir_lane_body<2, 4, false, F32>(a, f0, bx, lane);
+        else iir_lane_body<1, 4, false, F32>(a, f0, bx, lane);
     } else {
-        iir_lane_body<1, 12, true, F32>(a, a.dec_filter);
+        iir_lane_body<1, 12, true, F32>(a, a.dec_filter, bx, lane);
     }
+}
+
+template <bool F32>
+__global__ void __launch_bounds__(64) iir_lane_kernel(const IirStageArgs a, int n_band, int n_band_groups) {
+    iir_lane_wave<F32>(a, n_band, n_band_groups, blockIdx.x, blockIdx.y, threadIdx.x);
+}
+
+// The same wavefronts as workgroups of FOUR, one per SIMD of a compute unit, with a dynamic LDS reservation (never touched) sized so
+// that exactly ceil(workgroups / CUs) workgroups fit a CU: the hardware spreads a workgroup's waves over the four SIMDs and cannot
+// stack more workgroups on one CU than on another.  A wavefront's filter group is its index modulo the number of groups, so the
+// waves of a workgroup (and of a CU) are a mix of band groups and decimators in the launch's own proportion.
+template <bool F32>
+__global__ void __launch_bounds__(256) iir_lane_wg4_kernel(const IirStageArgs a, int n_band, int n_band_groups, int nbx, int ngy) {
+    extern __shared__ char lane_reservation[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long v = (long long)blockIdx.x * 4 + wave;
+    const int bx = (int)(v / ngy), g = (int)(v - (long long)bx * ngy);
+    if (bx >= nbx) return;
+    iir_lane_wave<F32>(a, n_band, n_band_groups, bx, g, threadIdx.x & 63);
 }
 
 // The lane kernel serves the output pass of an energy-only time-parallel stage when the stage is whole chunks of whole
@@ -592,8 +610,38 @@ static int launch_iir_lane(const IirStageArgs& a, int n_channels, hipStream_t st
     const int n_band = a.dec_filter, groups = (n_band + kLaneBands - 1) / kLaneBands;
     const long long bx = (long long)n_channels * ((a.nchunks + 63) / 64);
     FRT_REQUIRE(bx < (1ll << 31), "iir lane pass: too many wavefronts");
-    if (a.in_f32) hipLaunchKernelGGL(iir_lane_kernel<true>, dim3((unsigned)bx, groups + 1), dim3(64), 0, stream, a, n_band, groups);
-    else hipLaunchKernelGGL(iir_lane_kernel<false>, dim3((unsigned)bx, groups + 1), dim3(64), 0, stream, a, n_band, groups);
+    int gy = groups + 1, gb = groups;
+#ifdef FRT_EXPERIMENTS
+    // timing experiments (wrong results): only the band groups, or only the decimator, of every output pass
+    if (const char* e = exp_env("FRT_LANE_ONLY")) {
+        if (e[0] == 'b') gy = groups;
+        else { gy = 1; gb = 0; }
+    }
+#endif
+    // A launch of at most one wavefront per SIMD with long chunks (the high-rate stages of a few channels: 8 channels x 27 bands at
+    // chunks of 1024 are 512 band + 512 decimator wavefronts on 1024 SIMDs): as workgroups of four wavefronts, ONE per compute unit
+    // (iir_lane_wg4_kernel) — single-wavefront workgroups end up two to a SIMD on part of the chip while other SIMDs idle, and a
+    // SIMD shared by two of these float64 chains advances each at 0.73 of its solo rate (tools/exp/lane_probe.cpp).  Measured
+    // (profiles/r05_iir_launches.txt): stage 0 160.6 -> 135.6 us, stage 1 72.2 -> 62.9 us; equal from chunks of 256 down, slower
+    // with more than one workgroup per CU (216 bands).
+    {
+        const long long waves = bx * gy, nwg = (waves + 3) / 4;
+        if (nwg <= device_cu_count() && nwg * 2 > device_cu_count() && a.chunk >= 512 && !exp_env("FRT_LANE_NO_WG4")) {
+            static bool raised = false;
+            if (!raised) {
+                FRT_HIP_CHECK(hipFuncSetAttribute((const void*)iir_lane_wg4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                FRT_HIP_CHECK(hipFuncSetAttribute((const void*)iir_lane_wg4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                raised = true;
+            }
+            const size_t lds = (size_t)96 * 1024;            // more than half of a CU's 160 KB: a second workgroup does not fit
+            if (a.in_f32) hipLaunchKernelGGL(iir_lane_wg4_kernel<true>, dim3((unsigned)nwg), dim3(256), lds, stream, a, n_band, gb, (int)bx, gy);
+            else hipLaunchKernelGGL(iir_lane_wg4_kernel<false>, dim3((unsigned)nwg), dim3(256), lds, stream, a, n_band, gb, (int)bx, gy);
+            FRT_HIP_CHECK(hipGetLastError());
+            return FRT_OK;
+        }
+    }
+    if (a.in_f32) hipLaunchKernelGGL(iir_lane_kernel<true>, dim3((unsigned)bx, gy), dim3(64), 0, stream, a, n_band, gb);
+    else hipLaunchKernelGGL(iir_lane_kernel<false>, dim3((unsigned)bx, gy), dim3(64), 0, stream, a, n_band, gb);
     FRT_HIP_CHECK(hipGetLastError());
     return FRT_OK;
 }

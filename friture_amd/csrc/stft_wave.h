@@ -521,12 +521,20 @@ stft_kernel(const StftArgs a) {
                     // the self-paired bin M/2 for j = 3), so that every store covers [M - (j + 1) TPF, M - j TPF) exactly
                     const int ihi = i == 0 ? TPF : i;
                     typedef std::remove_cv_t<std::remove_pointer_t<decltype(vals)>> V;
+                    // non-temporal: every store of a one-wavefront frame writes whole 64-byte lines here, which the L2 can pass on
+                    // without keeping them (measured on aligned buffer sets, profiles/r05_headline_variants.txt: colour kind 0.117 ->
+                    // 0.113 ms, PSD kind 0.109 -> 0.105; on the packed rows' partial lines the same hint costs 3 %)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        stream_store(r + klo + j * TPF, vals[j]);
                         auto hv = vals[4 + j];
                         if (i == 0) hv = j < 3 ? vals[5 + (j < 3 ? j : 0)] : mid;
+#ifdef FRT_SPLIT_PLAIN_STORES
+                        stream_store(r + klo + j * TPF, vals[j]);
                         stream_store(r + M - ihi - j * TPF, hv);
+#else
+                        __builtin_nontemporal_store(vals[j], r + klo + j * TPF);
+                        __builtin_nontemporal_store(hv, r + M - ihi - j * TPF);
+#endif
                     }
                     // bin M (lane 0, slot 4)
                     if constexpr (NYQ_REG) {

@@ -29,6 +29,9 @@ import numpy as np, torch
 from friture_amd import _lib, filter_design
 from friture_amd.filter import IirBank
 ch, bpo, log2n = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (8, 3, 22)
+import os
+if os.environ.get("FRT_LIB_VARIANT"):      # A/B runs: a variant library built by tools/exp/build_variant.sh
+    _lib.LIB_PATH = ROOT / "tools" / "variants" / os.environ["FRT_LIB_VARIANT"] / "libfriture_hip.so"
 _lib.init(0)
 dev = torch.device("cuda", 0)
 t = filter_design.load_tables()
