@@ -29,6 +29,9 @@ struct frt_ola_state {
     // its launches read the tails of `pending` and write the new ones to `pending_next`, then the two swap
     frt::DeviceBuffer pending_next;
     frt::DeviceBuffer btw, btwl, bH, bHw, ewt;
+    frt::DeviceBuffer multi_tab[2];     // argument tables of ola_pair_multi_kernel, one per parity of the tails' swap
+    std::vector<char> multi_host[2];    // what each holds
+    int multi_parity = 0;
     std::vector<long long> ewt_off;     // per band: offset of its smoothing weights in ewt
     int ewt_block = 0;
     std::vector<double> ewt_alpha;

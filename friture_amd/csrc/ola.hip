@@ -276,6 +276,7 @@ struct OlaBatchArgs {
     const double* pend_in;     // [C][nfilt][kTail]
     double* pend_out;
     int nfilt, dec_filter, gsize;
+    int f_first, f_count;      // ola_pair_kernel: the launch serves filters f_first .. f_first + f_count - 1 in groups of gsize
     double* y;                 // packed band outputs or null
     long long y_cstride;
     long long y_off[kMaxFilters];
@@ -692,6 +693,8 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
     for (int k = 0; k < h->nbands; ++k) band_off[k + 1] = band_off[k] + len[kNOctave - 1 - k / h->bpo];
     if (d_eblock && (rc = ola_energy_weights(h, n, eblock0, whole, alphas))) return rc;
     const size_t stage_pend = (size_t)h->n_channels * h->nfilt * kTail;
+    std::vector<OlaBatchArgs> deferred;            // band filters of the stages whose decimators ran ahead (see below)
+    std::vector<long long> deferred_sets;
     for (int j = 0; j < kNOctave; ++j) {
         OlaBatchArgs a{};
         a.x = j == 0 ? d_x : h->xbuf[j].ptr;
@@ -731,18 +734,40 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
             a.Hw = o->bHw.as<double>();
             for (int i = 0; i < h->bpo; ++i) a.er[i] = d_eblock ? 1.0 - o->ewt_alpha[a.band_index[i]] : 0.0;
             const long long nsets = (len[j] + kTail + kOwSet - 1) / kOwSet, slots = 4ll * device_cu_count();
-            long long best = -1;
-            int best_groups = 1;
-            for (int g = 1; g <= h->nfilt; ++g) {
-                const int gs = (h->nfilt + g - 1) / g, g2 = (h->nfilt + gs - 1) / gs;
-                const long long rounds = (nsets * h->n_channels * g2 + slots - 1) / slots, cost = rounds * (1 + gs);
-                if (best < 0 || cost < best) {
-                    best = cost;
-                    best_groups = g2;
+            auto launch = [&](int f_first, int f_count) {
+                long long best = -1;
+                int best_groups = 1;
+                for (int g = 1; g <= f_count; ++g) {
+                    const int gs = (f_count + g - 1) / g, g2 = (f_count + gs - 1) / gs;
+                    const long long rounds = (nsets * h->n_channels * g2 + slots - 1) / slots, cost = rounds * (1 + gs);
+                    if (best < 0 || cost < best) {
+                        best = cost;
+                        best_groups = g2;
+                    }
                 }
+                a.f_first = f_first;
+                a.f_count = f_count;
+                a.gsize = (f_count + best_groups - 1) / best_groups;
+                hipLaunchKernelGGL(ola_pair_kernel, dim3((unsigned)nsets, best_groups, h->n_channels), dim3(kOwThreads), 0, h->stream, a);
+            };
+            // Only the DECIMATOR of a stage feeds the next one.  With many band filters per stage (bpo >= 6) the decimators run
+            // ahead, one short launch per stage (1 + 1 transforms per set instead of 1 + nfilt), and the band filters of those
+            // stages — which nothing waits for — follow in ONE launch over all of them (`deferred`, ola_pair_multi_kernel): the
+            // low-rate stages stop being a chain of launches that no longer fill the chip (15-50 us each in round 4), at the price
+            // of one more forward transform per set.  Measured (profiles/r05_ola_defer.txt, sets x channels up to 4 rounds of the
+            // chip's workgroup slots deferred): 8 ch x 2^20 at bpo 24 1.267 -> 1.137 ms, bpo 12 0.767 -> 0.688, bpo 6 0.768 -> 0.727;
+            // with 4 filters per stage (bpo 3) the repeated forward transform costs what the shorter chain saves (0.789 -> 0.799)
+            // and with 2 (bpo 1) more: one launch per stage there.
+            long long defer_below = h->bpo >= 6 ? 4 * slots : 0;
+            if (const char* e = exp_env("FRT_OLA_DEFER_BELOW")) defer_below = atoll(e);
+            const bool split_stage = nsets * h->n_channels <= defer_below && exp_env("FRT_OLA_NO_DEFER") == nullptr;
+            if (!split_stage) {
+                launch(0, h->nfilt);
+            } else {
+                launch(h->bpo, 1);
+                deferred.push_back(a);
+                deferred_sets.push_back(nsets);
             }
-            a.gsize = (h->nfilt + best_groups - 1) / best_groups;
-            hipLaunchKernelGGL(ola_pair_kernel, dim3((unsigned)nsets, best_groups, h->n_channels), dim3(kOwThreads), 0, h->stream, a);
             FRT_HIP_CHECK(hipGetLastError());
             continue;
         }
@@ -756,6 +781,48 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
         hipLaunchKernelGGL(ola_batch_kernel, dim3((unsigned)nblk, groups, h->n_channels), dim3(kObThreads), 0, h->stream, a);
         FRT_HIP_CHECK(hipGetLastError());
 #endif
+    }
+    if (!deferred.empty()) {
+        // the deferred band filters: ONE launch over all their stages (ola_pair_multi_kernel).  Its argument table lives in device
+        // memory; it changes only with the call's buffers and with the parity of the tails' swap, so a steady stream of calls
+        // uploads it twice.  (The copy is from pageable memory: the runtime has taken the bytes when it returns.)
+        OlaMultiIndex m{};
+        m.nstage = (int)deferred.size();
+        int best_groups = 1;
+        {
+            long long total = 0, best = -1;
+            for (long long ns : deferred_sets) total += ns;
+            const long long slots = 4ll * device_cu_count();
+            for (int g = 1; g <= h->bpo; ++g) {
+                const int gs = (h->bpo + g - 1) / g, g2 = (h->bpo + gs - 1) / gs;
+                const long long rounds = (total * h->n_channels * g2 + slots - 1) / slots, cost = rounds * (1 + gs);
+                if (best < 0 || cost < best) {
+                    best = cost;
+                    best_groups = g2;
+                }
+            }
+        }
+        int at = 0;
+        for (size_t i = 0; i < deferred.size(); ++i) {
+            m.first_set[i] = at;
+            at += (int)deferred_sets[i];
+            deferred[i].f_first = 0;
+            deferred[i].f_count = h->bpo;
+            deferred[i].gsize = (h->bpo + best_groups - 1) / best_groups;
+        }
+        m.first_set[deferred.size()] = at;
+        const int parity = o->multi_parity;
+        const size_t bytes = deferred.size() * sizeof(OlaBatchArgs);
+        std::vector<char>& held = o->multi_host[parity];
+        if (held.size() != bytes || memcmp(held.data(), deferred.data(), bytes) != 0) {
+            if ((rc = o->multi_tab[parity].reserve(kNOctave * sizeof(OlaBatchArgs)))) return rc;
+            held.assign((const char*)deferred.data(), (const char*)deferred.data() + bytes);
+            FRT_HIP_CHECK(hipMemcpyAsync(o->multi_tab[parity].ptr, held.data(), bytes, hipMemcpyHostToDevice, h->stream));
+        }
+        hipLaunchKernelGGL(ola_pair_multi_kernel, dim3((unsigned)at, best_groups, h->n_channels), dim3(kOwThreads), 0, h->stream,
+                           o->multi_tab[parity].as<OlaBatchArgs>(), m);
+        FRT_HIP_CHECK(hipGetLastError());
+        o->multi_parity ^= 1;
     }
     std::swap(o->pending.ptr, o->pending_next.ptr);             // equal sizes; the streaming path and the graphs follow `pending`
     return FRT_OK;

@@ -163,18 +163,21 @@ typedef double ow_d2 __attribute__((ext_vector_type(2), aligned(8)));
 
 // grid (sets, filter groups, channels), 128 threads.  A set = 3072 consecutive outputs of the stage's n + 511 (the outputs
 // past the stage's end are the new tails).  Global addresses are a uniform base plus a 32-bit thread offset throughout.
-__global__ void __launch_bounds__(kOwThreads, 2) ola_pair_kernel(const OlaBatchArgs a) {
+// A = OlaBatchArgs (kernel argument) or the same struct in the constant address space (a table in device memory read with scalar
+// loads): one body, two entry points below.
+template <typename A>
+__device__ __forceinline__ void ola_pair_body(const A& a, const int set, const int grp, const int ch, const int nsets) {
     using C = cpx<double>;
     __shared__ C xb[kOwN];
     __shared__ double wsum[2][12];
-    const int set = blockIdx.x, grp = blockIdx.y, ch = blockIdx.z;
     const long long S = (long long)set * kOwSet, n = a.n;
     const bool inner = set != 0 && S + kOwSet <= n;          // uniform: every sample and every output of the set exists
     const bool tail_set = S + kOwSet > n;                    // holds the stage's end: partial runs and the new tails
     const C* tw = (const C*)a.tw;
     const C w1 = tw[threadIdx.x], w128 = tw[16 * (threadIdx.x & 7)];
-    int nf = a.nfilt - grp * a.gsize;
+    int nf = a.f_count - grp * a.gsize;
     nf = nf < a.gsize ? nf : a.gsize;
+    const int fg = a.f_first + grp * a.gsize;                // first filter of this workgroup
 
     C v[16], xc[16];
     {
@@ -220,7 +223,7 @@ __global__ void __launch_bounds__(kOwThreads, 2) ola_pair_kernel(const OlaBatchA
             for (int e = 0; e < 2; ++e) xb[K0 + (e ^ x3) + 256 * d] = v[e + 2 * d];
         __syncthreads();
         const int R3 = t ^ ((t >> 3) & 1);
-        const C* H = (const C*)a.Hw + (size_t)(grp * a.gsize) * kOwN;
+        const C* H = (const C*)a.Hw + (size_t)fg * kOwN;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             xc[j] = cconj(xb[R3 + 128 * j]);
@@ -229,10 +232,10 @@ __global__ void __launch_bounds__(kOwThreads, 2) ola_pair_kernel(const OlaBatchA
         __syncthreads();
     }
     for (int it = 0; it < nf; ++it) {
-        const int f = grp * a.gsize + it;
+        const int f = fg + it;
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));
-        const bool tmark = FRT_OW_TIMING && it == 0 && set == (int)gridDim.x / 2 && ch == 0 && grp == 0 && n == (1ll << FRT_OW_TIMING);
+        const bool tmark = FRT_OW_TIMING && it == 0 && set == nsets / 2 && ch == 0 && grp == 0 && n == (1ll << FRT_OW_TIMING);
         OW_T(0);
         const bool dec = f == a.dec_filter;
         const bool energy = a.eblock && !dec;
@@ -360,6 +363,25 @@ __global__ void __launch_bounds__(kOwThreads, 2) ola_pair_kernel(const OlaBatchA
             for (int j = 0; j < 16; ++j) v[j] = cmul(xc[j], hn[j]);
         }
     }
+}
+
+__global__ void __launch_bounds__(kOwThreads, 2) ola_pair_kernel(const OlaBatchArgs a) {
+    ola_pair_body(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+}
+
+// Several stages' launches in one: blockIdx.x walks the sets of the stages listed in `m` one stage after the other, the stage's
+// arguments come from a table in device memory (wave-uniform: scalar loads through the constant address space).
+struct OlaMultiIndex {
+    int nstage;
+    int first_set[kNOctave + 1];        // blockIdx.x of a stage's first set; [nstage] = the grid's x
+};
+typedef const OlaBatchArgs __attribute__((address_space(4))) OlaBatchArgsK;
+__global__ void __launch_bounds__(kOwThreads, 2) ola_pair_multi_kernel(const OlaBatchArgs* table, const OlaMultiIndex m) {
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < kNOctave; ++i) s += (i < m.nstage && (int)blockIdx.x >= m.first_set[i]) ? 1 : 0;
+    const OlaBatchArgsK& a = ((OlaBatchArgsK*)(uintptr_t)table)[s];
+    ola_pair_body(a, (int)blockIdx.x - m.first_set[s], blockIdx.y, blockIdx.z, m.first_set[s + 1] - m.first_set[s]);
 }
 
 }  // namespace frt

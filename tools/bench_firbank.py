@@ -9,6 +9,9 @@ import torch
 from friture_amd import _lib, filter_design
 from friture_amd.filter import FirBank, IirBank
 
+import os
+if os.environ.get("FRT_LIB_VARIANT"):      # A/B runs: a variant library built by tools/exp/build_variant.sh
+    _lib.LIB_PATH = ROOT / "tools" / "variants" / os.environ["FRT_LIB_VARIANT"] / "libfriture_hip.so"
 _lib.init(0)
 dev = torch.device("cuda", 0)
 t = filter_design.load_tables()
@@ -28,7 +31,7 @@ for ch, bpo, log2n in ((8, 3, 22), (64, 24, 20), (8, 24, 20)):
         while time.perf_counter() - t0 < 0.3:
             bank.energies(x, 1024, alphas, out=out)
             torch.cuda.synchronize()
-        steps = 5
+        steps = 20
         t0 = time.perf_counter()
         for _ in range(steps):
             bank.energies(x, 1024, alphas, out=out)
