@@ -63,17 +63,23 @@ def synth_channel(channel: int, n: int) -> np.ndarray:
 
 
 def kernel_source_digest() -> str:
-    """Digest of the sources of the headline kernel (stft_kernel, N <= 1024: stft_wave.h + fft_core.h; stft.hip holds the host
-    side, stft_big.h / stft_pk.h the N >= 2048 instances) — their code, i.e. with comments and blank lines removed: a PMC
+    """Digest of the sources of the headline kernel (stft_kernel, N <= 1024: stft_wave.h + fft_core.h, and stft_launch of stft.hip,
+    which picks its instance, run length and grid; stft_big.h / stft_pk*.h hold the N >= 2048 instances) — their code, i.e. with comments and blank lines removed: a PMC
     traffic figure is only quoted for the code it was measured on (rewording a comment does not un-measure it).
     tests/test_evidence_fresh.py fails while profiles/pmc_traffic.json carries another digest."""
     import re
     h = hashlib.sha256()
-    for name in ("stft_wave.h", "fft_core.h"):
-        text = (ROOT / "friture_amd" / "csrc" / name).read_text()
+
+    def code(text):
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         lines = [re.sub(r"//[^\n]*", "", ln).rstrip() for ln in text.splitlines()]
-        h.update("\n".join(ln for ln in lines if ln.strip()).encode())
+        return "\n".join(ln for ln in lines if ln.strip()).encode()
+    for name in ("stft_wave.h", "fft_core.h"):
+        h.update(code((ROOT / "friture_amd" / "csrc" / name).read_text()))
+    # ... and the launch geometry (run length, lane groups, instance selection: it decides the re-read share of a launch)
+    host = (ROOT / "friture_amd" / "csrc" / "stft.hip").read_text()
+    m = re.search(r"static int stft_launch\(.*?\n}\n", host, re.S)
+    h.update(code(m.group(0)) if m else b"stft_launch not found")
     return h.hexdigest()[:16]
 
 
@@ -643,6 +649,12 @@ def main():
         legs.update(gcc_leg(dev, world, rank))
         legs.update(octave_legs(dev, world, rank, 8, 24, 20, "configs4_bank", False))
 
+    # Every collective of the job is behind us: the process group goes away HERE, before rank 0 times the CPU baseline — the other
+    # ranks are done and exit instead of spinning in a collective while rank 0 runs an all-cores pool on the same host.
+    import torch.distributed as dist
+    if dist.is_initialized():                  # (a group of one exists under FRT_DIST_FORCE=1: RCCL exercised on a single GPU)
+        dist.destroy_process_group()
+
     if rank == 0:
         spectra_per_step = n_channels * F
         value = spectra_per_step * args.steps / elapsed
@@ -709,7 +721,7 @@ def main():
             result["legs"] = legs
             result["octave_bands"] = legs.get("configs2_bank_iir_time_parallel")      # the metric's second half, as in round 1
         if args.cpu_budget > 0:
-            # rank 0 only, whatever the world size (after the timed region; the other ranks wait at the final barrier)
+            # rank 0 only, whatever the world size (after the timed region and after the process group is gone)
             base = cpu_baseline(host_x[0], n_fft, hop, consts["weight"], consts["lut"], args.cpu_budget, with_legs=bool(legs) or stub)
             side = base.pop("_side")
             result["cpu_baseline"] = base
@@ -738,9 +750,6 @@ def main():
         print(f"bench.py: ranks_seen = {ranks_seen}, expected 0..{world - 1}", file=sys.stderr)
         exit_code = 4
 
-    import torch.distributed as dist
-    if dist.is_initialized():                  # (a group of one exists under FRT_DIST_FORCE=1: RCCL exercised on a single GPU)
-        dist.destroy_process_group()
     if exit_code:
         raise SystemExit(exit_code)
 

@@ -111,6 +111,7 @@ SIGNATURES = {
 
 _lib = None
 _initialised = False
+bound_device = 0          # the HIP device frt_init bound this process to (set by init)
 
 
 def load() -> ctypes.CDLL:
@@ -159,6 +160,8 @@ def init(device: int | None = None) -> ctypes.CDLL:
                     if torch.cuda.is_available() and torch.cuda.is_initialized():
                         device = torch.cuda.current_device()
         check(lib.frt_init(device, None, None))
+        global bound_device
+        bound_device = int(device)
         _initialised = True
     return lib
 

@@ -69,11 +69,12 @@ bool is_device_pointer(const void* p);
 // block, and hipFree synchronises the whole device (not legal at all while a stream of this thread is capturing): the old
 // block is PARKED here instead — no synchronisation on growth.  Parked blocks are released together, behind one device
 // synchronisation, once more than kRetiredLimit bytes (or 64 blocks) are parked and the calling thread is not capturing,
-// and by frt_release_retired() (handle destruction calls it).  Buffers grow geometrically, so the parked total stays
-// below twice the live total.
+// and whenever a handle is destroyed (free_retired_allocations(true)).  Buffers grow geometrically, so the parked total
+// stays below twice the live total; when an allocation fails outside a capture the parked blocks are released and the
+// allocation is tried once more.
 void retire_allocation(void* p, size_t bytes);
 void free_retired_allocations(bool force);
-constexpr size_t kRetiredLimit = (size_t)1 << 30;
+constexpr size_t kRetiredLimit = (size_t)1 << 28;      // 256 MB parked at most between handle destructions
 struct CaptureScope {                       // marks the calling thread as capturing a stream for its lifetime
     CaptureScope();
     ~CaptureScope();
@@ -93,7 +94,13 @@ struct DeviceBuffer {
         }
         ptr = nullptr;
         bytes = 0;
-        FRT_HIP_CHECK(hipMalloc(&ptr, n));
+        hipError_t e = hipMalloc(&ptr, n);
+        if (e != hipSuccess && !CaptureScope::active()) {       // out of memory with blocks parked: release them, try once more
+            (void)hipGetLastError();
+            free_retired_allocations(true);
+            e = hipMalloc(&ptr, n);
+        }
+        FRT_HIP_CHECK(e);
         bytes = n;
         return FRT_OK;
     }

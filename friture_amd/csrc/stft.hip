@@ -503,7 +503,9 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
             auto groups = [&](int r) { return ((F + r - 1) / r) * h->n_channels; };
             brun = h->log2m >= 10 ? 16 : 8;
             while (brun > 1 && groups(brun) < need) brun /= 2;
-            if (h->log2m >= 10) {
+            // (only when the batch fills the chip at all: a widget-sized or catch-up call of a few frames keeps the halved run —
+            // four frames of one channel are four workgroups side by side, not one workgroup walking them one after the other)
+            if (h->log2m >= 10 && groups(brun) >= need) {
                 // one workgroup per CU (N = 16384), two (N = 8192), four (N = 4096) or eight (N = 2048): the groups should come in whole rounds of the chip (F = 253 frames x 32 channels in
                 // runs of 16 are 512 groups = two rounds, the second one short; in runs of 32 one round) with runs as long as
                 // that allows (every run re-reads N - hop samples of its predecessor and loads ~120 constants per thread)

@@ -21,6 +21,21 @@ DEFAULT_FFT_SIZE = 4096        # spectrogram_settings.py:27-34
 DEFAULT_TIMERANGE = 10.
 
 
+
+def _torch_device():
+    """(torch, the device the HIP library is bound to) when torch with a GPU is importable, else None: the device-resident hand-over
+    between the transform and the fused pipeline call needs a device allocation, which this class borrows from torch; without
+    torch the frames take the host path (one more round trip per chunk, same pixels)."""
+    try:
+        import torch
+    except ImportError:
+        return None
+    if not torch.cuda.is_available():
+        return None
+    from . import _lib
+    return torch, torch.device("cuda", _lib.bound_device)
+
+
 class Spectrogram:
     def __init__(self, fft_size=DEFAULT_FFT_SIZE, overlap=Fraction(3, 4), spec_min=-140., spec_max=0., weighting=0,
                  scale=fscales.Mel, minfreq=20., maxfreq=20000., screen_width=800, screen_height=400,
@@ -67,7 +82,7 @@ class Spectrogram:
         screen_rate_frac = Fraction(max(self.screen_width, 1), int(self.timerange_s * 1000))
         self.screen_resampler.set_ratio(self.sfft_rate_frac, screen_rate_frac)
         self.frequency_resampler.setnsamples(self.screen_height)
-        if self.audio_pipeline.fusable():
+        if self.audio_pipeline.fusable() and _torch_device() is not None:
             # one wait per chunk: the frames' (dB + w - min)/(max - min) stay on the device, frame-major as the kernel writes them
             # (enqueued, not waited for), and the fused pipeline call reads them there (until round 4: two host round trips)
             return self.audio_pipeline.push_frames_device(self._norm_dev(window[0], realizable), len(self.freq), realizable)
@@ -80,15 +95,14 @@ class Spectrogram:
         stream, which is ordered behind blocking streams only (friture_hip.h): the engine is put on the null stream first."""
         import ctypes
 
-        import torch
-
         from . import _lib
         from ._lib import FRT_STFT_NORM
+        torch, device = _torch_device()
         x = np.ascontiguousarray(samples, np.float64)
         nb = len(self.freq)
         d = getattr(self, "_d_norm", None)
         if d is None or d.shape[0] < n_frames or d.shape[1] != nb:
-            d = self._d_norm = torch.empty((max(n_frames, 8), nb), dtype=torch.float64, device="cuda")
+            d = self._d_norm = torch.empty((max(n_frames, 8), nb), dtype=torch.float64, device=device)      # the ENGINE's device
         nf = ctypes.c_int64(0)
         e = self._engine
         _lib.check(e._lib.frt_stft_set_stream(e._h, None))

@@ -36,7 +36,7 @@ def main():
         raise SystemExit(f"no FETCH_SIZE / WRITE_SIZE rows for '{needle}' under {root}: {sorted(raw)}")
     import bench
     read_b, write_b = 2.0 * raw["FETCH_SIZE"] * 1024.0, raw["WRITE_SIZE"] * 1024.0
-    rec = {"n_fft": 1024, "hop": 512, "frames": 131071, "kernel": f"{needle} (IMAGE kind, bench.py)",
+    rec = {"n_fft": 1024, "hop": 512, "frames": 131071, "kernel": f"{needle} (colour and PSD kinds of bench.py, split rows)",
            "kernel_sources": bench.kernel_source_digest(),
            "hbm_bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_bytes": write_b, "raw": raw,
            "check": {"TCC_EA0_RDREQ*128B": raw.get("TCC_EA0_RDREQ_sum", 0.0) * 128.0, "TCC_EA0_WRREQ*64B": raw.get("TCC_EA0_WRREQ_sum", 0.0) * 64.0},
@@ -44,8 +44,8 @@ def main():
            "method": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python bench.py --steps 5 --warmup 2 --cpu-budget 0 "
                      "--prewarm-ms 0 --no-legs; mean over the kernel's dispatches; FETCH_SIZE doubled per MI355X_MICROARCH.md",
            "algorithmic_bytes_per_launch": 131071 * 4100,
-           "kernel_sources_note": "digest of the code of stft_wave.h + fft_core.h (comments and blank lines removed) at the measured "
-                                  "revision; bench.kernel_source_digest()"}
+           "kernel_sources_note": "digest of the code of stft_wave.h + fft_core.h + stft_launch of stft.hip (comments and blank lines removed) at the "
+                                  "measured revision; bench.kernel_source_digest()"}
     (ROOT / "profiles" / "pmc_traffic.json").write_text(json.dumps(rec, indent=1))
     print(json.dumps({k: rec[k] for k in ("hbm_bytes_per_launch", "read_bytes", "write_bytes", "algorithmic_bytes_per_launch", "kernel_sources")}))
 

@@ -67,7 +67,7 @@ static std::vector<double> host_psd(const double* x, int N) {
     return p;
 }
 
-static int check_case(int N, int hop, int C, int frames, int precision, bool device_side, int run) {
+static int check_case(int N, int hop, int C, int frames, int precision, bool device_side, int run, bool split = false) {
     const int nb = N / 2 + 1;
     const int64_t T = (int64_t)N + (int64_t)hop * (frames - 1) + 3;  // a few unused tail samples
     const int64_t stride = T + (T & 1);
@@ -105,7 +105,31 @@ static int check_case(int N, int hop, int C, int frames, int precision, bool dev
         const size_t oesz = kind == FRT_STFT_IMAGE ? 4 : esz;
         out[kind].assign((size_t)C * F * nb * oesz, 0x7f);
         int64_t nf = 0;
-        if (device_side) {
+        if (split) {
+            // split rows (frt_stft_run_split): rows [C][F][N/2] + Nyquist plane [C][F], reassembled into the packed shape checked below
+            const size_t row_bytes = (size_t)C * F * (nb - 1) * oesz, nyq_bytes = (size_t)C * F * oesz;
+            std::vector<char> rows(row_bytes, 0x7f), nyq(nyq_bytes, 0x7f);
+            if (device_side) {
+                void *dx, *drows, *dnyq;
+                HK(hipMalloc(&dx, xd.size() * esz));
+                HK(hipMalloc(&drows, row_bytes));
+                HK(hipMalloc(&dnyq, nyq_bytes));
+                HK(hipMemcpy(dx, xin, xd.size() * esz, hipMemcpyHostToDevice));
+                CK(frt_stft_run_split(h, kind, dx, T, stride, drows, dnyq, &nf));
+                HK(hipDeviceSynchronize());
+                HK(hipMemcpy(rows.data(), drows, row_bytes, hipMemcpyDeviceToHost));
+                HK(hipMemcpy(nyq.data(), dnyq, nyq_bytes, hipMemcpyDeviceToHost));
+                HK(hipFree(dx));
+                HK(hipFree(drows));
+                HK(hipFree(dnyq));
+            } else {
+                CK(frt_stft_run_split(h, kind, xin, T, stride, rows.data(), nyq.data(), &nf));
+            }
+            for (size_t r = 0; r < (size_t)C * F; ++r) {
+                memcpy(&out[kind][r * nb * oesz], &rows[r * (nb - 1) * oesz], (nb - 1) * oesz);
+                memcpy(&out[kind][(r * nb + nb - 1) * oesz], &nyq[r * oesz], oesz);
+            }
+        } else if (device_side) {
             void *dx, *dout;
             HK(hipMalloc(&dx, xd.size() * esz));
             HK(hipMalloc(&dout, out[kind].size()));
@@ -158,8 +182,8 @@ static int check_case(int N, int hop, int C, int frames, int precision, bool dev
     const double tol = precision == 32 ? 1e-5 : 1e-12;
     const double tol_db = precision == 32 ? 2e-2 : 1e-9;
     const bool ok = worst <= tol && worst_db <= tol_db && pix_bad == 0;
-    printf("%s N=%5d hop=%5d C=%d F=%3d p%d %s run=%2d  psd_relmax=%.3e dB_abs=%.3e norm_abs=%.3e pix_bad=%ld pix_edge=%ld\n",
-           ok ? "ok  " : "FAIL", N, hop, C, frames, precision, device_side ? "dev " : "host", run, worst, worst_db,
+    printf("%s N=%5d hop=%5d C=%d F=%3d p%d %s%s run=%2d  psd_relmax=%.3e dB_abs=%.3e norm_abs=%.3e pix_bad=%ld pix_edge=%ld\n",
+           ok ? "ok  " : "FAIL", N, hop, C, frames, precision, device_side ? "dev " : "host", split ? " split" : "", run, worst, worst_db,
            worst_norm, pix_bad, pix_edge);
     return ok ? 0 : 1;
 }
@@ -172,6 +196,12 @@ static int do_check() {
         fails += check_case(N, 3 * N / 8, 2, 9, 32, false, 4);   // generic even hop
         fails += check_case(N, N / 2 + 1, 1, 7, 32, true, 3);      // odd hop: scalar loads
         fails += check_case(N, N / 4, 1, 5, 64, false, 0);
+    }
+    for (int N = 32; N <= 1024; N *= 2) {                       // split rows: every N <= 1024 instance class, both sides, both precisions
+        fails += check_case(N, N / 2, 2, 70, 32, true, 0, true);
+        fails += check_case(N, N / 4, 1, 19, 32, false, 5, true);
+        fails += check_case(N, N / 2 + 1, 1, 7, 32, true, 3, true);
+        fails += check_case(N, N / 2, 1, 9, 64, true, 0, true);
     }
     fails += check_case(1024, 512, 3, 300, 32, true, 0);
     fails += check_case(1024, 512, 1, 1, 32, true, 0);
