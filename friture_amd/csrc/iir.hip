@@ -606,27 +606,24 @@ static bool lane_kernel_serves(const IirStageArgs& a, const int* orders) {
     return vec_x && vec_xn && !off;
 }
 
-static int launch_iir_lane(const IirStageArgs& a, int n_channels, hipStream_t stream) {
+enum LaneWhich { kWhichAll, kWhichBands, kWhichDec };      // the launch's filter groups: every one, the band groups, the decimator
+
+static int launch_iir_lane(const IirStageArgs& a, int n_channels, hipStream_t stream, LaneWhich which) {
     const int n_band = a.dec_filter, groups = (n_band + kLaneBands - 1) / kLaneBands;
     const long long bx = (long long)n_channels * ((a.nchunks + 63) / 64);
     FRT_REQUIRE(bx < (1ll << 31), "iir lane pass: too many wavefronts");
-    int gy = groups + 1, gb = groups;
-#ifdef FRT_EXPERIMENTS
-    // timing experiments (wrong results): only the band groups, or only the decimator, of every output pass
-    if (const char* e = exp_env("FRT_LANE_ONLY")) {
-        if (e[0] == 'b') gy = groups;
-        else { gy = 1; gb = 0; }
-    }
-#endif
+    // the kernel takes its group from the launch's second axis: y < gb are band groups, the rest the decimator
+    const int gy = which == kWhichAll ? groups + 1 : which == kWhichBands ? groups : 1;
+    const int gb = which == kWhichDec ? 0 : groups;
     // A launch of at most one wavefront per SIMD with long chunks (the high-rate stages of a few channels: 8 channels x 27 bands at
     // chunks of 1024 are 512 band + 512 decimator wavefronts on 1024 SIMDs): as workgroups of four wavefronts, ONE per compute unit
     // (iir_lane_wg4_kernel) — single-wavefront workgroups end up two to a SIMD on part of the chip while other SIMDs idle, and a
     // SIMD shared by two of these float64 chains advances each at 0.73 of its solo rate (tools/exp/lane_probe.cpp).  Measured
     // (profiles/r05_iir_launches.txt): stage 0 160.6 -> 135.6 us, stage 1 72.2 -> 62.9 us; equal from chunks of 256 down, slower
-    // with more than one workgroup per CU (216 bands).
+    // with more than one workgroup per CU (216 bands).  (Only for launches that have the chip to themselves.)
     {
         const long long waves = bx * gy, nwg = (waves + 3) / 4;
-        if (nwg <= device_cu_count() && nwg * 2 > device_cu_count() && a.chunk >= 512 && !exp_env("FRT_LANE_NO_WG4")) {
+        if (which == kWhichAll && nwg <= device_cu_count() && nwg * 2 > device_cu_count() && a.chunk >= 512 && !exp_env("FRT_LANE_NO_WG4")) {
             static bool raised = false;
             if (!raised) {
                 FRT_HIP_CHECK(hipFuncSetAttribute((const void*)iir_lane_wg4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -682,6 +679,7 @@ struct ZeroStateArgs {
     const int* rowmap;         // [rows_padded]: f * kStates + s of each row, -1 for padding
     double* partial;           // [n_slices][C][nfilt][nchunks][kStates]
     long long partial_stride;
+    int rt_base, rt_count;     // MFMA kernel: the launch serves row tiles rt_base .. rt_base + rt_count - 1 (tile 0: the decimator)
 };
 
 // ROWS states x COLS (channel, chunk) columns per lane.  The table row g[k][.] reaches the FMAs through scalar registers,
@@ -792,11 +790,13 @@ typedef double zs_double4 __attribute__((ext_vector_type(4)));
 __host__ __device__ inline size_t zs_mfma_index(int k, int row, int row_tiles) {
     return (((((size_t)(k >> 4) * row_tiles + (row >> 4)) * 4 + ((k >> 2) & 3)) * 16 + (row & 15)) * 4) + (k & 3);
 }
-constexpr int kZsTiles = kZsRows / 16;          // row tiles per workgroup
 #ifndef FRT_ZS_UNROLL
 #define FRT_ZS_UNROLL 2
 #endif
 
+// kZsTiles row tiles (of 16 rows) per workgroup: 2 where the launch's tile range is even (every x value then feeds two MFMAs),
+// 1 for the decimator's single tile and odd ranges
+template <int kZsTiles>
 __global__ void __launch_bounds__(64) iir_zero_state_mfma_kernel(const ZeroStateArgs a) {
     const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
     const long long ncols = (long long)a.n_channels * a.nchunks;
@@ -805,7 +805,7 @@ __global__ void __launch_bounds__(64) iir_zero_state_mfma_kernel(const ZeroState
     const long long cc = valid ? col : 0;
     const int c = (int)(cc / a.nchunks), q = (int)(cc % a.nchunks);
     const int k0 = blockIdx.y * a.slice;                                  // a multiple of 16
-    const int rt0 = blockIdx.z * kZsTiles, row_tiles = a.rows_padded / 16;
+    const int rt0 = a.rt_base + blockIdx.z * kZsTiles, row_tiles = a.rows_padded / 16;
     const long long first = (long long)q * a.chunk + k0 + 4 * g;          // the lane's first sample
     const long long xrow = (long long)c * a.x_stride;
     zs_double4 acc[kZsTiles];
@@ -857,6 +857,7 @@ __global__ void __launch_bounds__(64) iir_zero_state_mfma_kernel(const ZeroState
     for (int rt = 0; rt < kZsTiles; ++rt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
+            if (rt0 + rt >= a.rt_base + a.rt_count) continue;              // (tile ranges are whole multiples of kZsTiles: never taken)
             const int m = a.rowmap[(rt0 + rt) * 16 + 4 * v + g];
             if (m >= 0) out[(((size_t)c * a.nfilt + (m >> 4)) * a.nchunks + q) * kStates + (m & 15)] = acc[rt][v];
         }
@@ -869,6 +870,17 @@ __global__ void __launch_bounds__(256) iir_slice_sum_kernel(double* __restrict__
     double e = partial[i];
     for (int p = 1; p < n_slices; ++p) e += partial[(size_t)p * stride + i];
     partial[i] = e;
+}
+
+// the same for the filters f0 .. f0 + nf - 1 only (the layout is [C][nfilt][nchunks][kStates]): grid (x over nf x nchunks x kStates, C)
+__global__ void __launch_bounds__(256) iir_slice_sum_range_kernel(double* __restrict__ partial, long long stride, int n_slices, int nfilt,
+                                                                  int nchunks, int f0, int nf) {
+    const long long per = (long long)nchunks * kStates, i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per * nf) return;
+    const long long at = ((long long)blockIdx.y * nfilt + f0) * per + i;
+    double e = partial[at];
+    for (int p = 1; p < n_slices; ++p) e += partial[(size_t)p * stride + at];
+    partial[at] = e;
 }
 
 // A^L z for the states of a filter held by the lanes of a DPP row, lane s owning row s of the matrix.  NT: number of
@@ -1017,10 +1029,11 @@ __global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* 
                                                                   const double* __restrict__ chunk_end,
                                                                   const int* __restrict__ order,
                                                                   double* __restrict__ chunk_init, int nfilt,
-                                                                  int nchunks, int group, int nrows, int nseg, int halo) {
+                                                                  int nchunks, int group, int nrows, int nseg, int halo, int f0, int nf) {
     __shared__ double gend[kScanRows][kStates];
-    const int gid = blockIdx.x / nseg, seg = blockIdx.x - gid * nseg;      // gid: (channel, filter) pair
-    const int f = gid % nfilt;
+    // the launch serves filters f0 .. f0 + nf - 1 of every channel; gid: the (channel, filter) pair's index in the [C][nfilt] layout
+    const int lid = blockIdx.x / nseg, seg = blockIdx.x - lid * nseg;
+    const int f = f0 + lid % nf, gid = (lid / nf) * nfilt + f;
     const int ord = order[f];                                 // uniform in the workgroup
     const bool live = (int)(threadIdx.x & 15) < ord;
     if (ord <= 4) iir_scan_body<4>(power_l, power_g, state, chunk_end, chunk_init, gid, seg, f, live, nchunks, group, nrows, halo, gend);
@@ -1363,6 +1376,13 @@ extern "C" void frt_octbank_destroy(frt_octbank* h) {
     for (auto& e : h->graphs)
         if (e.exec) (void)hipGraphExecDestroy(e.exec);
     if (h->gstream) (void)hipStreamDestroy(h->gstream);
+    for (auto& st : h->side)
+        if (st) (void)hipStreamDestroy(st);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    for (auto& e : h->ev_x)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : h->ev_side)
+        if (e) (void)hipEventDestroy(e);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     frt_ola_destroy(h);
@@ -1497,13 +1517,22 @@ static int ensure_powers(frt_octbank* h, int n) {
     }
     int rc = upload(h->power, p);
     if (rc) return rc;
-    // zero-state response tables g[k][row] = (A^(L-1-k) B)[s], rows = the live states of every filter
-    std::vector<int> rowmap;
-    for (int f = 0; f < h->nfilt; ++f)
+    // zero-state response tables g[k][row] = (A^(L-1-k) B)[s], rows = the live states of every filter.  The decimator's rows come
+    // first, padded to whole tiles of 16 rows, then the band filters': a launch of the table product can serve the decimator alone
+    // (the only filter the next stage waits for) or the band filters alone (ZeroStateArgs::rt_base / rt_count).
+    std::vector<int> rowmap, row_of(h->nfilt, 0);
+    const int fdec = h->nfilt - 1;                  // the decimator is the last filter of every stage (frt_octbank_create)
+    for (int t = 0; t < h->h_order[fdec]; ++t) rowmap.push_back(fdec * kStates + t);
+    rowmap.resize((rowmap.size() + 15) / 16 * 16, -1);
+    h->zs_dec_tiles = (int)rowmap.size() / 16;
+    for (int f = 0; f < fdec; ++f) {
+        row_of[f] = (int)rowmap.size();
         for (int t = 0; t < h->h_order[f]; ++t) rowmap.push_back(f * kStates + t);
+    }
     h->zs_rows = (int)rowmap.size();
-    h->zs_rows_padded = (h->zs_rows + kZsRows - 1) / kZsRows * kZsRows;
-    rowmap.resize(h->zs_rows_padded, -1);
+    rowmap.resize((rowmap.size() + 15) / 16 * 16, -1);
+    h->zs_band_tiles = (int)rowmap.size() / 16 - h->zs_dec_tiles;
+    h->zs_rows_padded = (int)rowmap.size();
     h->zs_offset.assign(kNOctave, 0);
     size_t total = 0;
     for (int j = 0; j < kNOctave; ++j) {
@@ -1513,9 +1542,8 @@ static int ensure_powers(frt_octbank* h, int n) {
     std::vector<double> tab(total, 0.0), tab_m(total, 0.0);      // tab_m: the same values in the MFMA kernel's operand order
     for (int j = 0; j < kNOctave; ++j) {
         const int L = stage_chunk(h->chunk0, j);
-        int row = 0;
         for (int f = 0; f < h->nfilt; ++f) {
-            const int ord = h->h_order[f];
+            const int ord = h->h_order[f], row = row_of[f];
             const double* bc = &h->h_coef[(size_t)f * kCoefStride];
             const double* ac = bc + kMaxOrder + 1;
             std::vector<long double> v(ord), w(ord);
@@ -1529,7 +1557,6 @@ static int ensure_powers(frt_octbank* h, int n) {
                 for (int t = 0; t < ord; ++t) w[t] = (t + 1 < ord ? v[t + 1] : 0.0L) - (long double)ac[t + 1] * v[0];
                 v.swap(w);
             }
-            row += ord;
         }
     }
     if ((rc = upload(h->zs_table, tab)) || (rc = upload(h->zs_table_m, tab_m)) || (rc = upload(h->zs_rowmap, rowmap))) return rc;
@@ -1547,19 +1574,63 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
     int len[kNOctave];
     stage_lengths(n, len);
     const bool parallel = h->chunk0 > 0 && n >= 2 * h->chunk0;
-    int nchunks = 1;              // the largest chunk count of any stage (scratch size)
+    // K-slices of a stage's table product: enough wavefronts to fill the chip when the columns (channel x chunk) alone do not
+    static const bool use_vector_alu = exp_env("FRT_ZS_VECTOR") != nullptr;      // A/B runs: the vector-ALU kernel
+    auto slices_for = [&](int chunk, int nch) {
+        const int cols_per_wave = use_vector_alu ? 64 * kZsCols : 16;
+        const int slice_min = use_vector_alu ? 8 : 16;
+        const long long colwaves = ((long long)h->n_channels * nch + cols_per_wave - 1) / cols_per_wave;
+        static const int max_slices = exp_int("FRT_ZS_MAX_SLICES", kMaxSlices);      // A/B runs
+        // (round 4: one wavefront per CU is where splitting K stops paying — every doubling adds the partial sums'
+        // traffic and, from 2 slices on, a launch that sums them: 2048 -> 256 took configs[4]'s 216-band bank from
+        // 0.90 to 0.72 ms and configs[2]'s from 0.72 to 0.70, profiles/r04_zero_state_slices.txt)
+        static const int wave_goal = exp_int("FRT_ZS_WAVE_GOAL", device_cu_count());
+        // (a slice is at least 64 samples: below that the product is launch-bound whatever its grid, and the launch that
+        // sums the slices costs its ~5 us — the 64-sample chunks of the low-rate stages are not sliced: -1 % at 8 ch x 27 bands)
+        int ns = 1;
+        while (ns < max_slices && colwaves * ns < wave_goal && chunk % (2 * ns * slice_min) == 0 && chunk / (2 * ns) >= 64) ns *= 2;      // whole K-blocks per slice
+        return ns;
+    };
+    // every stage has its own scratch (zero-state end states per K-slice, chunk start states): stages overlap in time (below)
+    size_t off_end[kNOctave] = {}, off_init[kNOctave] = {};
+    int stage_slices[kNOctave] = {};
     if (parallel) {
+        size_t tot_end = 0, tot_init = 0;
         for (int j = 0; j < kNOctave; ++j) {
-            const int cj = stage_chunk(h->chunk0, j);
+            int cj = stage_chunk(h->chunk0, j);
+            if (cj < 64) cj = 64;
             const int nj = (len[j] + cj - 1) / cj;
-            if (nj > nchunks) nchunks = nj;
+            const size_t ws = (size_t)h->n_channels * h->nfilt * (nj > 0 ? nj : 1) * kStates;
+            stage_slices[j] = slices_for(cj, nj);
+            off_end[j] = tot_end;
+            off_init[j] = tot_init;
+            tot_end += ws * stage_slices[j];
+            tot_init += ws;
         }
         int rc = ensure_powers(h, n);
         if (rc) return rc;
-        const size_t ws = (size_t)h->n_channels * h->nfilt * nchunks * kStates * sizeof(double);
-        if ((rc = h->chunk_end.reserve(ws * kMaxSlices)) || (rc = h->chunk_init.reserve(ws)))
+        if ((rc = h->chunk_end.reserve(tot_end * sizeof(double))) || (rc = h->chunk_init.reserve(tot_init * sizeof(double))))
             return rc;
     }
+    // EXPERIMENT (-DFRT_EXPERIMENTS builds, FRT_IIR_SIDE=1; measured and rejected, profiles/r05_iir_side_streams.txt): the band
+    // filters of a stage beside the decimator chain.  Only a stage's DECIMATOR feeds the next stage, so its table product, chunk
+    // scan and output pass run on the handle's stream one stage after the other, and every stage's band filters — the same three
+    // launches restricted to them — follow on a side stream as soon as the stage's input exists.  It does not pay: the
+    // decimator-only launches last what the all-filter launches last (the table product is bound by its sample loads, the output
+    // pass by its dependent float64 chain, the low-rate stages by launch latency), so the chain is no shorter and the band
+    // launches beside it slow it down: 8 ch x 27 bands 0.64 -> 0.81 ms, 8 ch x 216 bands 0.69 -> 0.72, 64 ch x 216 bands 4.62 -> 4.47.
+    bool beside = parallel && d_y == nullptr && d_eblock != nullptr && h->bpo >= 1 && !h->zero_state_by_recurrence && !use_vector_alu &&
+                  !CaptureScope::active() && exp_env("FRT_IIR_SIDE") != nullptr;
+    if (beside) {
+        if (!h->ev_start) {
+            FRT_HIP_CHECK(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
+            for (auto& e : h->ev_x) FRT_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto& e : h->ev_side) FRT_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto& st : h->side) FRT_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        }
+        FRT_HIP_CHECK(hipEventRecord(h->ev_start, h->stream));
+    }
+    bool side_used[frt_octbank::kSideStreams] = {};
     for (int j = 1; j < kNOctave; ++j) {
         int rc = h->xbuf[j].reserve((size_t)h->n_channels * len[j] * sizeof(double));
         if (rc) return rc;
@@ -1582,8 +1653,8 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
         a.chunk = parallel ? stage_chunk(h->chunk0, j) : ((len[j] + 63) / 64 * 64);
         if (a.chunk < 64) a.chunk = 64;
         a.nchunks = parallel ? (len[j] + a.chunk - 1) / a.chunk : 1;
-        a.chunk_end = h->chunk_end.as<double>();
-        a.chunk_init = h->chunk_init.as<double>();
+        a.chunk_end = h->chunk_end.as<double>() + off_end[j];
+        a.chunk_init = h->chunk_init.as<double>() + off_init[j];
         a.scan_group = parallel ? h->sgroup[j] : 1;
         a.scan_rows = (a.nchunks + a.scan_group - 1) / a.scan_group;
         a.y = d_y;
@@ -1624,68 +1695,100 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
             a.pass = 0;
             if ((rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream))) return rc;
         } else {
-            int n_slices = 1;
+            const int n_slices = stage_slices[j];
             const long long slice_stride = (long long)h->n_channels * h->nfilt * a.nchunks * kStates;
-            if (h->zero_state_by_recurrence) {
-                a.pass = 1;
-                if ((rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream))) return rc;
-            } else {
-                // K-slices: enough wavefronts to fill the chip when the columns alone do not
-                static const bool use_vector_alu = exp_env("FRT_ZS_VECTOR") != nullptr;      // A/B runs: the vector-ALU kernel
-                const int cols_per_wave = use_vector_alu ? 64 * kZsCols : 16;
-                const int slice_min = use_vector_alu ? 8 : 16;
-                const long long colwaves = ((long long)h->n_channels * a.nchunks + cols_per_wave - 1) / cols_per_wave;
-                static const int max_slices = exp_env("FRT_ZS_MAX_SLICES") ? atoi(exp_env("FRT_ZS_MAX_SLICES")) : kMaxSlices;      // A/B runs
-                // (round 4: one wavefront per CU is where splitting K stops paying — every doubling adds the partial sums'
-                // traffic and, from 2 slices on, a launch that sums them: 2048 -> 256 took configs[4]'s 216-band bank from
-                // 0.90 to 0.72 ms and configs[2]'s from 0.72 to 0.70, profiles/r04_zero_state_slices.txt)
-                static const int wave_goal = exp_env("FRT_ZS_WAVE_GOAL") ? atoi(exp_env("FRT_ZS_WAVE_GOAL")) : device_cu_count();
-                // (a slice is at least 64 samples: below that the product is launch-bound whatever its grid, and the launch that
-                // sums the slices costs its ~5 us — the 64-sample chunks of the low-rate stages are not sliced: -1 % at 8 ch x 27 bands)
-                while (n_slices < max_slices && colwaves * n_slices < wave_goal && a.chunk % (2 * n_slices * slice_min) == 0 &&
-                       a.chunk / (2 * n_slices) >= 64)
-                    n_slices *= 2;      // whole K-blocks per slice
-                ZeroStateArgs z{};
-                z.x = a.x; z.x_stride = a.x_stride; z.n = a.n; z.in_f32 = a.in_f32;
-                z.chunk = a.chunk; z.nchunks = a.nchunks; z.n_channels = h->n_channels; z.nfilt = h->nfilt;
-                z.slice = a.chunk / n_slices;
-                z.vec = ((uintptr_t)a.x % 16 == 0) && (a.x_stride % (a.in_f32 ? 4 : 2) == 0);
-                z.table = h->zs_table.as<double>() + h->zs_offset[j];
-                z.table_m = h->zs_table_m.as<double>() + h->zs_offset[j];
-                z.rows = h->zs_rows; z.rows_padded = h->zs_rows_padded;
-                z.rowmap = h->zs_rowmap.as<int>();
-                z.partial = h->chunk_end.as<double>();
-                z.partial_stride = slice_stride;
-                if (use_vector_alu)
-                    hipLaunchKernelGGL((iir_zero_state_kernel<kZsRowsPerPass, kZsCols>),
-                                       dim3((unsigned)colwaves, n_slices, h->zs_rows_padded / kZsRowsPerPass), dim3(64), 0, h->stream, z);
-                else
-                    hipLaunchKernelGGL(iir_zero_state_mfma_kernel, dim3((unsigned)colwaves, n_slices, h->zs_rows_padded / kZsRows), dim3(64),
-                                       0, h->stream, z);
-                if (n_slices > 1)
-                    hipLaunchKernelGGL(iir_slice_sum_kernel, dim3((unsigned)((slice_stride + 255) / 256)), dim3(256), 0, h->stream,
-                                       h->chunk_end.as<double>(), slice_stride, n_slices, slice_stride);
-            }
-            const size_t per = (size_t)kNOctave * h->nfilt * kStates * kStates, off = (size_t)j * h->nfilt * kStates * kStates;
-            const int halo = h->shalo[j], nseg = (a.scan_rows + (kScanRows - halo) - 1) / (kScanRows - halo);
-            hipLaunchKernelGGL(iir_scan_kernel, dim3((unsigned)(h->n_channels * h->nfilt * nseg)), dim3(kScanRows * 16), 0, h->stream,
-                               h->power.as<double>() + off, h->power.as<double>() + per + off, a.state, h->chunk_end.as<double>(),
-                               h->order.as<int>(), h->chunk_init.as<double>(), h->nfilt, a.nchunks,
-                               a.scan_group, a.scan_rows, nseg, halo);
+            const int fdec = h->nfilt - 1;
             a.pass = 2;
             static const bool exact_ops = exp_env("FRT_IIR_EXACT_OPS") != nullptr;      // A/B runs
             a.fused = (d_y == nullptr && d_eblock != nullptr && !exact_ops) ? 1 : 0;
             a.n_channels = h->n_channels;
-            if (lane_kernel_serves(a, h->h_order.data())) rc = launch_iir_lane(a, h->n_channels, h->stream);
-            else {
-                set_eblock(elen_true, 1);            // the slot kernel writes every entry of the block axis itself
-                rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream);
+            const bool lane_serves = lane_kernel_serves(a, h->h_order.data());
+            ZeroStateArgs z{};
+            z.x = a.x; z.x_stride = a.x_stride; z.n = a.n; z.in_f32 = a.in_f32;
+            z.chunk = a.chunk; z.nchunks = a.nchunks; z.n_channels = h->n_channels; z.nfilt = h->nfilt;
+            z.slice = a.chunk / n_slices;
+            z.vec = ((uintptr_t)a.x % 16 == 0) && (a.x_stride % (a.in_f32 ? 4 : 2) == 0);
+            z.table = h->zs_table.as<double>() + h->zs_offset[j];
+            z.table_m = h->zs_table_m.as<double>() + h->zs_offset[j];
+            z.rows = h->zs_rows; z.rows_padded = h->zs_rows_padded;
+            z.rowmap = h->zs_rowmap.as<int>();
+            double* const cend = h->chunk_end.as<double>() + off_end[j];
+            double* const cinit = h->chunk_init.as<double>() + off_init[j];
+            z.partial = cend;
+            z.partial_stride = slice_stride;
+            const long long colwaves = ((long long)h->n_channels * a.nchunks + 15) / 16;
+            const size_t per = (size_t)kNOctave * h->nfilt * kStates * kStates, off = (size_t)j * h->nfilt * kStates * kStates;
+            const int halo = h->shalo[j], nseg = (a.scan_rows + (kScanRows - halo) - 1) / (kScanRows - halo);
+            // table product, slice sum and chunk scan of the filters f0 .. f0 + nf - 1 (row tiles t0 .. t0 + nt - 1) on `st`
+            auto front = [&](hipStream_t st, int t0, int nt, int f0, int nf) {
+                z.rt_base = t0;
+                z.rt_count = nt;
+                if (nt % 2 == 0)
+                    hipLaunchKernelGGL(iir_zero_state_mfma_kernel<2>, dim3((unsigned)colwaves, n_slices, nt / 2), dim3(64), 0, st, z);
+                else
+                    hipLaunchKernelGGL(iir_zero_state_mfma_kernel<1>, dim3((unsigned)colwaves, n_slices, nt), dim3(64), 0, st, z);
+                if (n_slices > 1) {
+                    const long long cnt = (long long)a.nchunks * kStates * nf;
+                    hipLaunchKernelGGL(iir_slice_sum_range_kernel, dim3((unsigned)((cnt + 255) / 256), h->n_channels), dim3(256), 0, st, cend,
+                                       slice_stride, n_slices, h->nfilt, a.nchunks, f0, nf);
+                }
+                hipLaunchKernelGGL(iir_scan_kernel, dim3((unsigned)(h->n_channels * nf * nseg)), dim3(kScanRows * 16), 0, st,
+                                   h->power.as<double>() + off, h->power.as<double>() + per + off, a.state, cend,
+                                   h->order.as<int>(), cinit, h->nfilt, a.nchunks, a.scan_group, a.scan_rows, nseg, halo, f0, nf);
+            };
+            if (h->zero_state_by_recurrence || use_vector_alu) {
+                // A/B paths of the table product: a second run of the recurrence, or the vector-ALU kernel; every filter in one chain
+                if (h->zero_state_by_recurrence) {
+                    a.pass = 1;
+                    if ((rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream))) return rc;
+                    a.pass = 2;
+                } else {
+                    hipLaunchKernelGGL((iir_zero_state_kernel<kZsRowsPerPass, kZsCols>),
+                                       dim3((unsigned)(((long long)h->n_channels * a.nchunks + 64 * kZsCols - 1) / (64 * kZsCols)), n_slices,
+                                            h->zs_rows_padded / kZsRowsPerPass), dim3(64), 0, h->stream, z);
+                    if (n_slices > 1)
+                        hipLaunchKernelGGL(iir_slice_sum_kernel, dim3((unsigned)((slice_stride + 255) / 256)), dim3(256), 0, h->stream,
+                                           cend, slice_stride, n_slices, slice_stride);
+                }
+                hipLaunchKernelGGL(iir_scan_kernel, dim3((unsigned)(h->n_channels * h->nfilt * nseg)), dim3(kScanRows * 16), 0, h->stream,
+                                   h->power.as<double>() + off, h->power.as<double>() + per + off, a.state, cend,
+                                   h->order.as<int>(), cinit, h->nfilt, a.nchunks, a.scan_group, a.scan_rows, nseg, halo, 0, h->nfilt);
+                if (lane_serves) rc = launch_iir_lane(a, h->n_channels, h->stream, kWhichAll);
+                else {
+                    set_eblock(elen_true, 1);            // the slot kernel writes every entry of the block axis itself
+                    rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream);
+                }
+            } else if (beside && lane_serves) {
+                // the decimator on the handle's stream ...
+                front(h->stream, 0, h->zs_dec_tiles, fdec, 1);
+                if ((rc = launch_iir_lane(a, h->n_channels, h->stream, kWhichDec))) return rc;
+                FRT_HIP_CHECK(hipEventRecord(h->ev_x[j + 1], h->stream));
+                // ... the band filters beside it, as soon as the stage's input exists
+                const int sidx = j % frt_octbank::kSideStreams;
+                hipStream_t sst = h->side[sidx];
+                FRT_HIP_CHECK(hipStreamWaitEvent(sst, j == 0 ? h->ev_start : h->ev_x[j], 0));
+                front(sst, h->zs_dec_tiles, h->zs_band_tiles, 0, fdec);
+                rc = launch_iir_lane(a, h->n_channels, sst, kWhichBands);
+                side_used[sidx] = true;
+            } else {
+                front(h->stream, 0, h->zs_dec_tiles + h->zs_band_tiles, 0, h->nfilt);
+                if (lane_serves) rc = launch_iir_lane(a, h->n_channels, h->stream, kWhichAll);
+                else {
+                    set_eblock(elen_true, 1);            // the slot kernel writes every entry of the block axis itself
+                    rc = launch_iir_stage(a, h->h_order.data(), h->n_channels, h->stream);
+                }
+                if (beside) FRT_HIP_CHECK(hipEventRecord(h->ev_x[j + 1], h->stream));      // (a later stage may still go beside)
             }
             if (rc) return rc;
             a.fused = 0;
         }
         FRT_HIP_CHECK(hipGetLastError());
     }
+    for (int i = 0; i < frt_octbank::kSideStreams; ++i)
+        if (side_used[i]) {                      // whatever follows on the handle's stream (the energy recurrences) waits for the band filters
+            FRT_HIP_CHECK(hipEventRecord(h->ev_side[i], h->side[i]));
+            FRT_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_side[i], 0));
+        }
     return FRT_OK;
 }
 

@@ -59,6 +59,11 @@ struct frt_octbank {
     std::vector<double> alpha_host, decay_host, weight_host;     // what the three tables hold (upload_if_changed)
     int power_chunk0 = -1;
     int power_n = -1;
+    int zs_dec_tiles = 0, zs_band_tiles = 0;   // row tiles (of 16) of the zero-state table: the decimator's first, then the band filters'
+    // the time-parallel mode's side streams: the band filters of a stage run beside the decimator chain (iir.hip, run_stages)
+    static constexpr int kSideStreams = 3;
+    hipStream_t side[kSideStreams] = {};
+    hipEvent_t ev_start = nullptr, ev_x[frt::kNOctave + 1] = {}, ev_side[kSideStreams] = {};
     frt_ola_state* ola = nullptr;
     // interactive host-buffer path: the per-block launch sequence (H2D, nine stage kernels, D2H) is
     // launch bound, so it is captured once per block length into a hipGraph and replayed

@@ -29,6 +29,7 @@ import numpy as np, torch
 from friture_amd import _lib, filter_design
 from friture_amd.filter import IirBank
 ch, bpo, log2n = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (8, 3, 22)
+chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
 import os
 if os.environ.get("FRT_LIB_VARIANT"):      # A/B runs: a variant library built by tools/exp/build_variant.sh
     _lib.LIB_PATH = ROOT / "tools" / "variants" / os.environ["FRT_LIB_VARIANT"] / "libfriture_hip.so"
@@ -41,7 +42,7 @@ decs = [2 ** j for j in range(9)[::-1] for _ in range(bpo)]
 alphas = np.array([1.0 - (1.0 - 0.65) ** (1.0 / (1.0 * 48000 / d + 1)) for d in decs])
 out = torch.empty((ch, n // 1024, 9 * bpo), dtype=torch.float32, device=dev)
 bank = IirBank(t["bdec"], t["adec"], list(t[f"boct_{bpo}"]), list(t[f"aoct_{bpo}"]), ch)
-bank.set_chunk(1024)
+bank.set_chunk(chunk)
 for _ in range(6):
     bank.energies(x, 1024, alphas, out=out)
 torch.cuda.synchronize()

@@ -1,15 +1,17 @@
 #!/bin/bash
 # One GPU-box session: parity tests, smoke, bench, rocprofv3 kernel stats + PMC traffic.  Outputs -> gpurun_out/.
+# (Round 5: the shipped library reads no environment switches; A/B of kernel generations are tools/exp sessions on variant builds.)
 set -u
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 echo "== selftest"; timeout 300 tools/bin/stft_selftest check | tail -2
 echo "== pytest -m gpu"; timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-echo "== bench (image, all legs)"; timeout 900 python bench.py --steps 50 --warmup 5 2>gpurun_out/bench_image.err | tail -1 | tee gpurun_out/${TAG}_bench_image.json | cut -c1-400
+echo "== bench (image, all legs)"; timeout 900 python bench.py --steps 50 --warmup 5 --full-json gpurun_out/${TAG}_bench_full.json 2>gpurun_out/bench_image.err | tail -1 | tee gpurun_out/${TAG}_bench_image.json | cut -c1-400; wc -c gpurun_out/${TAG}_bench_image.json
 echo "== bench (psd)"; timeout 600 python bench.py --steps 50 --warmup 5 --kind psd --cpu-budget 0 --no-legs 2>&1 | tail -1 | tee gpurun_out/${TAG}_bench_psd.json | cut -c1-300
+echo "== bench (packed rows, for comparison)"; timeout 600 python bench.py --steps 50 --warmup 5 --layout packed --cpu-budget 0 --no-legs 2>&1 | tail -1 | tee gpurun_out/${TAG}_bench_packed.json | cut -c1-300
 echo "== rocprofv3 kernel stats of the bench command"
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/stats -o bench -- python $R/bench.py --steps 20 --warmup 3 --cpu-budget 0 > $R/gpurun_out/prof/stats.log 2>&1 )
 python tools/prof_summary.py stats gpurun_out/prof/stats/bench_results.db > gpurun_out/${TAG}_bench_kernel_stats.txt 2>/dev/null; head -12 gpurun_out/${TAG}_bench_kernel_stats.txt | cut -c1-200
@@ -26,23 +28,33 @@ timeout 900 python bench.py --steps 50 --warmup 5 --cpu-budget 0 --no-legs 2>/de
 echo "== large frames: rates, PMC summaries (N = 16384 and 4096)"
 ( export FRT_BENCH_SETS=4; for cfg in "16384 8192 32 20 0" "16384 8192 32 20 3" "8192 4096 32 21 0" "8192 4096 32 21 3" "4096 2048 16 22 0" "4096 1024 16 22 3" "2048 1024 8 24 0" "2048 512 8 24 3"; do tools/bin/stft_selftest bench $cfg 0 40 | tail -1; done ) > gpurun_out/${TAG}_stft_big_bench.txt 2>&1; cat gpurun_out/${TAG}_stft_big_bench.txt | cut -c1-150
 bash tools/gpu_pmc.sh ${TAG}_n16384 0 3 16384 8192 32 20 > /dev/null 2>&1; python tools/prof_summary.py pmc gpurun_out/pmc_${TAG}_n16384 stft_pk > gpurun_out/${TAG}_stft16384_pmc.txt
-bash tools/gpu_pmc.sh ${TAG}_n4096 0 3 4096 1024 16 22 > /dev/null 2>&1; python tools/prof_summary.py pmc gpurun_out/pmc_${TAG}_n4096 stft_pk16q > gpurun_out/${TAG}_stft4096_pmc.txt
 echo "== kernel stats of the screen-space / widget / GCC kernels (their GPU tests under rocprofv3)"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/widgets -o w -- python -m pytest $R/tests/test_pipeline_gpu.py $R/tests/test_widgets_gpu.py $R/tests/test_gcc_gpu.py -q -m gpu -p no:cacheprovider > $R/gpurun_out/prof/widgets.log 2>&1 )
 python tools/prof_summary.py stats gpurun_out/prof/widgets/w_results.db > gpurun_out/${TAG}_widgets_kernel_stats.txt 2>/dev/null; head -5 gpurun_out/${TAG}_widgets_kernel_stats.txt | cut -c1-160
 echo "== GCC-PHAT against the batch size"
 python tools/bench_gcc.py 2>/dev/null | grep -v "^{" > gpurun_out/${TAG}_gcc_batch.txt; cat gpurun_out/${TAG}_gcc_batch.txt
 echo "== banks and latency"
-python tools/bench_firbank.py > gpurun_out/${TAG}_banks.json 2>&1; cut -c1-250 gpurun_out/${TAG}_banks.json
+python tools/bench_firbank.py > gpurun_out/${TAG}_banks.json 2>/dev/null; cut -c1-250 gpurun_out/${TAG}_banks.json
 python tools/stream_latency.py > gpurun_out/${TAG}_stream_latency.json 2>gpurun_out/stream_latency.err; head -c 300 gpurun_out/${TAG}_stream_latency.json
-echo "== N = 16384: stft_pk_kernel (FRT_STFT_NO_PK16=1) against stft_pk16_kernel, same session"
-( for cfg in "16384 8192 32 20 0" "16384 8192 32 20 3" "16384 4096 32 20 0" "16384 4096 32 20 3"; do echo "pk  : $(FRT_STFT_NO_PK16=1 tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; echo "pk16: $(tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; done ) > gpurun_out/${TAG}_stft16384_pk16_ab.txt 2>&1; cat gpurun_out/${TAG}_stft16384_pk16_ab.txt
-echo "== overlap-add bank: launch durations per octave stage (ola_pair_kernel / FRT_OLA_NO_WAVE=1: ola_batch_kernel)"
-bash tools/exp/session_r4p.sh > gpurun_out/${TAG}_ola_stage_times.txt 2>&1; head -12 gpurun_out/${TAG}_ola_stage_times.txt
-echo "== N = 8192: stft_big_kernel (FRT_STFT_NO_PK16H=1) against stft_pk16h_kernel, same session"
-( for cfg in "8192 4096 32 21 0" "8192 4096 32 21 3" "8192 2048 32 21 0" "8192 2048 32 21 3"; do echo "big  : $(FRT_STFT_NO_PK16H=1 tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; echo "pk16h: $(tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; done ) > gpurun_out/${TAG}_stft8192_ab.txt 2>&1; cat gpurun_out/${TAG}_stft8192_ab.txt
-echo "== exact IIR bank: the launches of one call"
-( cd /tmp && rm -rf /tmp/iirt && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/iirt -- python $R/tools/exp/iir_stage_times.py 8 3 22 > /dev/null 2>&1; python $R/tools/exp/iir_stage_times.py --parse /tmp/iirt ) > gpurun_out/${TAG}_iir_launches.txt 2>&1; tail -3 gpurun_out/${TAG}_iir_launches.txt
-echo "== N = 4096 / 2048: stft_big_kernel (FRT_STFT_NO_PK16Q=1 / FRT_STFT_NO_PK16W=1) against stft_pk16q_kernel / stft_pk16w_kernel"
-( for cfg in "4096 2048 16 22 0" "4096 2048 16 22 3" "4096 1024 16 22 0" "4096 1024 16 22 3"; do echo "big  : $(FRT_STFT_NO_PK16Q=1 tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; echo "pk16q: $(tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; done ) > gpurun_out/${TAG}_stft4096_ab.txt 2>&1; cat gpurun_out/${TAG}_stft4096_ab.txt
-( for cfg in "2048 1024 8 24 0" "2048 1024 8 24 3" "2048 512 8 24 0" "2048 512 8 24 3"; do echo "big  : $(FRT_STFT_NO_PK16W=1 tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; echo "pk16w: $(tools/bin/stft_selftest bench $cfg 0 40 | tail -1 | cut -c1-160)"; done ) > gpurun_out/${TAG}_stft2048_ab.txt 2>&1; cat gpurun_out/${TAG}_stft2048_ab.txt
+echo "== exact IIR bank: the launches of one call (27 bands, chunks of 1024; 216 bands)"
+( cd /tmp && rm -rf /tmp/iirt && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/iirt -- python $R/tools/exp/iir_stage_times.py 8 3 22 > /dev/null 2>&1; python $R/tools/exp/iir_stage_times.py --parse /tmp/iirt ) > gpurun_out/${TAG}_iir_launches_call.txt 2>&1; tail -3 gpurun_out/${TAG}_iir_launches_call.txt
+( cd /tmp && rm -rf /tmp/iirt24 && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/iirt24 -- python $R/tools/exp/iir_stage_times.py 8 24 20 512 > /dev/null 2>&1; python $R/tools/exp/iir_stage_times.py --parse /tmp/iirt24 ) > gpurun_out/${TAG}_iir_launches_call_bpo24.txt 2>&1; tail -3 gpurun_out/${TAG}_iir_launches_call_bpo24.txt
+echo "== overlap-add bank: the launches of one call (27 bands; 216 bands)"
+for cfg in "8 3 22" "8 24 20"; do
+  tag=$(echo $cfg | tr ' ' '_'); OUT=/tmp/olat_$tag; rm -rf $OUT
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python $R/tools/exp/fir_only.py $cfg 6 > /dev/null 2>&1 )
+  python - $OUT <<'PY' > gpurun_out/${TAG}_ola_launches_$tag.txt
+import csv, glob, sys
+rows=[]
+for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-34:], int(r["Grid_Size_X"])//int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"])))
+rows.sort()
+ends=[i for i,r in enumerate(rows) if "energy_finish" in r[2]]
+a,b=ends[-2]+1,ends[-1]+1
+t0=rows[a][0]
+for s,e,n,gx,gy,gz in rows[a:b]: print(f"{(s-t0)/1e3:8.1f} us  {n:34s} grid {gx:6d} x {gy:3d} x {gz:3d}  {(e-s)/1e3:7.1f} us")
+print(f"{b-a} launches, span {(rows[b-1][1]-t0)/1e3:.1f} us")
+PY
+  tail -2 gpurun_out/${TAG}_ola_launches_$tag.txt
+done
