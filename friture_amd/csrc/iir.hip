@@ -794,8 +794,7 @@ __host__ __device__ inline size_t zs_mfma_index(int k, int row, int row_tiles) {
 #define FRT_ZS_UNROLL 2
 #endif
 
-// kZsTiles row tiles (of 16 rows) per workgroup: 2 where the launch's tile range is even (every x value then feeds two MFMAs),
-// 1 for the decimator's single tile and odd ranges
+// kZsTiles row tiles (of 16 rows) per workgroup: 2 (every x value then feeds two MFMAs), or 1 for a range of a single tile
 template <int kZsTiles>
 __global__ void __launch_bounds__(64) iir_zero_state_mfma_kernel(const ZeroStateArgs a) {
     const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
@@ -841,7 +840,10 @@ __global__ void __launch_bounds__(64) iir_zero_state_mfma_kernel(const ZeroState
             }
             const size_t kblock = (size_t)(k0 >> 4) + (in_slice ? kb + u : 0);
 #pragma unroll
-            for (int rt = 0; rt < kZsTiles; ++rt) av[u][rt] = tm[((kblock * row_tiles + rt0 + rt) * 4 + g) * 16 + j];
+            for (int rt = 0; rt < kZsTiles; ++rt) {
+                const int tile = rt0 + rt < row_tiles ? rt0 + rt : row_tiles - 1;      // (an odd range's last workgroup: its second tile is not stored)
+                av[u][rt] = tm[((kblock * row_tiles + tile) * 4 + g) * 16 + j];
+            }
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u)
@@ -857,7 +859,7 @@ __global__ void __launch_bounds__(64) iir_zero_state_mfma_kernel(const ZeroState
     for (int rt = 0; rt < kZsTiles; ++rt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            if (rt0 + rt >= a.rt_base + a.rt_count) continue;              // (tile ranges are whole multiples of kZsTiles: never taken)
+            if (rt0 + rt >= a.rt_base + a.rt_count) continue;              // the second tile of an odd range's last workgroup
             const int m = a.rowmap[(rt0 + rt) * 16 + 4 * v + g];
             if (m >= 0) out[(((size_t)c * a.nfilt + (m >> 4)) * a.nchunks + q) * kStates + (m & 15)] = acc[rt][v];
         }
@@ -1723,8 +1725,10 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
             auto front = [&](hipStream_t st, int t0, int nt, int f0, int nf) {
                 z.rt_base = t0;
                 z.rt_count = nt;
-                if (nt % 2 == 0)
-                    hipLaunchKernelGGL(iir_zero_state_mfma_kernel<2>, dim3((unsigned)colwaves, n_slices, nt / 2), dim3(64), 0, st, z);
+                // two row tiles per workgroup (every sample feeds two MFMAs) unless the range is a single tile; an odd range's last
+                // workgroup computes one tile it does not store (216 bands: 7 tiles, 4 workgroups along z as in round 4)
+                if (nt >= 2)
+                    hipLaunchKernelGGL(iir_zero_state_mfma_kernel<2>, dim3((unsigned)colwaves, n_slices, (nt + 1) / 2), dim3(64), 0, st, z);
                 else
                     hipLaunchKernelGGL(iir_zero_state_mfma_kernel<1>, dim3((unsigned)colwaves, n_slices, nt), dim3(64), 0, st, z);
                 if (n_slices > 1) {
