@@ -58,7 +58,7 @@ int option(Option o);         // -1 = not set: the shape rule decides
 // (tools/exp/build_variant.sh); in the shipped library the switch and the code behind it fold away at compile time.
 #ifdef FRT_EXPERIMENTS
 inline const char* exp_env(const char* name) { return getenv(name); }
-inline int exp_int(const char* name, int otherwise) { const char* e = getenv(name); return e ? atoi(e) : otherwise; }
+inline int exp_int(const char* name, int otherwise) { const char* e = exp_env(name); return e ? atoi(e) : otherwise; }
 #else
 constexpr const char* exp_env(const char*) { return nullptr; }
 constexpr int exp_int(const char*, int otherwise) { return otherwise; }

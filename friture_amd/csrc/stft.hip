@@ -453,7 +453,7 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
     a.rising = h->spec_max > h->spec_min;
     a.eps_free = h->eps_free;
 #ifdef FRT_ABLATE
-    a.ablate = getenv("FRT_ABLATE") ? atoi(getenv("FRT_ABLATE")) : 0;
+    a.ablate = exp_int("FRT_ABLATE", 0);        // (-DFRT_ABLATE builds are experiment builds: add -DFRT_EXPERIMENTS)
 #endif
 
     // slots of 2*TPF samples a hop advances; the register-shift kernels need hop = s*N/8, s in {2,4}

@@ -31,9 +31,8 @@ def test_runtime_entry_points_do_not_read_the_reference_checkout():
 
 
 def test_the_library_never_reads_the_environment():
-    """No getenv in the shipped library: the only one sits inside the -DFRT_EXPERIMENTS helper of common.h (tools/exp builds) and
-    one inside an #ifdef FRT_ABLATE block; path selection for tests goes through frt_set_option.  The built library must not
-    import getenv at all."""
+    """No getenv in the shipped library: the only one sits inside the -DFRT_EXPERIMENTS helper of common.h (tools/exp builds); path
+    selection for tests goes through frt_set_option.  The built library must not import getenv at all."""
     import subprocess
     hits = []
     for p in product_sources():
@@ -41,7 +40,7 @@ def test_the_library_never_reads_the_environment():
             for n, line in enumerate(p.read_text().splitlines(), 1):
                 if re.search(r"\bgetenv\s*\(", line) and not line.lstrip().startswith("//"):
                     hits.append(f"{p.name}:{n}")
-    assert len(hits) <= 2 and all(h.startswith(("common.h", "stft.hip")) for h in hits), hits
+    assert len(hits) == 1 and hits[0].startswith("common.h"), hits
     from friture_amd import _lib
     syms = subprocess.run(["nm", "-D", "--undefined-only", str(_lib.LIB_PATH)], capture_output=True, text=True).stdout
     assert not re.search(r"\b(secure_)?getenv\b", syms), "libfriture_hip.so imports getenv"
