@@ -8,6 +8,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 d = json.loads((ROOT / "profiles" / "r05_bench_full.json").read_text())
 packed = json.loads((ROOT / "profiles" / "r05_bench_packed.json").read_text())
+traffic = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())["hbm_bytes_per_launch"]      # the PMC passes of the same session
 L = d["legs"]
 
 
@@ -27,7 +28,7 @@ r = d["roofline"]
 rows = [
     ("**headline** configs[1], float32, colour, split rows", f"**{e(d['value'], 4)} spectra/s**, {d['ms_per_step']:.4f} ms",
      f"**{r['frac']:.3f}** of 8 TB/s (kernel {r['kernel_ms']:.4f} ms; packed rows, same session: {packed['roofline']['frac']:.3f}); traffic "
-     f"{(r.get('traffic') or 0) / 1e6:.1f} MB vs {r['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic", "0.588",
+     f"{traffic / 1e6:.1f} MB vs {r['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic", "0.588",
      f"{e(d['cpu_baseline']['value'], 2)} / {e(d['cpu_baseline']['all_cores']['value'], 2)} spectra/s"),
     ("same batches, PSD kind", e(d["psd_output"]["spectra_per_s"], 4), f"{d['psd_output']['frac_of_hbm_peak']:.3f}", "0.608", ""),
     ("`configs1_f64_psd` / `_image` (split rows)", f"{e(L['configs1_f64_psd']['value'])} / {e(L['configs1_f64_image']['value'])}",
