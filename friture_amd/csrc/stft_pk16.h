@@ -38,6 +38,13 @@ __global__ void __launch_bounds__(Pk16Plan::BLOCK, 2) stft_pk16_kernel(const Stf
     constexpr int M = P::M, MS = P::MS, RS = P::RS;
     constexpr int PH = 16 / HS;                                     // frames until the ring is back in phase
     constexpr bool IMAGE = KIND >= 3, EPS_FREE = KIND == 4;
+#if defined(FRT_PKS_NT_BOTH)          // experiment builds: both hops / neither
+    constexpr bool kNtRows = true;
+#elif defined(FRT_PKS_NT_NONE)
+    constexpr bool kNtRows = false;
+#else
+    constexpr bool kNtRows = HS == 4;                               // non-temporal row stores at hop N/4 (see the stores)
+#endif
     __shared__ __attribute__((aligned(1024))) char smem[P::LDS_BYTES];
     const uint32_t sm = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;      // LDS byte address of the block
     uint32_t* const lut_lds = (uint32_t*)(smem + P::LUT_OFF);
@@ -268,8 +275,16 @@ __global__ void __launch_bounds__(Pk16Plan::BLOCK, 2) stft_pk16_kernel(const Stf
             const float* plo = pl[gq];
             const float* phi = phh[gq];
             if constexpr (KIND == 0) {
-                *(pk_f4*)(row + klo) = pk_f4{plo[0], plo[1], plo[2], plo[3]};
-                *(pk_f4*)(row + khi - 3) = pk_f4{phi[3], phi[2], phi[1], phi[0]};
+                // hop N/4 (the widgets' default overlap): a frame writes twice the bytes it reads, and the rows leave non-temporally
+                // (measured, profiles/r05_stft16384_nt.txt: 0.121-0.123 -> 0.115-0.116 ms, colour 0.148 -> 0.141; at hop N/2 the same
+                // hint costs 6-10 %: plain stores there)
+                if constexpr (kNtRows) {
+                    __builtin_nontemporal_store(pk_f4{plo[0], plo[1], plo[2], plo[3]}, (pk_f4*)(row + klo));
+                    __builtin_nontemporal_store(pk_f4{phi[3], phi[2], phi[1], phi[0]}, (pk_f4*)(row + khi - 3));
+                } else {
+                    *(pk_f4*)(row + klo) = pk_f4{plo[0], plo[1], plo[2], plo[3]};
+                    *(pk_f4*)(row + khi - 3) = pk_f4{phi[3], phi[2], phi[1], phi[0]};
+                }
             } else if constexpr (IMAGE) {
                 float vv[8];
                 uint32_t cc[8];
@@ -292,8 +307,13 @@ __global__ void __launch_bounds__(Pk16Plan::BLOCK, 2) stft_pk16_kernel(const Stf
                         if (near_edge) cc[e] = lut_lds[n];
                     }
                 }
-                *(pk_u4*)(prow + klo) = pk_u4{cc[0], cc[1], cc[2], cc[3]};
-                *(pk_u4*)(prow + khi - 3) = pk_u4{cc[7], cc[6], cc[5], cc[4]};
+                if constexpr (kNtRows) {
+                    __builtin_nontemporal_store(pk_u4{cc[0], cc[1], cc[2], cc[3]}, (pk_u4*)(prow + klo));
+                    __builtin_nontemporal_store(pk_u4{cc[7], cc[6], cc[5], cc[4]}, (pk_u4*)(prow + khi - 3));
+                } else {
+                    *(pk_u4*)(prow + klo) = pk_u4{cc[0], cc[1], cc[2], cc[3]};
+                    *(pk_u4*)(prow + khi - 3) = pk_u4{cc[7], cc[6], cc[5], cc[4]};
+                }
             } else {
                 *(pk_f4*)(row + klo) = pk_f4{finish(plo[0], wgr[8 * gq]), finish(plo[1], wgr[8 * gq + 1]), finish(plo[2], wgr[8 * gq + 2]),
                                              finish(plo[3], wgr[8 * gq + 3])};

@@ -31,6 +31,13 @@ __global__ void __launch_bounds__(Pk16wPlan::BLOCK, 2) stft_pk16w_kernel(const S
     constexpr int M = P::M, MS = P::MS, RS = P::RS;
     constexpr int PH = 16 / HS;                                     // frames until the ring is back in phase
     constexpr bool IMAGE = KIND >= 3, EPS_FREE = KIND == 4;
+#if defined(FRT_PKS_NT_BOTH)
+    constexpr bool kNtRows = true;
+#elif defined(FRT_PKS_NT_NONE)
+    constexpr bool kNtRows = false;
+#else
+    constexpr bool kNtRows = HS == 4;                               // non-temporal row stores at hop N/4 (stft_pk16.h; profiles/r05_stft16384_nt.txt)
+#endif
     __shared__ __attribute__((aligned(1024))) char smem[P::LDS_BYTES];
     const uint32_t sm = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;      // LDS byte address of the block
     uint32_t* const lut_lds = (uint32_t*)(smem + P::LUT_OFF);
@@ -226,8 +233,8 @@ __global__ void __launch_bounds__(Pk16wPlan::BLOCK, 2) stft_pk16w_kernel(const S
             }
             const int k0 = 4 * t + (M / 4) * g2;
             if constexpr (KIND == 0) {
-                *(pk_f4*)(row + k0) = pk_f4{plo[0], plo[1], plo[2], plo[3]};
-                *(pk_f4*)(row + M - k0 - 3) = pk_f4{phi[3], phi[2], phi[1], phi[0]};
+                pk_row_store<kNtRows>((pk_f4*)(row + k0), pk_f4{plo[0], plo[1], plo[2], plo[3]});
+                pk_row_store<kNtRows>((pk_f4*)(row + M - k0 - 3), pk_f4{phi[3], phi[2], phi[1], phi[0]});
             } else if constexpr (IMAGE) {
                 float vv[8];
                 uint32_t cc[8];
@@ -250,8 +257,8 @@ __global__ void __launch_bounds__(Pk16wPlan::BLOCK, 2) stft_pk16w_kernel(const S
                         if (near_edge) cc[e] = lut_lds[n];
                     }
                 }
-                *(pk_u4*)(prow + k0) = pk_u4{cc[0], cc[1], cc[2], cc[3]};
-                *(pk_u4*)(prow + M - k0 - 3) = pk_u4{cc[7], cc[6], cc[5], cc[4]};
+                pk_row_store<kNtRows>((pk_u4*)(prow + k0), pk_u4{cc[0], cc[1], cc[2], cc[3]});
+                pk_row_store<kNtRows>((pk_u4*)(prow + M - k0 - 3), pk_u4{cc[7], cc[6], cc[5], cc[4]});
             } else {
                 *(pk_f4*)(row + k0) = pk_f4{finish(plo[0], wgr[4 * g2]), finish(plo[1], wgr[4 * g2 + 1]), finish(plo[2], wgr[4 * g2 + 2]),
                                             finish(plo[3], wgr[4 * g2 + 3])};
