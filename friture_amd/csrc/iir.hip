@@ -415,13 +415,22 @@ static_assert(kLanePrefetch == 1 || kLanePrefetch == 2 || kLanePrefetch == 4, "p
 constexpr int kLaneBands = FRT_LANE_BANDS;      // measured: one band filter per wavefront re-reads the samples per filter and is 15-70 % slower (bpo 3 / 24)
 
 // (bx, lane): the wavefront's index along the launch's first axis — channel x 64-chunk group — and the lane inside it
-template <int NF, int ORD, bool DEC, bool F32>
-__device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0, int bx, int lane) {
-    const int nblk = (a.nchunks + 63) / 64;
+// LPC (lanes per chunk) > 1: the band filters of a group on LPC neighbouring lanes of ONE chunk, a filter per lane (NF = 1; `nlive`
+// of them exist), 64 / LPC chunks per wavefront — a third of the dependent float64 instructions per sample and wave and three
+// times the wavefronts of the filter-group-per-lane form (iir_lane_split_kernel).  The lanes of a chunk read the same samples.
+template <int NF, int ORD, bool DEC, bool F32, int LPC = 1>
+__device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_group, int bx, int lane, int nlive = NF) {
+    static_assert(LPC == 1 || (NF == 1 && !DEC), "a filter per lane");
+    constexpr int CPW = 64 / LPC;                               // chunks per wavefront
+    const int cl = LPC == 1 ? lane : (lane * 43) >> 7;          // lane / 3 for lane < 64 (LPC is 1 or 3)
+    static_assert(LPC == 1 || LPC == 3, "lane / LPC by multiply-shift");
+    const int ml = lane - cl * LPC;                             // the lane's filter inside the group
+    const int nblk = (a.nchunks + CPW - 1) / CPW;
     const int c = bx / nblk;
-    const int q = (bx - c * nblk) * 64 + lane;
-    const bool valid = q < a.nchunks;
-    const int qc = valid ? q : a.nchunks - 1;                  // lanes past the end shadow the last chunk, store nothing
+    const int q = (bx - c * nblk) * CPW + cl;
+    const bool valid = q < a.nchunks && cl < CPW && ml < nlive;
+    const int qc = (q < a.nchunks && cl < CPW) ? q : a.nchunks - 1;      // lanes past the end shadow the last chunk, store nothing
+    const int f0 = f0_group + (LPC > 1 && ml < nlive ? ml : 0);          // (per lane when LPC > 1)
     const int L = a.chunk;
 
     // initial state of every filter of the group: formed by iir_scan_kernel (zero-start prefix + (A^L)^i x the scan row's true
@@ -429,6 +438,7 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0, int
     // round trips, most of what a low-rate stage's launch lasted.
     static_assert(ORD % 2 == 0, "states are read as pairs of doubles");
     double z[NF][ORD], acc[NF], alpha[NF], decay[NF];
+    int bandv[NF];
 #pragma unroll
     for (int m = 0; m < NF; ++m) {
         const int f = f0 + m;
@@ -439,7 +449,10 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0, int
             z[m][t] = iv.x;
             z[m][t + 1] = iv.y;
         }
-        const int band = a.band_index[f];
+        // (a stage's band filters carry consecutive band indices: a lane's own is the group's first plus its offset, no
+        // lane-indexed read of the argument block)
+        const int band = LPC > 1 ? a.band_index[f0_group] + (f - f0_group) : a.band_index[f];
+        bandv[m] = band;
         alpha[m] = (!DEC && band >= 0) ? a.alpha[band] : 0.0;
         decay[m] = 1.0 - alpha[m];
         acc[m] = 0.0;
@@ -523,7 +536,7 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0, int
                 const long long blk = ((s0 + k) >> a.eblock_shift) * a.eblock_mul;      // first entry of the block axis this block spans
 #pragma unroll
                 for (int m = 0; m < NF; ++m) {
-                    const int band = a.band_index[f0 + m];
+                    const int band = bandv[m];
                     if (band >= 0) {
                         double* e = a.eblock + ((size_t)c * a.nblocks + blk) * a.nbands + band;
                         for (int i = 0; i + 1 < a.eblock_mul; ++i) e[(size_t)i * a.nbands] = 0.0;
@@ -556,6 +569,118 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0, int
         for (int m = 0; m < NF; ++m)
 #pragma unroll
             for (int st = 0; st < ORD; ++st) a.state[((size_t)c * a.nfilt + f0 + m) * kStates + st] = z[m][st];
+    }
+}
+
+// The decimator of a chunk on a PAIR of lanes: lane A (even) owns states 0..5, lane B (odd) states 6..11 of the 12th-order DF2T
+// recurrence  y = b0 x + z0;  z_s <- b_{s+1} x - a_{s+1} y + z_{s+1}  (lfilter.py:131-139, re-associated like the rest of the
+// time-parallel mode).  Per sample: A forms y, a quad permute hands it to B, another hands B's z6 (its old value) to A for z5;
+// then both lanes update their six states — 13 multiply-adds + 5 moves per lane instead of 25 multiply-adds on one, and the
+// dependent chain from a sample's y to the next is  y -> permute -> z0 -> y  whatever the order.  32 chunks per wavefront.
+template <int CTRL>
+__device__ __forceinline__ double quad_perm_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <bool F32>
+__device__ __forceinline__ void iir_lane_dec_pair_body(const IirStageArgs& a, int bx, int lane) {
+    constexpr int H = 6, CPW = 32;
+    const int f = a.dec_filter;
+    const int half = lane & 1, cl = lane >> 1;
+    const int nblk = (a.nchunks + CPW - 1) / CPW;
+    const int c = bx / nblk;
+    const int q = (bx - c * nblk) * CPW + cl;
+    const bool valid = q < a.nchunks;
+    const int qc = valid ? q : a.nchunks - 1;
+    const int L = a.chunk;
+    double u[H];
+    {
+        const double* init = a.chunk_init + (((size_t)c * a.nfilt + f) * a.nchunks + qc) * kStates + H * half;
+#pragma unroll
+        for (int t = 0; t < H; t += 2) {
+            const double2 iv = *(const double2*)(init + t);
+            u[t] = iv.x;
+            u[t + 1] = iv.y;
+        }
+    }
+    // this lane's coefficients: b[H half + s + 1], -a[H half + s + 1] for its states s = 0..5, and b0 (lane A forms y)
+    // (through the constant address space like the band lanes' tables: plain global loads would be re-read behind every store)
+    typedef const double __attribute__((address_space(4))) * ktable;
+    const ktable tab = (ktable)(uintptr_t)(a.coef + (size_t)f * kCoefStride);
+    const double b0 = tab[0];
+    double cb[H], ca[H];
+#pragma unroll
+    for (int sidx = 0; sidx < H; ++sidx) {
+        cb[sidx] = tab[H * half + sidx + 1];
+        ca[sidx] = -tab[kMaxOrder + 1 + H * half + sidx + 1];
+    }
+    const bool is_a = half == 0;
+    const long long s0 = (long long)qc * L;
+    const float* xf = (const float*)a.x + (long long)c * a.x_stride + s0;
+    const double* xd = (const double*)a.x + (long long)c * a.x_stride + s0;
+    double* xn = a.xnext ? a.xnext + (long long)c * a.xnext_stride + (s0 >> 1) : nullptr;
+    constexpr int G = 16;
+    float4 rf[4];
+    double2 rd[8];
+    auto request = [&](int k) {
+        if (F32) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rf[i] = *(const float4*)(xf + k + 4 * i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rd[i] = *(const double2*)(xd + k + 2 * i);
+        }
+    };
+    request(0);
+    for (int k0 = 0; k0 < L; k0 += G) {
+        double xg[G];
+        if (F32) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xg[4 * i] = rf[i].x; xg[4 * i + 1] = rf[i].y; xg[4 * i + 2] = rf[i].z; xg[4 * i + 3] = rf[i].w; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { xg[2 * i] = rd[i].x; xg[2 * i + 1] = rd[i].y; }
+        }
+        if (k0 + G < L) request(k0 + G);
+        double yd[G / 2];
+#pragma unroll
+        for (int t = 0; t < G; ++t) {
+            const double x = xg[t];
+            const double y = quad_perm_f64<0xA0>(__builtin_fma(b0, x, u[0]));      // quad_perm [0,0,2,2]: lane A's value
+            const double z6 = quad_perm_f64<0xF5>(u[0]);                            // quad_perm [1,1,3,3]: lane B's first state, before its update
+            const double tail = is_a ? z6 : 0.0;                                    // z_12 does not exist
+#pragma unroll
+            for (int sidx = 0; sidx + 1 < H; ++sidx) u[sidx] = __builtin_fma(ca[sidx], y, __builtin_fma(cb[sidx], x, u[sidx + 1]));
+            u[H - 1] = __builtin_fma(ca[H - 1], y, __builtin_fma(cb[H - 1], x, tail));
+            if (!(t & 1)) yd[t / 2] = y;                                            // decimate.py:41: samples 0, 2, 4, ...
+        }
+        if (xn && valid && is_a) {
+#pragma unroll
+            for (int i = 0; i < G / 4; ++i) *(double2*)(xn + (k0 >> 1) + 2 * i) = double2{yd[2 * i], yd[2 * i + 1]};
+        }
+    }
+    if (valid && q == a.nchunks - 1) {
+#pragma unroll
+        for (int sidx = 0; sidx < H; ++sidx) a.state[((size_t)c * a.nfilt + f) * kStates + H * half + sidx] = u[sidx];
+    }
+}
+
+// grid (lane-split form): x = n_channels * ceil(nchunks / 21), y = band groups of 3 filters (a filter per lane, three lanes per chunk),
+// then the decimator (a pair of lanes per chunk; its wavefronts are ceil(nchunks / 32) per channel: the others leave at once)
+template <bool F32>
+__global__ void __launch_bounds__(64) iir_lane_split_kernel(const IirStageArgs a, int n_band, int n_band_groups) {
+    const int g = blockIdx.y, lane = threadIdx.x;
+    if (g < n_band_groups) {
+        const int f0 = g * 3, left = n_band - f0;
+        iir_lane_body<1, 4, false, F32, 3>(a, f0, blockIdx.x, lane, left < 3 ? left : 3);
+    } else {
+        const int per_b = (a.nchunks + 20) / 21, per_d = (a.nchunks + 31) / 32;
+        const int c = blockIdx.x / per_b, i = blockIdx.x - c * per_b;
+        if (i >= per_d) return;
+        iir_lane_dec_pair_body<F32>(a, c * per_d + i, lane);
     }
 }
 
@@ -615,6 +740,20 @@ static int launch_iir_lane(const IirStageArgs& a, int n_channels, hipStream_t st
     // the kernel takes its group from the launch's second axis: y < gb are band groups, the rest the decimator
     const int gy = which == kWhichAll ? groups + 1 : which == kWhichBands ? groups : 1;
     const int gb = which == kWhichDec ? 0 : groups;
+    // Few wavefronts (at most one per CU in the form above: the low-rate stages, calls of a few channels): the lane-split form — a band
+    // filter per lane on three lanes of a chunk, the decimator on a pair — has three / two times the wavefronts with a third / two
+    // thirds of the dependent float64 instructions per sample each (iir_lane_split_kernel).  Measured (profiles/r05_iir_lane_split.txt),
+    // it pays only while the chip is mostly idle: with 2.5 wavefronts per SIMD stage 0 of 8 ch x 27 bands takes 168 us against 136 (a
+    // filter per LANE means coefficients in vector registers and permutes in the decimator's chain: more issue slots per sample
+    // in total), but stages 6-8 go 9.8 / 10.0 / 10.6 -> 7.8 / 7.2 / 6.8 us and a 2-channel call 0.43 -> 0.365 ms.
+    if (which == kWhichAll && bx * gy <= (long long)exp_int("FRT_LANE_SPLIT_BELOW", device_cu_count())) {
+        const int sgroups = (n_band + 2) / 3;
+        const long long sbx = (long long)n_channels * ((a.nchunks + 20) / 21);
+        if (a.in_f32) hipLaunchKernelGGL(iir_lane_split_kernel<true>, dim3((unsigned)sbx, sgroups + 1), dim3(64), 0, stream, a, n_band, sgroups);
+        else hipLaunchKernelGGL(iir_lane_split_kernel<false>, dim3((unsigned)sbx, sgroups + 1), dim3(64), 0, stream, a, n_band, sgroups);
+        FRT_HIP_CHECK(hipGetLastError());
+        return FRT_OK;
+    }
     // A launch of at most one wavefront per SIMD with long chunks (the high-rate stages of a few channels: 8 channels x 27 bands at
     // chunks of 1024 are 512 band + 512 decimator wavefronts on 1024 SIMDs): as workgroups of four wavefronts, ONE per compute unit
     // (iir_lane_wg4_kernel) — single-wavefront workgroups end up two to a SIMD on part of the chip while other SIMDs idle, and a
