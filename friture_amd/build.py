@@ -23,7 +23,7 @@ LIB = LIBDIR / "libfriture_hip.so"
 ARCH = "gfx950"
 
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-CXXFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+CXXFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "--offload-compress",
             f"-I{ROOT / 'include'}"]
 
 # translation units with special flags: the exact IIR bank replays the reference's IEEE operation

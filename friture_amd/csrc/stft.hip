@@ -22,6 +22,9 @@
 #include "stft_big.h"
 #include "stft_pk.h"          // packed-arithmetic helpers; round 3's N = 16384 instance itself only in -DFRT_EXPERIMENTS builds
 #include "stft_pk16.h"
+#ifdef FRT_EXPERIMENTS
+#include "stft_pk16r.h"       // N = 16384 with two workgroups per CU: measured 7-25 % slower (profiles/r05_stft16384_two_workgroups.txt)
+#endif
 #include "stft_pk16h.h"
 #include "stft_pk16q.h"
 #include "stft_pk16w.h"
@@ -61,6 +64,24 @@ static int launch_pk16(const StftArgs& a, hipStream_t stream) {
     FRT_HIP_CHECK(hipGetLastError());
     return FRT_OK;
 }
+
+#ifdef FRT_EXPERIMENTS
+// N = 16384 with two workgroups per CU: samples in a register ring, constants streamed (stft_pk16r.h; FRT_STFT_PK16R=1 selects it)
+template <int HS>
+static int launch_pk16r(const StftArgs& a, hipStream_t stream) {
+    const dim3 grid(a.n_groups), block(Pk16rPlan::BLOCK);
+    switch (a.kind) {
+        case FRT_STFT_PSD: hipLaunchKernelGGL((stft_pk16r_kernel<0, HS>), grid, block, 0, stream, a); break;
+        case FRT_STFT_IMAGE:
+            if (a.eps_free) hipLaunchKernelGGL((stft_pk16r_kernel<4, HS>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((stft_pk16r_kernel<3, HS>), grid, block, 0, stream, a);
+            break;
+        default: hipLaunchKernelGGL((stft_pk16r_kernel<1, HS>), grid, block, 0, stream, a); break;
+    }
+    FRT_HIP_CHECK(hipGetLastError());
+    return FRT_OK;
+}
+#endif
 
 // N = 8192: the same structure one size down (stft_pk16h.h)
 template <int HS>
@@ -141,6 +162,12 @@ static int launch_big_one(const StftArgs& a, hipStream_t stream) {
                 }
             }
             if constexpr (LOG2M == Pk16Plan::LOG2M) {
+#ifdef FRT_EXPERIMENTS
+                if (exp_env("FRT_STFT_PK16R")) {
+                    if (half) return launch_pk16r<8>(a, stream);
+                    if (quarter) return launch_pk16r<4>(a, stream);
+                }
+#endif
                 if (!exp_env("FRT_STFT_NO_PK16") && !exp_env("FRT_STFT_NO_PK")) {
                     if (half) return launch_pk16<8>(a, stream);
                     if (quarter) return launch_pk16<4>(a, stream);
@@ -201,6 +228,9 @@ static int launch_shift(const StftArgs& a, int shift, int blocks, hipStream_t st
         if (shift == -1) return launch_one<TIN, T, LOG2M, -1>(a, blocks, stream);
     }
     if (shift < 0) shift = 4;
+    // N >= 2048 comes here only off the 8-byte grid (no register window then) or through a negative run length (tests: the generic
+    // workgroup walk against the radix-16 instances): the slot-reloading instance serves both — no window instances of those sizes
+    if constexpr (LOG2M >= 10) return launch_one<TIN, T, LOG2M, 0>(a, blocks, stream);
     if constexpr (sizeof(T) == 4) {
         if (shift == 2) return launch_one<TIN, T, LOG2M, 2>(a, blocks, stream);
     }
@@ -498,7 +528,9 @@ static int stft_launch(frt_stft* h, int kind, const void* d_x, int64_t x_stride,
             // Measured (run sweep with tools/stft_selftest bench, one frame per workgroup): 8 frames is the plateau at
             // N = 4096 / 8192, 16 at N = 16384; N = 2048 keeps gaining up to 32 (+6 % over 8) provided two full
             // rounds of groups remain.
-            const int resident = h->log2m >= 13 ? 1 : h->log2m == 12 ? 2 : h->log2m == 11 ? 4 : 8;   // groups per CU
+            // (N = 16384: one; two for -DFRT_EXPERIMENTS runs of stft_pk16r_kernel)
+            const bool two_per_cu = h->precision == 32 && exp_env("FRT_STFT_PK16R") != nullptr;
+            const int resident = h->log2m >= 13 ? (two_per_cu ? 2 : 1) : h->log2m == 12 ? 2 : h->log2m == 11 ? 4 : 8;   // groups per CU
             const long long need = (long long)device_cu_count() * resident;
             auto groups = [&](int r) { return ((F + r - 1) / r) * h->n_channels; };
             brun = h->log2m >= 10 ? 16 : 8;
