@@ -44,3 +44,14 @@ def test_the_library_never_reads_the_environment():
     from friture_amd import _lib
     syms = subprocess.run(["nm", "-D", "--undefined-only", str(_lib.LIB_PATH)], capture_output=True, text=True).stdout
     assert not re.search(r"\b(secure_)?getenv\b", syms), "libfriture_hip.so imports getenv"
+
+
+def test_library_size_and_experiment_kernels_stay_out():
+    """The shipped library carries no superseded or experimental kernel generation (those compile only with -DFRT_EXPERIMENTS:
+    stft_pk_kernel, stft_pk16r_kernel, ola_batch_kernel) and stays below 2.5 MB (device code compressed)."""
+    import subprocess
+    from friture_amd import _lib
+    assert _lib.LIB_PATH.stat().st_size < 2_500_000, _lib.LIB_PATH.stat().st_size
+    syms = subprocess.run(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], capture_output=True, text=True).stdout
+    for name in ("stft_pk_kernel", "stft_pk16r_kernel", "ola_batch_kernel"):
+        assert name not in syms, name
