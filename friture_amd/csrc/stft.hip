@@ -25,9 +25,7 @@
 #ifdef FRT_EXPERIMENTS
 #include "stft_pk16r.h"       // N = 16384 with two workgroups per CU: measured 7-25 % slower (profiles/r05_stft16384_two_workgroups.txt)
 #endif
-#include "stft_pk16h.h"
-#include "stft_pk16q.h"
-#include "stft_pk16w.h"
+#include "stft_pk16s.h"       // N = 8192 / 4096 / 2048: one template over the size
 
 namespace frt {
 
@@ -83,49 +81,17 @@ static int launch_pk16r(const StftArgs& a, hipStream_t stream) {
 }
 #endif
 
-// N = 8192: the same structure one size down (stft_pk16h.h)
-template <int HS>
-static int launch_pk16h(const StftArgs& a, hipStream_t stream) {
-    const dim3 grid(a.n_groups), block(Pk16hPlan::BLOCK);
+// N = 8192 / 4096 / 2048: the same structure one, two, three sizes down (stft_pk16s.h)
+template <int LOG2M, int HS>
+static int launch_pk16s(const StftArgs& a, hipStream_t stream) {
+    const dim3 grid(a.n_groups), block(Pk16sPlan<LOG2M>::BLOCK);
     switch (a.kind) {
-        case FRT_STFT_PSD: hipLaunchKernelGGL((stft_pk16h_kernel<0, HS>), grid, block, 0, stream, a); break;
+        case FRT_STFT_PSD: hipLaunchKernelGGL((stft_pk16s_kernel<LOG2M, 0, HS>), grid, block, 0, stream, a); break;
         case FRT_STFT_IMAGE:
-            if (a.eps_free) hipLaunchKernelGGL((stft_pk16h_kernel<4, HS>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((stft_pk16h_kernel<3, HS>), grid, block, 0, stream, a);
+            if (a.eps_free) hipLaunchKernelGGL((stft_pk16s_kernel<LOG2M, 4, HS>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((stft_pk16s_kernel<LOG2M, 3, HS>), grid, block, 0, stream, a);
             break;
-        default: hipLaunchKernelGGL((stft_pk16h_kernel<1, HS>), grid, block, 0, stream, a); break;
-    }
-    FRT_HIP_CHECK(hipGetLastError());
-    return FRT_OK;
-}
-
-// N = 4096: one more size down (stft_pk16q.h)
-template <int HS>
-static int launch_pk16q(const StftArgs& a, hipStream_t stream) {
-    const dim3 grid(a.n_groups), block(Pk16qPlan::BLOCK);
-    switch (a.kind) {
-        case FRT_STFT_PSD: hipLaunchKernelGGL((stft_pk16q_kernel<0, HS>), grid, block, 0, stream, a); break;
-        case FRT_STFT_IMAGE:
-            if (a.eps_free) hipLaunchKernelGGL((stft_pk16q_kernel<4, HS>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((stft_pk16q_kernel<3, HS>), grid, block, 0, stream, a);
-            break;
-        default: hipLaunchKernelGGL((stft_pk16q_kernel<1, HS>), grid, block, 0, stream, a); break;
-    }
-    FRT_HIP_CHECK(hipGetLastError());
-    return FRT_OK;
-}
-
-// N = 2048: one wavefront per frame (stft_pk16w.h)
-template <int HS>
-static int launch_pk16w(const StftArgs& a, hipStream_t stream) {
-    const dim3 grid(a.n_groups), block(Pk16wPlan::BLOCK);
-    switch (a.kind) {
-        case FRT_STFT_PSD: hipLaunchKernelGGL((stft_pk16w_kernel<0, HS>), grid, block, 0, stream, a); break;
-        case FRT_STFT_IMAGE:
-            if (a.eps_free) hipLaunchKernelGGL((stft_pk16w_kernel<4, HS>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((stft_pk16w_kernel<3, HS>), grid, block, 0, stream, a);
-            break;
-        default: hipLaunchKernelGGL((stft_pk16w_kernel<1, HS>), grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL((stft_pk16s_kernel<LOG2M, 1, HS>), grid, block, 0, stream, a); break;
     }
     FRT_HIP_CHECK(hipGetLastError());
     return FRT_OK;
@@ -143,22 +109,10 @@ static int launch_big_one(const StftArgs& a, hipStream_t stream) {
     if constexpr (sizeof(T) == 4) {
         if (aligned16 && !exp_env("FRT_STFT_NO_DMA")) {
             const bool half = a.hop == B::M, quarter = a.hop == B::M / 2;        // hop N/2, N/4
-            if constexpr (LOG2M == Pk16wPlan::LOG2M) {
-                if (!exp_env("FRT_STFT_NO_PK16W")) {
-                    if (half) return launch_pk16w<8>(a, stream);
-                    if (quarter) return launch_pk16w<4>(a, stream);
-                }
-            }
-            if constexpr (LOG2M == Pk16qPlan::LOG2M) {
-                if (!exp_env("FRT_STFT_NO_PK16Q")) {
-                    if (half) return launch_pk16q<8>(a, stream);
-                    if (quarter) return launch_pk16q<4>(a, stream);
-                }
-            }
-            if constexpr (LOG2M == Pk16hPlan::LOG2M) {
-                if (!exp_env("FRT_STFT_NO_PK16H")) {
-                    if (half) return launch_pk16h<8>(a, stream);
-                    if (quarter) return launch_pk16h<4>(a, stream);
+            if constexpr (LOG2M >= 10 && LOG2M <= 12) {
+                if (!exp_env(LOG2M == 10 ? "FRT_STFT_NO_PK16W" : LOG2M == 11 ? "FRT_STFT_NO_PK16Q" : "FRT_STFT_NO_PK16H")) {
+                    if (half) return launch_pk16s<LOG2M, 8>(a, stream);
+                    if (quarter) return launch_pk16s<LOG2M, 4>(a, stream);
                 }
             }
             if constexpr (LOG2M == Pk16Plan::LOG2M) {

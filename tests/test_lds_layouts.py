@@ -39,9 +39,11 @@ def test_exchange_layouts_are_conflict_free(kernel):
 
 def test_source_and_model_agree_on_the_constants():
     """the strides and offsets the model uses appear in the sources (a changed layout must change the model)"""
-    src = {n: (ROOT / "friture_amd" / "csrc" / n).read_text() for n in ("stft_pk16.h", "stft_pk16h.h", "stft_pk16q.h", "stft_pk16w.h", "ola_wave.h")}
+    src = {n: (ROOT / "friture_amd" / "csrc" / n).read_text() for n in ("stft_pk16.h", "stft_pk16s.h", "ola_wave.h")}
     assert "RS = MS + 34" in src["stft_pk16.h"] and "(lv + 272 * lu) * 8" in src["stft_pk16.h"] and "(17 * lv + 272 * lu) * 8" in src["stft_pk16.h"]
-    assert "RS = MS + 34" in src["stft_pk16h.h"] and "wave + 4 * (qw >> 1) + 8 * (qw & 1)" in src["stft_pk16h.h"] and "(17 * l4) * 8" in src["stft_pk16h.h"]
-    assert "RS * reg + 8 * ((reg + (reg >> 2)) & 3)" in src["stft_pk16q.h"] and "(l3 ^ c) * 8u" in src["stft_pk16q.h"]
-    assert "RS * reg + 4 * ((reg & 5) | ((((reg >> 1) ^ (reg >> 3)) & 1) << 1))" in src["stft_pk16w.h"]
+    # the size template (N = 8192 / 4096 / 2048): region stride and bases per lane count, the exchange maps
+    s = src["stft_pk16s.h"]
+    assert "RS = L == 16 ? MS + 34 : MS + 32" in s and "wave + 4 * (qw >> 1) + 8 * (qw & 1)" in s and "(17 * lp) * 8" in s
+    assert "RS * reg + 8 * ((reg + (reg >> 2)) & 3)" in s and "(lp ^ c) * 8u" in s
+    assert "RS * reg + 4 * ((reg & 5) | ((((reg >> 1) ^ (reg >> 3)) & 1) << 1))" in s
     assert "(t & 7) + 128 * (t >> 3)" in src["ola_wave.h"] and "(k2h ^ b) + 128 * k2l + 256 * b" in src["ola_wave.h"] and "(t ^ bb) + 128 * (e + 2 * bb)" in src["ola_wave.h"]
