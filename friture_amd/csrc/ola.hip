@@ -263,7 +263,7 @@ int frt_ola_filter(frt_octbank* h, const double* d_x, int n, double* d_y, int64_
 //   * per filter of its group: Y = X H_f, inverse, then band output / decimated stage output / block energies straight
 //     from LDS; the workgroup holding the end of the stage also writes the new tails (its window ends in 511 + zeros).
 // 4096 = 3072 + 511 + 511 + 2: the circular convolution never wraps into a sample that is used.
-constexpr int kObF = 4096, kObM = kObF / 2, kObL = 3072, kObThreads = 256;
+[[maybe_unused]] constexpr int kObF = 4096, kObM = kObF / 2, kObL = 3072, kObThreads = 256;      // (ola_batch_kernel: -DFRT_EXPERIMENTS builds)
 
 struct OlaBatchArgs {
     const void* x;             // [C][x_stride] stage input: float (x_f32) or double

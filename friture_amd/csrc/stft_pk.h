@@ -226,11 +226,12 @@ typedef __attribute__((address_space(3))) pk2 lds_pk2;
 __device__ __forceinline__ pk2 lds_rd(uint32_t addr) { return *(const volatile lds_pk2*)addr; }
 __device__ __forceinline__ void lds_wr(uint32_t addr, pk2 v) { *(volatile lds_pk2*)addr = v; }
 
-// a 16-byte row store, non-temporal or plain
+// a 16-byte row store on a 4-byte boundary (rows of N/2 + 1 values), non-temporal or plain
 template <bool NT, typename V>
-__device__ __forceinline__ void pk_row_store(V* p, V v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
+__device__ __forceinline__ void pk_row_store(void* p, V v) {
+    typedef V row_vec __attribute__((aligned(4)));
+    if constexpr (NT) __builtin_nontemporal_store(v, (row_vec*)p);
+    else *(row_vec*)p = v;
 }
 
 #ifdef FRT_EXPERIMENTS   // round 3's kernel: superseded by stft_pk16_kernel (stft_pk16.h), kept for A/B builds of tools/exp

@@ -9,7 +9,7 @@ D=$R/tools/variants/$NAME
 mkdir -p $D
 EXTRA=""
 case $SRC in
-  stft.hip) EXTRA="-fno-slp-vectorize";;
+  stft.hip) EXTRA="-fno-slp-vectorize -Wno-inline-asm";;
   iir.hip|pipeline.hip|pitch.hip|specgram.hip) EXTRA="-ffp-contract=off";;
 esac
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DFRT_EXPERIMENTS -I$R/include $EXTRA "$@" -c $R/friture_amd/csrc/$SRC -o $D/${SRC%.hip}.o
