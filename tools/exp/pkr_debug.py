@@ -22,9 +22,9 @@ for kind in ("psd", "db"):
         A = tables.weighting_db(tables.rfft_frequencies(N), 1e-50)[0]
         e.set_epilogue(A, -140.0, 0.0, np.arange(256, dtype=np.uint32))
     f = getattr(e, kind)
-    os.environ["FRT_STFT_NO_PK16R"] = "1"
+    os.environ.pop("FRT_STFT_PK16R", None)
     ref = f(x).clone()
-    del os.environ["FRT_STFT_NO_PK16R"]
+    os.environ["FRT_STFT_PK16R"] = "1"
     outs = [f(x).clone() for _ in range(3)]
     torch.cuda.synchronize()
     print(kind, "repeatable:", all(torch.equal(outs[0], o) for o in outs[1:]))
