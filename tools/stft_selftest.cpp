@@ -240,8 +240,16 @@ static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int ite
         if (split) CK(frt_stft_run_split(h, kind, xin, T, T, o, o + row_bytes, &nf_g));
         else CK(frt_stft_run(h, kind, xin, T, T, o, &nf_g));
     };
-    HK(hipMalloc(&dx0, in_bytes * sets));
-    HK(hipMalloc(&dout0, out_bytes * sets));
+    // FRT_BENCH_OUT_SHIFT / FRT_BENCH_IN_SHIFT (bytes, multiples of 4096): the buffers start that far into their allocations — where the
+    // rows lie relative to the samples in the memory's channel interleave (tools/exp/session_r5t.sh)
+    const size_t out_shift = getenv("FRT_BENCH_OUT_SHIFT") ? (size_t)atoll(getenv("FRT_BENCH_OUT_SHIFT")) : 0;
+    const size_t in_shift = getenv("FRT_BENCH_IN_SHIFT") ? (size_t)atoll(getenv("FRT_BENCH_IN_SHIFT")) : 0;
+    char *dx_alloc, *dout_alloc;
+    HK(hipMalloc(&dx_alloc, in_bytes * sets + in_shift));
+    HK(hipMalloc(&dout_alloc, out_bytes * sets + out_shift));
+    dx0 = dx_alloc + in_shift;
+    dout0 = dout_alloc + out_shift;
+    if (getenv("FRT_BENCH_SHOW_PTRS")) printf("x %p out %p in_bytes %zu out_bytes %zu\n", (void*)dx0, (void*)dout0, in_bytes, out_bytes);
     for (int k = 0; k < sets; ++k) HK(hipMemcpy(dx0 + in_bytes * k, xhost, x.size() * esz, hipMemcpyHostToDevice));
     char* dx = dx0;
     void* dout = dout0;
@@ -296,8 +304,8 @@ static int do_bench(int N, int hop, int C, int log2T, int kind, int run, int ite
     printf("bench p%d N=%d hop=%d C=%d T=2^%d F=%lld kind=%d run=%d sets=%d %s: %.3f ms/launch  %.4e spectra/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)  [isolated launch: %.3f ms]\n",
            precision, N, hop, C, log2T, (long long)F, kind, run, sets, split ? "split" : "packed", per * 1e3, spectra, bytes / per * 1e-9, bytes / per / 8e12 * 100, iso_ms);
     frt_stft_destroy(h);
-    HK(hipFree(dx0));
-    HK(hipFree(dout0));
+    HK(hipFree(dx_alloc));
+    HK(hipFree(dout_alloc));
     return 0;
 }
 
