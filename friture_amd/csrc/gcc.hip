@@ -45,6 +45,7 @@ struct GccArgs {
     const double* tws;     // tables of the compile-time plan (fft_static.h) when M2 = 6000
     const double* twl;     // [M+1] exp(-2 pi i k / L)
     const double* dw;      // [M+1] complex: rfft(window) — the mean of a signal leaves its spectrum as mean * dw (gcc_phat_kernel)
+    double* psum;          // [pairs][2][R] sums of the samples a forward workgroup loaded (R = 4 with the 3000-point plan), else null
     double* scratch;       // [pairs][4 M + 2] complex
     MixedPlan plan;        // for M2
     int L, M, M2, R;
@@ -81,11 +82,14 @@ __device__ double block_max(double v, double* red) {
 
 // The sub-transform engine: the compile-time plan 6 x 10 x 10 x 10 (fft_static.h) for the default window's 6000 points,
 // the run-time mixed-radix plan for every other 5-smooth length.
-constexpr int kGccStaticM2 = 6000;
+// ST: 0 the run-time plan, 1 the 6000-point plan (R = 2 of the default window), 2 the 3000-point plan 3 x 10 x 10 x 10 (R = 4 of the
+// default window: small batches as launches of their phases — eight forward and four inverse workgroups of 48 KB per pair, three per CU)
+constexpr int kGccStaticM2 = 6000, kGccStaticM2Small = 3000;
 constexpr int kGccSlotsMax = (kGccMaxM2 + kGccThreads - 1) / kGccThreads;      // points of a sub-transform per thread: 6
-template <bool ST>
+template <int ST>
 __device__ __forceinline__ void gcc_fft(cpx<double>* buf, const GccArgs& a, int tid) {
-    if constexpr (ST) static_fft_forward<double, kGccThreads, 6, 10, 10, 10>(buf, (const cpx<double>*)a.tws, tid);
+    if constexpr (ST == 1) static_fft_forward<double, kGccThreads, 6, 10, 10, 10>(buf, (const cpx<double>*)a.tws, tid);
+    else if constexpr (ST == 2) static_fft_forward<double, kGccThreads, 3, 10, 10, 10>(buf, (const cpx<double>*)a.tws, tid);
     else fft_mixed_forward<double, kGccMaxB>(buf, (const cpx<double>*)a.tw2, a.plan, tid, kGccThreads);
 }
 
@@ -139,9 +143,10 @@ __device__ __forceinline__ double gcc_thread_sum(const double* sig, int L, int v
     return acc;
 }
 
-// (x - mean) w of sub-transform r into the LDS array, every thread's (at most six) loads in flight together
+// (x - mean) w of sub-transform r into the LDS array, every thread's (at most six) loads in flight together; returns the sum of the
+// thread's samples x
 template <int R>
-__device__ __forceinline__ void gcc_load_sub(const GccArgs& a, const double* sig, double mean, int r, cpx<double>* buf, int tid) {
+__device__ __forceinline__ double gcc_load_sub(const GccArgs& a, const double* sig, double mean, int r, cpx<double>* buf, int tid) {
     const double2* wn = (const double2*)a.window;
     const int M2 = a.M2;
     double2 x[kGccSlotsMax], w[kGccSlotsMax];
@@ -154,11 +159,14 @@ __device__ __forceinline__ void gcc_load_sub(const GccArgs& a, const double* sig
             w[i] = wn[R * m + r];
         }
     }
+    double acc = 0.0;
 #pragma unroll
     for (int i = 0; i < kGccSlotsMax; ++i) {
         const int m = tid + i * kGccThreads;
+        acc += x[i].x + x[i].y;                             // (slots beyond M2 hold zeros)
         if (m < M2) buf[m] = {(x[i].x - mean) * w[i].x, (x[i].y - mean) * w[i].y};
     }
+    return acc;
 }
 
 // Input of inverse sub-transform r into the LDS array: conj( W_M^{-r k} sum_q W_R^{-r q} Zi[k + q M2] ) (the conjugate turns
@@ -200,7 +208,7 @@ __device__ __forceinline__ void gcc_load_inverse(const cpx<double>* Zi, const cp
 // gives the mean, turns them into (x - mean) w in place, and feeds sub-transform after sub-transform from registers — no
 // second pass over the window for the mean, no re-read per sub-transform.  Returns the mean.
 constexpr int kGccSlots = (kGccMaxM2 + kGccThreads - 1) / kGccThreads;      // 6
-template <int R, bool ST>
+template <int R, int ST>
 __device__ __forceinline__ double gcc_forward_signal(const GccArgs& a, const double* sig, cpx<double>* Sdst, cpx<double>* buf,
                                                     double* red, int tid) {
     static_assert(R <= 2, "register budget");
@@ -305,7 +313,7 @@ __device__ __forceinline__ cpx<double> gcc_zfull_at(const GccSub<R>& sub, const 
     return acc;
 }
 
-template <int R, bool ST>
+template <int R, int ST>
 __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) {
     using C = cpx<double>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -590,7 +598,7 @@ __global__ void __launch_bounds__(kGccThreads) gcc_readout_kernel(const double* 
 // occupies 100 of the 256 CUs.  For batches that do not fill the chip the work of a pair is dealt to more workgroups —
 // 2 R forward sub-transforms, the cross spectrum in slices, R inverse sub-transforms — at the price of four kernel
 // boundaries; every phase reads what the previous one left in the pair's scratch slab (same layout as above).
-template <int R, bool ST>
+template <int R, int ST>
 __global__ void __launch_bounds__(kGccThreads) gcc_fwd_kernel(const GccArgs a, unsigned long long* __restrict__ gmax) {
     using C = cpx<double>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -611,24 +619,50 @@ __global__ void __launch_bounds__(kGccThreads) gcc_fwd_kernel(const GccArgs a, u
     } else {
         const int s = blockIdx.x / R, r = blockIdx.x - s * R;
         const double* sig = (s ? a.d1 : a.d0) + (size_t)pair * L;
-        const double mean = block_sum(gcc_thread_sum(sig, L, a.vec, tid), red) / (double)L;
-        if (tid == 0 && r == 0) {
-            if (a.means) a.means[2 * pair + s] = mean;
-            if (s == 0) gmax[pair] = 0ull;
+        if constexpr (ST == 2) {
+            // every sample is read once over the signal's R workgroups: the transform of x w, and the sum of this workgroup's samples
+            // for the mean, which gcc_cross_kernel removes in the spectrum (mean * rfft(window), as gcc_phat_kernel does)
+            const double part = block_sum(gcc_load_sub<R>(a, sig, 0.0, r, buf, tid), red);
+            if (tid == 0) {
+                a.psum[((size_t)pair * 2 + s) * R + r] = part;
+                if (s == 0 && r == 0) gmax[pair] = 0ull;
+            }
+        } else {
+            const double mean = block_sum(gcc_thread_sum(sig, L, a.vec, tid), red) / (double)L;
+            if (tid == 0 && r == 0) {
+                if (a.means) a.means[2 * pair + s] = mean;
+                if (s == 0) gmax[pair] = 0ull;
+            }
+            gcc_load_sub<R>(a, sig, mean, r, buf, tid);
         }
-        gcc_load_sub<R>(a, sig, mean, r, buf, tid);
         __syncthreads();
         gcc_fft<ST>(buf, a, tid);
         for (int k = tid; k < M2; k += kGccThreads) S[((size_t)s * R + r) * M2 + k] = buf[k];
     }
 }
 
-template <int R>
+// DW: the means were not removed from the samples (gcc_fwd_kernel with the 3000-point plan left the sums of its workgroups' samples):
+// D_s[k] -= mean_s rfft(window)[k] here
+template <int R, bool DW = false>
 __global__ void __launch_bounds__(256) gcc_cross_kernel(const GccArgs a, unsigned long long* __restrict__ gmax) {
     using C = cpx<double>;
     __shared__ double red[4];
     const int pair = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
     const int M = a.M, M2 = a.M2;
+    double mean[2] = {0.0, 0.0};
+    if constexpr (DW) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            double acc = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc += a.psum[((size_t)pair * 2 + s) * R + r];
+            mean[s] = acc / (double)a.L;
+        }
+        if (k == 0 && a.means) {
+            a.means[2 * pair] = mean[0];
+            a.means[2 * pair + 1] = mean[1];
+        }
+    }
     const C* S = (const C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2);
     C* G = (C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2) + 2 * (size_t)M;
     const C* twm = (const C*)a.twm;
@@ -643,6 +677,11 @@ __global__ void __launch_bounds__(256) gcc_cross_kernel(const GccArgs a, unsigne
             const C Za = gcc_zfull<R>(S, twm, s, k, M, M2), Zb = gcc_zfull<R>(S, twm, s, km, M, M2);
             d_lo[s] = gcc_unpack(Za, Zb, tk);
             d_hi[s] = gcc_unpack(Zb, Za, tm);
+            if constexpr (DW) {
+                const C wl = ((const C*)a.dw)[k], wh = ((const C*)a.dw)[M - k];
+                d_lo[s] = {d_lo[s].x - mean[s] * wl.x, d_lo[s].y - mean[s] * wl.y};
+                d_hi[s] = {d_hi[s].x - mean[s] * wh.x, d_hi[s].y - mean[s] * wh.y};
+            }
         }
         const C glo = cmul(cconj(d_lo[0]), d_lo[1]), ghi = cmul(cconj(d_hi[0]), d_hi[1]);
         G[k] = glo;
@@ -687,7 +726,7 @@ __global__ void __launch_bounds__(256) gcc_pack_kernel(const GccArgs a, const un
 // Inverse sub-transform r of a pair; the workgroup leaves the (|value|, first index) of its slice's extremum for
 // gcc_argmax_combine_kernel.  (Folding the R slices in the pair's last workgroup to finish was measured: the device-scope
 // fences that hand-over needs on a multi-XCD part cost 10 us per launch, twice the tiny launch below.)
-template <int R, bool ST>
+template <int R, int ST>
 __global__ void __launch_bounds__(kGccThreads) gcc_inv_kernel(const GccArgs a, double* __restrict__ part_val, int* __restrict__ part_idx) {
     using C = cpx<double>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1058,7 +1097,8 @@ struct frt_gcc {
     MixedPlan plan{};
     hipStream_t stream = nullptr;
     DeviceBuffer window, twm, tw2, tws, twl, dw, scratch;
-    bool static_plan = false;            // M2 = 6000: the compile-time plan of fft_static.h
+    int static_plan = 0;                 // 1: M2 = 6000, 2: M2 = 3000 — the compile-time plans of fft_static.h (gcc_fft)
+    DeviceBuffer psum;
     DeviceBuffer in0, in1, out, argmax, means, old, sm, stats;
     size_t lds_bytes = 0;
     // any-length path (chirp-z): lengths the one-workgroup kernel does not take
@@ -1072,7 +1112,7 @@ extern "C" void frt_gcc_destroy(frt_gcc* h) {
     free_retired_allocations(true);      // blocks parked by growing buffers (common.h); synchronises the device like the releases below
     DeviceBuffer* bufs[] = {&h->window, &h->twm, &h->tw2, &h->tws, &h->twl, &h->dw, &h->scratch, &h->in0, &h->in1,
                             &h->out, &h->argmax, &h->means, &h->old, &h->sm, &h->stats,
-                            &h->chirp, &h->bhat, &h->work, &h->spec, &h->twr, &h->twc, &h->gmax, &h->part_val, &h->part_idx, &h->prof};
+                            &h->chirp, &h->bhat, &h->work, &h->spec, &h->twr, &h->twc, &h->gmax, &h->part_val, &h->part_idx, &h->prof, &h->psum};
     for (auto* b : bufs) b->release();
     delete h;
 }
@@ -1092,6 +1132,14 @@ extern "C" int frt_gcc_create(frt_gcc** out, int length, int n_pairs) {
         const int want = atoi(fr);
         while (R < want && R < kGccMaxR && h->M % (2 * R) == 0) R *= 2;
     }
+    // The default window (24000 samples: M = 12000) in batches whose eight forward workgroups per pair find a CU each (32 pairs on 256
+    // CUs; the widget's one pair): four sub-transforms of 3000 points instead of two of 6000 — eight forward and four inverse workgroups
+    // per pair side by side.  Measured (profiles/r05_gcc_batch.txt): 1 pair 47.5 -> 35.1 us, 4: 50.1 -> 36.7, 16: 58.1 -> 45.8,
+    // 32: 62.6 -> 56.7; beyond that the quarter-strided loads and stores of the four-way split cost more than its width buys
+    // (64 pairs 72 -> 80 us, 100: 84 -> 114) and the two-way split stays.
+    const bool small_batch = h->M == 2 * kGccStaticM2 && (long long)n_pairs * 8 <= (long long)device_cu_count() && option(kOptGccOneWorkgroup) <= 0 &&
+                             exp_env("FRT_GCC_NO_STATIC_PLAN") == nullptr && exp_env("FRT_GCC_NO_SMALL_PLAN") == nullptr;
+    if (small_batch && R == 2) R = 4;
     h->R = R;
     h->M2 = h->M / R;
     // numpy.hanning(L) = 0.5 - 0.5 cos(2 pi n / (L - 1))
@@ -1160,15 +1208,19 @@ extern "C" int frt_gcc_create(frt_gcc** out, int length, int n_pairs) {
         return FRT_ERR_HIP;
     }
     h->lds_bytes = (size_t)h->M2 * 16 + 16 * sizeof(double) + 16 * sizeof(int);
-    h->static_plan = h->M2 == kGccStaticM2 && exp_env("FRT_GCC_NO_STATIC_PLAN") == nullptr;
-    if (h->static_plan && (rc = upload(h->tws, make_static_twiddles<double>({6, 10, 10, 10})))) {
+    h->static_plan = exp_env("FRT_GCC_NO_STATIC_PLAN") != nullptr ? 0 : h->M2 == kGccStaticM2 ? 1 : (h->M2 == kGccStaticM2Small && small_batch) ? 2 : 0;
+    if (h->static_plan == 1) rc = upload(h->tws, make_static_twiddles<double>({6, 10, 10, 10}));
+    else if (h->static_plan == 2 && !(rc = upload(h->tws, make_static_twiddles<double>({3, 10, 10, 10}))))
+        rc = h->psum.reserve((size_t)n_pairs * 2 * 4 * sizeof(double));
+    if (rc) {
         frt_gcc_destroy(h);
         return rc;
     }
-    const void* big[] = {(const void*)gcc_phat_kernel<1, false>, (const void*)gcc_phat_kernel<2, false>, (const void*)gcc_phat_kernel<4, false>,
-                         (const void*)gcc_phat_kernel<2, true>,  (const void*)gcc_fwd_kernel<1, false>,  (const void*)gcc_fwd_kernel<2, false>,
-                         (const void*)gcc_fwd_kernel<4, false>,  (const void*)gcc_fwd_kernel<2, true>,   (const void*)gcc_inv_kernel<1, false>,
-                         (const void*)gcc_inv_kernel<2, false>,  (const void*)gcc_inv_kernel<4, false>,  (const void*)gcc_inv_kernel<2, true>};
+    const void* big[] = {(const void*)gcc_phat_kernel<1, 0>, (const void*)gcc_phat_kernel<2, 0>, (const void*)gcc_phat_kernel<4, 0>,
+                         (const void*)gcc_phat_kernel<2, 1>, (const void*)gcc_fwd_kernel<1, 0>,  (const void*)gcc_fwd_kernel<2, 0>,
+                         (const void*)gcc_fwd_kernel<4, 0>,  (const void*)gcc_fwd_kernel<2, 1>,  (const void*)gcc_fwd_kernel<4, 2>,
+                         (const void*)gcc_inv_kernel<1, 0>,  (const void*)gcc_inv_kernel<2, 0>,  (const void*)gcc_inv_kernel<4, 0>,
+                         (const void*)gcc_inv_kernel<2, 1>,  (const void*)gcc_inv_kernel<4, 2>};
     for (const void* f : big)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
             set_last_error("frt_gcc_create: cannot reserve %zu bytes of LDS", h->lds_bytes);
@@ -1258,7 +1310,8 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
         a.prof = h->prof.as<long long>();
     }
     a.vec = ((uintptr_t)a.d0 % 16 == 0) && ((uintptr_t)a.d1 % 16 == 0) && ((uintptr_t)a.xcorr % 16 == 0);
-    const bool st = h->static_plan;
+    const int st = h->static_plan;
+    a.psum = st == 2 ? h->psum.as<double>() : nullptr;
     const int force = option(kOptGccOneWorkgroup);
     const bool split = force >= 0 ? force == 0 : (long long)h->n_pairs * 8 <= 5ll * device_cu_count();
     if (split) {
@@ -1269,28 +1322,31 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
             return rc;
         const dim3 fgrid(h->R <= 2 ? 2 : 2 * h->R, h->n_pairs), igrid(h->R, h->n_pairs), cgrid((h->M / 2 + 1 + 255) / 256, h->n_pairs);
         const dim3 block(kGccThreads);
-        if (st) hipLaunchKernelGGL((gcc_fwd_kernel<2, true>), fgrid, block, h->lds_bytes, h->stream, a, gm);
-        else if (h->R == 1) hipLaunchKernelGGL((gcc_fwd_kernel<1, false>), fgrid, block, h->lds_bytes, h->stream, a, gm);
-        else if (h->R == 2) hipLaunchKernelGGL((gcc_fwd_kernel<2, false>), fgrid, block, h->lds_bytes, h->stream, a, gm);
-        else hipLaunchKernelGGL((gcc_fwd_kernel<4, false>), fgrid, block, h->lds_bytes, h->stream, a, gm);
-        if (h->R == 1) hipLaunchKernelGGL(gcc_cross_kernel<1>, cgrid, dim3(256), 0, h->stream, a, gm);
-        else if (h->R == 2) hipLaunchKernelGGL(gcc_cross_kernel<2>, cgrid, dim3(256), 0, h->stream, a, gm);
-        else hipLaunchKernelGGL(gcc_cross_kernel<4>, cgrid, dim3(256), 0, h->stream, a, gm);
+        if (st == 1) hipLaunchKernelGGL((gcc_fwd_kernel<2, 1>), fgrid, block, h->lds_bytes, h->stream, a, gm);
+        else if (st == 2) hipLaunchKernelGGL((gcc_fwd_kernel<4, 2>), fgrid, block, h->lds_bytes, h->stream, a, gm);
+        else if (h->R == 1) hipLaunchKernelGGL((gcc_fwd_kernel<1, 0>), fgrid, block, h->lds_bytes, h->stream, a, gm);
+        else if (h->R == 2) hipLaunchKernelGGL((gcc_fwd_kernel<2, 0>), fgrid, block, h->lds_bytes, h->stream, a, gm);
+        else hipLaunchKernelGGL((gcc_fwd_kernel<4, 0>), fgrid, block, h->lds_bytes, h->stream, a, gm);
+        if (h->R == 1) hipLaunchKernelGGL((gcc_cross_kernel<1>), cgrid, dim3(256), 0, h->stream, a, gm);
+        else if (h->R == 2) hipLaunchKernelGGL((gcc_cross_kernel<2>), cgrid, dim3(256), 0, h->stream, a, gm);
+        else if (st == 2) hipLaunchKernelGGL((gcc_cross_kernel<4, true>), cgrid, dim3(256), 0, h->stream, a, gm);
+        else hipLaunchKernelGGL((gcc_cross_kernel<4>), cgrid, dim3(256), 0, h->stream, a, gm);
         hipLaunchKernelGGL(gcc_pack_kernel, cgrid, dim3(256), 0, h->stream, a, gm);
         double* pv = h->part_val.as<double>();
         int* pi = h->part_idx.as<int>();
-        if (st) hipLaunchKernelGGL((gcc_inv_kernel<2, true>), igrid, block, h->lds_bytes, h->stream, a, pv, pi);
-        else if (h->R == 1) hipLaunchKernelGGL((gcc_inv_kernel<1, false>), igrid, block, h->lds_bytes, h->stream, a, pv, pi);
-        else if (h->R == 2) hipLaunchKernelGGL((gcc_inv_kernel<2, false>), igrid, block, h->lds_bytes, h->stream, a, pv, pi);
-        else hipLaunchKernelGGL((gcc_inv_kernel<4, false>), igrid, block, h->lds_bytes, h->stream, a, pv, pi);
+        if (st == 1) hipLaunchKernelGGL((gcc_inv_kernel<2, 1>), igrid, block, h->lds_bytes, h->stream, a, pv, pi);
+        else if (st == 2) hipLaunchKernelGGL((gcc_inv_kernel<4, 2>), igrid, block, h->lds_bytes, h->stream, a, pv, pi);
+        else if (h->R == 1) hipLaunchKernelGGL((gcc_inv_kernel<1, 0>), igrid, block, h->lds_bytes, h->stream, a, pv, pi);
+        else if (h->R == 2) hipLaunchKernelGGL((gcc_inv_kernel<2, 0>), igrid, block, h->lds_bytes, h->stream, a, pv, pi);
+        else hipLaunchKernelGGL((gcc_inv_kernel<4, 0>), igrid, block, h->lds_bytes, h->stream, a, pv, pi);
         hipLaunchKernelGGL(gcc_argmax_combine_kernel, dim3((h->n_pairs + 255) / 256), dim3(256), 0, h->stream, h->part_val.as<double>(),
                            h->part_idx.as<int>(), h->R, h->n_pairs, h->argmax.as<int>());
     } else {
         const dim3 grid(h->n_pairs), block(kGccThreads);
-        if (st) hipLaunchKernelGGL((gcc_phat_kernel<2, true>), grid, block, h->lds_bytes, h->stream, a);
-        else if (h->R == 1) hipLaunchKernelGGL((gcc_phat_kernel<1, false>), grid, block, h->lds_bytes, h->stream, a);
-        else if (h->R == 2) hipLaunchKernelGGL((gcc_phat_kernel<2, false>), grid, block, h->lds_bytes, h->stream, a);
-        else hipLaunchKernelGGL((gcc_phat_kernel<4, false>), grid, block, h->lds_bytes, h->stream, a);
+        if (st == 1) hipLaunchKernelGGL((gcc_phat_kernel<2, 1>), grid, block, h->lds_bytes, h->stream, a);
+        else if (h->R == 1) hipLaunchKernelGGL((gcc_phat_kernel<1, 0>), grid, block, h->lds_bytes, h->stream, a);
+        else if (h->R == 2) hipLaunchKernelGGL((gcc_phat_kernel<2, 0>), grid, block, h->lds_bytes, h->stream, a);
+        else hipLaunchKernelGGL((gcc_phat_kernel<4, 0>), grid, block, h->lds_bytes, h->stream, a);
     }
     FRT_HIP_CHECK(hipGetLastError());
     if (profile && !split) {
