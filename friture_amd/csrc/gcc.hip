@@ -15,7 +15,9 @@
 // into R interleaved sub-transforms of length M2 <= 6144 so that one sub-transform (96 KB of
 // complex doubles) fits in LDS next to nothing else; sub-spectra and the cross spectrum pass
 // through an HBM scratch slab owned by the workgroup (L2 resident: 64 bytes per complex point of
-// M).  The default L = 24000 = 2 * 2 * 6000 (friture/delay_estimator.py:114-115) runs R = 2.
+// M).  The default L = 24000 = 2 * 2 * 6000 (friture/delay_estimator.py:114-115) runs R = 2; handles of at most 32 pairs (the
+// widget's one pair) run it as R = 4 sub-transforms of 3000 points — a pair is then eight forward and four inverse workgroups of the
+// launches-of-phases path (gcc_fwd / cross / pack / inv_kernel), three per CU.
 #include <cmath>
 
 #include "common.h"
