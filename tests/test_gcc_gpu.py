@@ -365,3 +365,23 @@ def test_gcc_small_batch_path_equals_one_workgroup_path(hip, option):
             assert np.max(np.abs(x[1] - ref)) <= 1e-9 * np.max(np.abs(ref)), L
         assert np.max(np.abs(x_multi - x_one)) <= 1e-12 * np.max(np.abs(x_one)), L
         assert list(am_multi) == list(am_one) == [17] * 3
+
+
+def test_gcc_default_window_four_way_small_batches_equal_the_two_way_split(hip):
+    """Handles of at most CUs / 8 pairs of the default window (24000 samples) run the launches-of-phases path with FOUR
+    sub-transforms of 3000 points (compile-time plan 3 x 10 x 10 x 10; the means from the forward workgroups' partial sums, removed
+    in the spectrum), larger ones with two of 6000: the same pairs through a 32-pair handle and through the first 32 pairs of a
+    33-pair handle, with large means — 1e-13 of the correlation (measured 4e-16)'s scale, identical arg-max and means, and the oracle on one pair."""
+    from friture_amd.signal.correlation import GccPhat
+    L = 24000
+    rng = np.random.default_rng(2405)
+    d0 = 0.25 * rng.standard_normal((33, L)) + rng.uniform(-3.0, 3.0, (33, 1))
+    d1 = np.roll(d0, 29, axis=1) + 0.05 * rng.standard_normal((33, L)) - 1.5
+    x4, am4 = GccPhat(L, 32).correlate(d0[:32].copy(), d1[:32].copy())
+    x2, am2 = GccPhat(L, 33).correlate(d0.copy(), d1.copy())
+    assert np.max(np.abs(x4 - x2[:32])) <= 1e-13 * np.max(np.abs(x2)), np.max(np.abs(x4 - x2[:32])) / np.max(np.abs(x2))
+    assert list(am4) == list(am2[:32]) == [29] * 32
+    ref, _, _ = dsp.gcc_phat(d0[7].copy(), d1[7].copy())
+    assert np.max(np.abs(x4[7] - ref)) <= 1e-9 * np.max(np.abs(ref))
+    one, am1 = GccPhat(L, 1).correlate(d0[7:8].copy(), d1[7:8].copy())
+    assert np.max(np.abs(one[0] - ref)) <= 1e-9 * np.max(np.abs(ref)) and int(am1[0]) == 29
