@@ -23,7 +23,7 @@
 #include "stft_pk.h"          // packed-arithmetic helpers; round 3's N = 16384 instance itself only in -DFRT_EXPERIMENTS builds
 #include "stft_pk16.h"
 #ifdef FRT_EXPERIMENTS
-#include "stft_pk16r.h"       // N = 16384 with two workgroups per CU: measured 7-25 % slower (profiles/r05_stft16384_two_workgroups.txt)
+#include "../../tools/exp/stft_pk16r.h"      // N = 16384 with two workgroups per CU: measured 7-25 % slower (profiles/r05_stft16384_two_workgroups.txt)
 #endif
 #include "stft_pk16s.h"       // N = 8192 / 4096 / 2048: one template over the size
 

@@ -1,5 +1,5 @@
 // stft_pk16r.h — K1 for N = 16384, float32, hop N/2 or N/4: stft_pk16_kernel (stft_pk16.h) cut down to TWO workgroups per CU.
-// Included by stft.hip after stft_pk16.h, whose first stage, 16 x 16 x 2 sub-transforms, LDS exchange layout and unpack it keeps.
+// Included by stft.hip (-DFRT_EXPERIMENTS builds only) after stft_pk16.h, whose first stage, 16 x 16 x 2 sub-transforms, LDS exchange layout and unpack it keeps.
 //
 // stft_pk16_kernel holds 137 KB of LDS (a 64 KB sample ring filled by LDS-DMA beside the 70 KB of exchange regions) and 176 / 208
 // registers (122 of them the run's window, twiddle and weight factors): one 512-thread workgroup per CU, two waves per SIMD, and
