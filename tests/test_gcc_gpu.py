@@ -385,3 +385,22 @@ def test_gcc_default_window_four_way_small_batches_equal_the_two_way_split(hip):
     assert np.max(np.abs(x4[7] - ref)) <= 1e-9 * np.max(np.abs(ref))
     one, am1 = GccPhat(L, 1).correlate(d0[7:8].copy(), d1[7:8].copy())
     assert np.max(np.abs(one[0] - ref)) <= 1e-9 * np.max(np.abs(ref)) and int(am1[0]) == 29
+
+
+def test_gcc_four_way_handle_forced_onto_the_one_workgroup_kernel(hip, option):
+    """A small-batch handle of the default window is made with four sub-transforms of 3000 points; forcing the one-workgroup kernel on it
+    AFTER it was made runs that kernel's R = 4 instance on the run-time plan — slower, and the same correlation."""
+    from friture_amd.signal.correlation import GccPhat
+    L = 24000
+    rng = np.random.default_rng(77)
+    d0 = 0.25 * rng.standard_normal((2, L)) + 0.5
+    d1 = np.roll(d0, 11, axis=1) + 0.03 * rng.standard_normal((2, L))
+    g = GccPhat(L, 2)
+    x_phases, am_phases = g.correlate(d0.copy(), d1.copy())
+    option("gcc_one_workgroup", 1)
+    x_one, am_one = g.correlate(d0.copy(), d1.copy())
+    option("gcc_one_workgroup", -1)
+    assert np.max(np.abs(x_phases - x_one)) <= 1e-12 * np.max(np.abs(x_one))
+    assert list(am_phases) == list(am_one) == [11, 11]
+    ref, _, _ = dsp.gcc_phat(d0[0].copy(), d1[0].copy())
+    assert np.max(np.abs(x_one[0] - ref)) <= 1e-9 * np.max(np.abs(ref))
