@@ -951,6 +951,63 @@ __global__ void __launch_bounds__(64) iir_zero_state_mfma_kernel(const ZeroState
     for (int rt = 0; rt < kZsTiles; ++rt) acc[rt] = zs_double4{0.0, 0.0, 0.0, 0.0};
     const zs_double4* __restrict__ tm = (const zs_double4*)a.table_m;
     constexpr int UN = FRT_ZS_UNROLL;                                                 // blocks of 16 samples whose loads are in flight together
+    // Every column of the wavefront a whole slice of an aligned row (the bulk of every launch): a loop without the per-block choices
+    // below.  With them the float32 samples of stage 0 were CONVERTED inside the branch that had loaded them — a wait for every load
+    // right behind it, the table loads and the next block's samples queued behind that wait (ISA: global_load_dwordx4, s_waitcnt vmcnt(0),
+    // v_cvt_f64_f32 x 4, then the table loads): the blocks' loads were never in flight together at the stage that has the most of them.
+    // Same products in the same order: bit-identical end states.
+    const bool whole = a.vec && valid && first - 4 * g + a.slice <= a.n && (a.slice / 16) % UN == 0;
+    if (__all(whole)) {
+        const int tile0 = rt0 < row_tiles ? rt0 : row_tiles - 1, tile1 = rt0 + 1 < row_tiles ? rt0 + 1 : row_tiles - 1;
+        const size_t kb0 = (size_t)(k0 >> 4);
+        auto table_at = [&](size_t kblock, int rt) { return tm[((kblock * row_tiles + (rt == 0 ? tile0 : tile1)) * 4 + g) * 16 + j]; };
+        if (a.in_f32) {
+            const float* xp = (const float*)a.x + xrow + first;
+            for (int kb = 0; kb < a.slice / 16; kb += UN) {
+                float4 raw[UN];
+                zs_double4 av[UN][kZsTiles];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) raw[u] = *(const float4*)(xp + 16 * (kb + u));
+#pragma unroll
+                for (int u = 0; u < UN; ++u)
+#pragma unroll
+                    for (int rt = 0; rt < kZsTiles; ++rt) av[u][rt] = table_at(kb0 + kb + u, rt);
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const double xs[4] = {(double)raw[u].x, (double)raw[u].y, (double)raw[u].z, (double)raw[u].w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int rt = 0; rt < kZsTiles; ++rt)
+                            acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][rt][t], xs[t], acc[rt], 0, 0, 0);
+                }
+            }
+        } else {
+            const double* xp = (const double*)a.x + xrow + first;
+            for (int kb = 0; kb < a.slice / 16; kb += UN) {
+                double2 raw[UN][2];
+                zs_double4 av[UN][kZsTiles];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    raw[u][0] = *(const double2*)(xp + 16 * (kb + u));
+                    raw[u][1] = *(const double2*)(xp + 16 * (kb + u) + 2);
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u)
+#pragma unroll
+                    for (int rt = 0; rt < kZsTiles; ++rt) av[u][rt] = table_at(kb0 + kb + u, rt);
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const double xs[4] = {raw[u][0].x, raw[u][0].y, raw[u][1].x, raw[u][1].y};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int rt = 0; rt < kZsTiles; ++rt)
+                            acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][rt][t], xs[t], acc[rt], 0, 0, 0);
+                }
+            }
+        }
+    } else
     for (int kb = 0; kb < a.slice / 16; kb += UN) {
         double xs[UN][4];
         zs_double4 av[UN][kZsTiles];
