@@ -960,14 +960,17 @@ __global__ void __launch_bounds__(64) iir_zero_state_mfma_kernel(const ZeroState
     if (__all(whole)) {
         const int tile0 = rt0 < row_tiles ? rt0 : row_tiles - 1, tile1 = rt0 + 1 < row_tiles ? rt0 + 1 : row_tiles - 1;
         const size_t kb0 = (size_t)(k0 >> 4);
-        auto table_at = [&](size_t kblock, int rt) { return tm[((kblock * row_tiles + (rt == 0 ? tile0 : tile1)) * 4 + g) * 16 + j]; };
+        auto table_at = [&](size_t kblock, int rt) {
+            if (FRT_ZS_ABLATE & 1) kblock = kb0;                    // (timing experiments: every block the same table values — from L1)
+            return tm[((kblock * row_tiles + (rt == 0 ? tile0 : tile1)) * 4 + g) * 16 + j];
+        };
         if (a.in_f32) {
             const float* xp = (const float*)a.x + xrow + first;
             for (int kb = 0; kb < a.slice / 16; kb += UN) {
                 float4 raw[UN];
                 zs_double4 av[UN][kZsTiles];
 #pragma unroll
-                for (int u = 0; u < UN; ++u) raw[u] = *(const float4*)(xp + 16 * (kb + u));
+                for (int u = 0; u < UN; ++u) raw[u] = (FRT_ZS_ABLATE & 2) ? float4{0.5f, 0.25f, -0.5f, 1.f} : *(const float4*)(xp + 16 * (kb + u));
 #pragma unroll
                 for (int u = 0; u < UN; ++u)
 #pragma unroll
