@@ -249,22 +249,28 @@ __device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long 
         // the load, convert and LDS-write instructions — the pass runs at its VALU issue rate, and this prologue was 4 of
         // its 15.6 instructions per sample), one sample at a time for the ragged end of a channel
         if (a.vec_x && cnt == 64) {
+            // (every load of the group first, then the conversions and LDS writes: written load-by-load the compiler gave all of
+            // them one register and waited behind each — eight round trips per group of a quad slot's float64 samples)
             if (a.in_f32) {
                 const float* xp = (const float*)a.x + xrow + base;
+                float4 v[SPW / 4];
+#pragma unroll
+                for (int j = 0; j < SPW / 4; ++j) v[j] = *(const float4*)(xp + 4 * (s + LPS * j));
 #pragma unroll
                 for (int j = 0; j < SPW / 4; ++j) {
                     const int k = 4 * (s + LPS * j);
-                    const float4 v = *(const float4*)(xp + k);
-                    *(double2*)(xy + k) = double2{(double)v.x, (double)v.y};
-                    *(double2*)(xy + k + 2) = double2{(double)v.z, (double)v.w};
+                    *(double2*)(xy + k) = double2{(double)v[j].x, (double)v[j].y};
+                    *(double2*)(xy + k + 2) = double2{(double)v[j].z, (double)v[j].w};
                 }
             } else {
                 const double* xp = (const double*)a.x + xrow + base;
+                double2 v[SPW / 2];
 #pragma unroll
-                for (int j = 0; j < SPW / 2; ++j) {
-                    const int k = 2 * (s + LPS * j);
-                    *(double2*)(xy + k) = *(const double2*)(xp + k);
-                }
+                for (int j = 0; j < SPW / 2; ++j) v[j] = *(const double2*)(xp + 2 * (s + LPS * j));
+#pragma unroll
+                for (int j = 0; j < SPW / 2; ++j) asm volatile("" : "+v"(v[j].x), "+v"(v[j].y));      // (all of them requested before the first is stored)
+#pragma unroll
+                for (int j = 0; j < SPW / 2; ++j) *(double2*)(xy + 2 * (s + LPS * j)) = v[j];
             }
         } else {
 #pragma unroll
