@@ -326,7 +326,10 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
     const int tid = threadIdx.x;
     const int pair = blockIdx.x;
     const int L = a.L, M = a.M, M2 = a.M2;
-    const double* sig[2] = {a.d0 + (size_t)pair * L, a.d1 + (size_t)pair * L};
+    // (no array that the loops over s and r index at run time: such an array lives in scratch memory, every use is a scratch load and
+    // a wait for EVERY load in flight — the signal pointers, the means and the sub-spectrum pointers were 80 bytes of it)
+    const double* const sig0 = a.d0 + (size_t)pair * L;
+    const double* const sig1 = a.d1 + (size_t)pair * L;
     C* S = (C*)a.scratch + (size_t)pair * (4 * (size_t)M + 2);   // [2][R][M2] sub-spectra
     C* Zi = S + 2 * (size_t)M + (M + 1);                         // [M] packed inverse input (R = 4 only)
     const C* twm = (const C*)a.twm;
@@ -342,37 +345,39 @@ __global__ void __launch_bounds__(kGccThreads) gcc_phat_kernel(const GccArgs a) 
     // computed the means first was a fifth of this kernel at a full chip (28 of 150 us per pair: the chip's whole HBM stream).
     // (Requesting the samples of the next sub-transform while the one before it runs — twelve 16-byte loads per thread held across
     // it — was measured: 0.58 against 0.54 ms for 1024 pairs; the kernel sits at its 256 registers and spills.)
-    double mean[2];
-    GccSub<R> sub;
+    double mean0 = 0.0, mean1 = 0.0;
     for (int s = 0; s < 2; ++s) {
         double acc = 0.0;
         for (int r = 0; r < R; ++r) {
-            {
-                const double2* wn = (const double2*)a.window;
-                for (int m = tid; m < M2; m += kGccThreads) {
-                    const double2 x = gcc_pair_at(sig[s], R * m + r, a.vec), w = wn[R * m + r];
-                    acc += x.x + x.y;
-                    buf[m] = {x.x * w.x, x.y * w.y};
-                }
-            }
+            // (every load of the sub-transform's samples and window values in flight together: as a loop of one pair of loads per
+            // trip — not unrolled by the compiler — each of the twelve trips waited for its own round trip: 8-12 us per sub-transform)
+            acc += gcc_load_sub<R>(a, s == 0 ? sig0 : sig1, 0.0, r, buf, tid);
             __syncthreads();
             if (s == 0 && r == 0) GCC_STAMP(2);
             gcc_fft<ST>(buf, a, tid);
             if (s == 0 && r == 0) GCC_STAMP(3);
             const bool last = s == 1 && r == R - 1;
             C* dst = S + ((size_t)s * R + r) * M2;
-            sub.p[s][r] = last ? (const C*)buf : (const C*)dst;
             if (!last) {
                 for (int k = tid; k < M2; k += kGccThreads) dst[k] = buf[k];
                 __syncthreads();
             }
         }
-        mean[s] = block_sum(acc, red) / (double)L;
+        const double m = block_sum(acc, red) / (double)L;
+        if (s == 0) mean0 = m;
+        else mean1 = m;
     }
     if (tid == 0 && a.means) {
-        a.means[2 * pair] = mean[0];
-        a.means[2 * pair + 1] = mean[1];
+        a.means[2 * pair] = mean0;
+        a.means[2 * pair + 1] = mean1;
     }
+    const double mean[2] = {mean0, mean1};                      // (indexed by unrolled loops only)
+    GccSub<R> sub;                                               // sub-spectrum (s, r): the scratch slab, or LDS for the last one
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            sub.p[s][r] = (s == 1 && r == R - 1) ? (const C*)buf : (const C*)(S + ((size_t)s * R + r) * M2);
     __threadfence_block();
     __syncthreads();
     GCC_STAMP(4);
