@@ -184,13 +184,18 @@ static int launch_shift(const StftArgs& a, int shift, int blocks, hipStream_t st
     if (shift < 0) shift = 4;
     // N >= 2048 comes here only off the 8-byte grid (no register window then) or through a negative run length (tests: the generic
     // workgroup walk against the radix-16 instances): the slot-reloading instance serves both — no window instances of those sizes
-    if constexpr (LOG2M >= 10) return launch_one<TIN, T, LOG2M, 0>(a, blocks, stream);
-    if constexpr (sizeof(T) == 4) {
-        if (shift == 2) return launch_one<TIN, T, LOG2M, 2>(a, blocks, stream);
+    // (an `else`, not a `return` in front of the rest: statements behind a constexpr-if's return are still instantiated, and the device
+    // side would go on emitting their kernels)
+    if constexpr (LOG2M >= 10) {
+        return launch_one<TIN, T, LOG2M, 0>(a, blocks, stream);
+    } else {
+        if constexpr (sizeof(T) == 4) {
+            if (shift == 2) return launch_one<TIN, T, LOG2M, 2>(a, blocks, stream);
+        }
+        // hop = N/2 keeps half of the register window (float64 too: the reference's own precision at BASELINE's overlap)
+        if (shift == 4) return launch_one<TIN, T, LOG2M, 4>(a, blocks, stream);
+        return launch_one<TIN, T, LOG2M, 0>(a, blocks, stream);
     }
-    // hop = N/2 keeps half of the register window (float64 too: the reference's own precision at BASELINE's overlap)
-    if (shift == 4) return launch_one<TIN, T, LOG2M, 4>(a, blocks, stream);
-    return launch_one<TIN, T, LOG2M, 0>(a, blocks, stream);
 }
 
 template <typename TIN, typename T>
