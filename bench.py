@@ -470,6 +470,24 @@ class StubEngine:
         return rows, nyq
 
 
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` started without a launcher (WORLD_SIZE unset): re-execute the same command line as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same args>`
+    — one rank per GPU, rank 0 prints the one JSON line — so both forms of the contract's launch work.  The port is a free
+    one picked here; the child's exit status is this process's."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")                     # (torchrun would set it, with a warning)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -493,6 +511,9 @@ def main():
     ap.add_argument("--full-json", default="", help="also write the uncompacted record (prose notes, full-precision floats) to this file")
     ap.add_argument("--stub-engine", action="store_true", help="tests only: CPU stand-in engine over gloo, see StubEngine")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus)        # plain `python bench.py --gpus N`: becomes the contract's launch line (does not return)
 
     import torch
 

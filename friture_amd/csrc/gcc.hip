@@ -51,6 +51,7 @@ struct GccArgs {
     double* scratch;       // [pairs][4 M + 2] complex
     MixedPlan plan;        // for M2
     int L, M, M2, R;
+    int n_pairs;           // gcc_phat_resident_kernel: a workgroup takes the pairs blockIdx.x, blockIdx.x + gridDim.x, ...
     int vec;               // d0, d1 and xcorr are 16-byte aligned
     long long* prof;       // FRT_GCC_PROFILE: phase time stamps of workgroup 0 (100 MHz counter), else null
 };
@@ -281,6 +282,14 @@ __global__ void __launch_bounds__(256) gcc_window_rfft_kernel(const double* __re
     dw[2 * k] = sr;
     dw[2 * k + 1] = si;
 }
+
+}  // namespace frt
+#include "gcc_resident.h"
+#ifndef FRT_GCC_RES_THREADS
+#define FRT_GCC_RES_THREADS 768
+#endif
+constexpr int kResThreads = FRT_GCC_RES_THREADS;
+namespace frt {
 
 // One window pair per workgroup, everything between the two signals and the correlation in this launch.  What passes
 // through the pair's scratch slab is only what cannot stay on the CU: of the 2 R sub-spectra (M2 complex each, one LDS
@@ -1197,8 +1206,7 @@ extern "C" int frt_gcc_create(frt_gcc** out, int length, int n_pairs) {
         return FRT_OK;
     }
     if ((rc = upload(h->window, win)) || (rc = upload(h->twm, make_twiddles<double>(h->M))) ||
-        (rc = upload(h->tw2, make_pass_twiddles<double>(h->plan))) || (rc = upload(h->twl, make_twiddles<double>(length, h->M + 1))) ||
-        (rc = h->scratch.reserve((size_t)n_pairs * (4 * (size_t)h->M + 2) * 2 * sizeof(double)))) {
+        (rc = upload(h->tw2, make_pass_twiddles<double>(h->plan))) || (rc = upload(h->twl, make_twiddles<double>(length, h->M + 1)))) {
         frt_gcc_destroy(h);
         return rc;
     }
@@ -1234,6 +1242,12 @@ extern "C" int frt_gcc_create(frt_gcc** out, int length, int n_pairs) {
             frt_gcc_destroy(h);
             return FRT_ERR_HIP;
         }
+    if (h->static_plan == 1 && hipFuncSetAttribute((const void*)gcc_phat_resident_kernel<kResThreads>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)ResPlan<kResThreads>::LDS_BYTES) != hipSuccess) {
+        set_last_error("frt_gcc_create: cannot reserve %zu bytes of LDS", ResPlan<kResThreads>::LDS_BYTES);
+        frt_gcc_destroy(h);
+        return FRT_ERR_HIP;
+    }
     *out = h;
     return FRT_OK;
 }
@@ -1303,7 +1317,6 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
     a.twm = h->twm.as<double>();
     a.tw2 = h->tw2.as<double>();
     a.twl = h->twl.as<double>();
-    a.scratch = h->scratch.as<double>();
     a.plan = h->plan;
     a.L = h->L;
     a.M = h->M;
@@ -1319,8 +1332,13 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
     a.vec = ((uintptr_t)a.d0 % 16 == 0) && ((uintptr_t)a.d1 % 16 == 0) && ((uintptr_t)a.xcorr % 16 == 0);
     const int st = h->static_plan;
     a.psum = st == 2 ? h->psum.as<double>() : nullptr;
+    a.n_pairs = h->n_pairs;
     const int force = option(kOptGccOneWorkgroup);
     const bool split = force >= 0 ? force == 0 : (long long)h->n_pairs * 8 <= 5ll * device_cu_count();
+    // the default window, one workgroup per pair: nothing passes through HBM between the signals and the correlation (gcc_resident.h)
+    const bool resident = !split && st == 1 && h->R == 2 && option(kOptGccResident) != 0;
+    if (!resident && (rc = h->scratch.reserve((size_t)h->n_pairs * (4 * (size_t)h->M + 2) * 2 * sizeof(double)))) return rc;
+    a.scratch = h->scratch.as<double>();
     if (split) {
         // up to 5/8 of a workgroup per CU (160 pairs on 256 CUs; measured crossover between 100 and 256): a pair as launches of its own phases
         if ((rc = h->gmax.reserve((size_t)h->n_pairs * 8))) return rc;
@@ -1350,7 +1368,9 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
                            h->part_idx.as<int>(), h->R, h->n_pairs, h->argmax.as<int>());
     } else {
         const dim3 grid(h->n_pairs), block(kGccThreads);
-        if (st == 1) hipLaunchKernelGGL((gcc_phat_kernel<2, 1>), grid, block, h->lds_bytes, h->stream, a);
+        if (resident) {
+            hipLaunchKernelGGL(gcc_phat_resident_kernel<kResThreads>, grid, dim3(kResThreads), ResPlan<kResThreads>::LDS_BYTES, h->stream, a);
+        } else if (st == 1) hipLaunchKernelGGL((gcc_phat_kernel<2, 1>), grid, block, h->lds_bytes, h->stream, a);
         else if (h->R == 1) hipLaunchKernelGGL((gcc_phat_kernel<1, 0>), grid, block, h->lds_bytes, h->stream, a);
         else if (h->R == 2) hipLaunchKernelGGL((gcc_phat_kernel<2, 0>), grid, block, h->lds_bytes, h->stream, a);
         else hipLaunchKernelGGL((gcc_phat_kernel<4, 0>), grid, block, h->lds_bytes, h->stream, a);
@@ -1360,7 +1380,8 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
         long long t[9];
         FRT_HIP_CHECK(hipStreamSynchronize(h->stream));
         FRT_HIP_CHECK(hipMemcpy(t, h->prof.ptr, sizeof(t), hipMemcpyDeviceToHost));
-        fprintf(stderr, "gcc_phat_kernel phases (us): means %.1f | load0 %.1f | fft0 %.1f | rest of forward %.1f | cross %.1f | pack %.1f | inverse %.1f | argmax %.1f | total %.1f\n",
+        fprintf(stderr, resident ? "gcc_phat_resident_kernel phases (us): load of signal 0 %.1f | its first transform %.1f | quads, second transform %.1f | signal 1 %.1f | cross %.1f | pack %.1f | inverse transforms %.1f | stores, argmax %.1f | total %.1f\n"
+                                 : "gcc_phat_kernel phases (us): means %.1f | load0 %.1f | fft0 %.1f | rest of forward %.1f | cross %.1f | pack %.1f | inverse %.1f | argmax %.1f | total %.1f\n",
                 (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01,
                 (t[7] - t[6]) * 0.01, (t[8] - t[7]) * 0.01, (t[8] - t[0]) * 0.01);
     }

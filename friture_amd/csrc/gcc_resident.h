@@ -1,0 +1,383 @@
+// gcc_resident.h — GCC-PHAT of the delay estimator's default window (L = 24000 samples, friture/delay_estimator.py:114-115;
+// semantics: friture/signal/correlation.py:24-43) with NOTHING in HBM between the two signals and the correlation.
+//
+// gcc_phat_kernel<2, 1> (gcc.hip) parks three of a pair's four 96 KB sub-spectra in a per-pair scratch slab and reads them back for
+// the cross spectrum: +288 KB written and +288 KB read beside the 576 KB a pair moves algorithmically, and its sample loads take
+// every second 16-byte word of a line (sub-transform r takes the sample pairs 2 m + r), four load phases per pair that each fetch
+// whole lines for half their bytes.  Here the parked sub-spectra live where the CU has room for them:
+//
+//   * a CU's register file is 512 KB and this kernel owns it (one workgroup per CU).  The 6000-point transform needs a part of a
+//     thread's registers; the others park data across it.
+//   * ownership by QUADS of bins: with M = 2 M2 the bins {q, M - q, M2 - q, M2 + q}, q <= M2 / 2, are formed from the SAME two
+//     elements q and M2 - q of every sub-spectrum — Z_s[q] = a + t b, Z_s[M2 + q] = a - t b, Z_s[M - q] = c + conj(t) d,
+//     Z_s[M2 - q] = c - conj(t) d with (a, b) = S_s0/1[q], (c, d) = S_s0/1[M2 - q], t = exp(-2 pi i q / M) — and so are the four
+//     inverse-transform inputs of the quad (elements q and M2 - q of both inverse sub-transforms).  Thread t owns the quads
+//     q = t + NT i: it reads its elements of a sub-spectrum out of LDS when the transform ends and nobody else ever needs them —
+//     no exchange between threads from the forward transforms to the inverse ones but the block maximum of |G|.
+//   * signal 0's two sub-spectra wait in registers; signal 1's first waits in the 64 KB of LDS the transform array leaves free
+//     (+ a few registers); its second is read where the transform left it.
+//   * a signal is loaded ONCE, whole lines (both 16-byte words of a 32-byte slot in one phase): the r = 0 half goes into the
+//     transform array, the r = 1 half waits in the second LDS array (+ a few registers) for the first transform to end.
+//   * the r = 0 half of the correlation waits in registers for the r = 1 half, so a thread stores 32 contiguous bytes per slot.
+//
+// HBM traffic per pair = the algorithmic 24 L bytes (+ table reads that hit in L2).
+#pragma once
+
+namespace frt {
+
+constexpr int kResM2 = 6000, kResM = 2 * kResM2, kResL = 2 * kResM;
+constexpr int kResSpare = 4096;                                                   // complex doubles of the second LDS array
+
+template <int NT>
+struct ResPlan {
+    static constexpr int NS = (kResM2 + NT - 1) / NT;                             // points of a sub-transform per thread (slots)
+    static constexpr int NQ = (kResM2 / 2 + 1 + NT - 1) / NT;                     // quads per thread (q <= 3000)
+    static constexpr int NE = 2 * NQ;                                             // elements of a sub-spectrum per thread
+    static constexpr int SPS = kResSpare / NT;                                    // a thread's slots in the second LDS array
+    static constexpr int NW = NT / 64;
+    static constexpr size_t LDS_BYTES = (size_t)(kResM2 + SPS * NT) * 16 + 2 * 16 * sizeof(double) + 16 * sizeof(int);
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS of a CU");
+    static_assert(NW <= 16 && NT % 64 == 0, "reduction arrays");
+    static constexpr bool slot_full(int j) { return (j + 1) * NT <= kResM2; }     // every thread's point of slot j exists
+    static constexpr bool quad_full(int i) { return (i + 1) * NT <= kResM2 / 2 + 1; }
+};
+
+// Buffer accesses: the descriptor in scalar registers, ONE 32-bit lane offset and a scalar offset per access.  As flat accesses the
+// loads of a signal and the stores of a correlation each keep a 64-bit address pair alive — computed at the top of the kernel,
+// spilled, reloaded.  (A 16-byte buffer access needs 4-byte alignment only: windows that are views into a ring go the same way.)
+typedef __amdgpu_buffer_rsrc_t res_rsrc;
+typedef double res_d2 __attribute__((ext_vector_type(2)));
+typedef uint32_t res_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ res_rsrc res_make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);      // raw buffer, gfx950 data format word
+}
+__device__ __forceinline__ cpx<double> res_load16(res_rsrc r, uint32_t lane_off, uint32_t soff) {
+    const res_d2 v = __builtin_bit_cast(res_d2, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, soff, 0));
+    return {v.x, v.y};
+}
+__device__ __forceinline__ void res_store16(res_rsrc r, uint32_t lane_off, uint32_t soff, double x, double y) {
+    const res_u4 bits = __builtin_bit_cast(res_u4, res_d2{x, y});
+    __builtin_amdgcn_raw_buffer_store_b128(bits, r, lane_off, soff, 0);
+    // the data registers stay untouched for two more issue slots: the compiler pads the "store of more than 8 bytes, then a write
+    // of its data registers" hazard only when the scalar offset is an immediate (round 5, tools/exp/stft_pk16r.h)
+    asm volatile("s_nop 1" ::"v"(bits));
+}
+
+// A value the compiler must treat as produced HERE: table loads addressed through it cannot be hoisted above this point (they are
+// loads of read-only memory: without this every quad's table entries are fetched at the top of the kernel and spilled), and
+// `chain` orders the point behind the arithmetic that produced it (one quad's loads at a time).
+__device__ __forceinline__ int res_opaque(int v, double& chain) {
+    asm volatile("" : "+v"(v), "+v"(chain));
+    return v;
+}
+
+// One signal, read once: (x w) of the even sample pairs into the transform array, of the odd ones into the thread's slots of the
+// second array (the last slots: registers).  Returns the sum of the thread's samples (the mean leaves in the spectrum: rfft((x - m) w)
+// = rfft(x w) - m rfft(w)).  Two batches of slots: 2 x 2 x NS / 2 loads of 16 bytes in flight per thread.
+template <int NT>
+__device__ __forceinline__ double res_load_signal(const double* __restrict__ sig, res_rsrc wrs, cpx<double>* buf, cpx<double>* sp,
+                                                  cpx<double> (&Y)[ResPlan<NT>::NS - ResPlan<NT>::SPS], int tid) {
+    using C = cpx<double>;
+    using P = ResPlan<NT>;
+    constexpr int HB = (P::NS + 1) / 2;
+    const res_rsrc srs = res_make_rsrc(sig);
+    uint32_t lane = (uint32_t)tid * 32u;                                            // slot j of thread tid: bytes 32 (tid + NT j) ...
+    asm volatile("" : "+v"(lane));      // (or the second signal re-uses the first one's window values: 2 NS x 4 registers kept from here to there)
+    uint32_t lane_hi = lane + 16u;
+    double acc = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        C x0[HB], x1[HB], w0[HB], w1[HB];
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            const int j = HB * h + i, m = tid + j * NT;
+            const uint32_t soff = (uint32_t)j * (NT * 32u);
+            x0[i] = x1[i] = w0[i] = w1[i] = C{0.0, 0.0};
+            if (j < P::NS && (P::slot_full(j) || m < kResM2)) {
+                x0[i] = res_load16(srs, lane, soff);
+                x1[i] = res_load16(srs, lane_hi, soff);
+                w0[i] = res_load16(wrs, lane, soff);
+                w1[i] = res_load16(wrs, lane_hi, soff);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            const int j = HB * h + i, m = tid + j * NT;
+            if (j < P::NS) {
+                acc += (x0[i].x + x0[i].y) + (x1[i].x + x1[i].y);
+                const C y1 = {x1[i].x * w1[i].x, x1[i].y * w1[i].y};
+                if (P::slot_full(j) || m < kResM2) buf[m] = {x0[i].x * w0[i].x, x0[i].y * w0[i].y};
+                if (j < P::SPS) sp[m] = y1;                         // (a thread's slots of the second array are its own: no barrier)
+                else Y[j - P::SPS] = y1;
+            }
+        }
+        asm volatile("" : "+v"(lane), "+v"(lane_hi), "+v"(acc));   // the second batch's loads behind the first batch's arithmetic (the
+                                                                   // scheduler otherwise issues all 4 NS loads first and spills them)
+    }
+    return acc;
+}
+
+// The waiting r = 1 half into the transform array (the array's readers are behind a barrier)
+template <int NT>
+__device__ __forceinline__ void res_second_half(cpx<double>* buf, const cpx<double>* sp, const cpx<double> (&Y)[ResPlan<NT>::NS - ResPlan<NT>::SPS],
+                                                int tid) {
+    using P = ResPlan<NT>;
+#pragma unroll
+    for (int j = 0; j < P::NS; ++j) {
+        const int m = tid + j * NT;
+        if (j < P::SPS) buf[m] = sp[m];
+        else if (P::slot_full(j) || m < kResM2) buf[m] = Y[j - P::SPS];
+    }
+}
+
+// The thread's elements of the sub-spectrum in the transform array: E[2 i], E[2 i + 1] = elements q, M2 - q of quad i
+template <int NT>
+__device__ __forceinline__ void res_take_quads(const cpx<double>* buf, cpx<double> (&E)[ResPlan<NT>::NE], int tid) {
+    using P = ResPlan<NT>;
+#pragma unroll
+    for (int i = 0; i < P::NQ; ++i) {
+        const int q = tid + i * NT;
+        E[2 * i] = E[2 * i + 1] = {0.0, 0.0};
+        if (P::quad_full(i) || q <= kResM2 / 2) {
+            E[2 * i] = buf[q];
+            E[2 * i + 1] = buf[q == 0 ? 0 : kResM2 - q];
+        }
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT) gcc_phat_resident_kernel(const GccArgs a) {
+    using C = cpx<double>;
+    using P = ResPlan<NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    C* buf = (C*)smem;                                  // the transform array, M2 points
+    C* sp = buf + kResM2;                               // SPS slots per thread, element (slot, tid) at slot * NT + tid: thread-private
+    double* red = (double*)(sp + P::SPS * NT);          // 2 x 16 doubles + 16 ints
+    int* redi = (int*)(red + 32);
+    const int tid = threadIdx.x;
+    constexpr int M = kResM, M2 = kResM2, L = kResL, NQ = P::NQ, NS = P::NS, NE = P::NE, SPS = P::SPS;
+    const res_rsrc wrs = res_make_rsrc(a.window), twm_rs = res_make_rsrc(a.twm), twl_rs = res_make_rsrc(a.twl), dw_rs = res_make_rsrc(a.dw);
+    const C* __restrict__ tws = (const C*)a.tws;
+
+    // (one pair per workgroup: as a loop over pairs the compiler hoists the loop-invariant table loads of the cross spectrum out of it
+    // and spills them)
+    const int pair = blockIdx.x;
+    const double* const sig0 = a.d0 + (size_t)pair * L;
+    const double* const sig1 = a.d1 + (size_t)pair * L;
+    GCC_STAMP(0);
+    // ---- signal 0: both sub-spectra into registers ----------------------------------------------------------------------
+    C Y[NS - SPS];
+    C e00[NE], e01[NE];
+    // (the wavefronts' sample sums wait in LDS for the cross spectrum, not in registers across four transforms)
+    auto leave_sum = [&](double v, int at) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((tid & 63) == 0) red[at + (tid >> 6)] = v;
+    };
+    leave_sum(res_load_signal<NT>(sig0, wrs, buf, sp, Y, tid), 0);
+    __syncthreads();
+    GCC_STAMP(1);
+    static_fft_forward<double, NT, 6, 10, 10, 10>(buf, tws, tid);
+    GCC_STAMP(2);
+    res_take_quads<NT>(buf, e00, tid);
+    __syncthreads();
+    res_second_half<NT>(buf, sp, Y, tid);
+    __syncthreads();
+    static_fft_forward<double, NT, 6, 10, 10, 10>(buf, tws, tid);
+    res_take_quads<NT>(buf, e01, tid);
+    __syncthreads();
+    GCC_STAMP(3);
+    // ---- signal 1: first sub-spectrum into the second LDS array (the thread's first SPS elements) and registers (the others) --
+    leave_sum(res_load_signal<NT>(sig1, wrs, buf, sp, Y, tid), 16);
+    __syncthreads();
+    static_fft_forward<double, NT, 6, 10, 10, 10>(buf, tws, tid);
+    C e10r[NE - SPS];
+    {
+        C te[NE];
+        res_take_quads<NT>(buf, te, tid);
+        __syncthreads();
+        res_second_half<NT>(buf, sp, Y, tid);                // (reads the thread's slots of the second array ...
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {                       //  ... before these writes re-use them: same thread, program order)
+            if (e < SPS) sp[e * NT + tid] = te[e];
+            else e10r[e - SPS] = te[e];
+        }
+    }
+    __syncthreads();
+    static_fft_forward<double, NT, 6, 10, 10, 10>(buf, tws, tid);
+    GCC_STAMP(4);
+    // ---- the means ---------------------------------------------------------------------------------------------------------
+    double mean0 = 0.0, mean1 = 0.0;                     // (the sums were left before barriers long past)
+#pragma unroll
+    for (int w = 0; w < P::NW; ++w) {
+        mean0 += red[w];
+        mean1 += red[16 + w];
+    }
+    mean0 /= (double)L;
+    mean1 /= (double)L;
+    if (tid == 0 && a.means) {
+        a.means[2 * pair] = mean0;
+        a.means[2 * pair + 1] = mean1;
+    }
+    // ---- cross spectrum of the thread's quads; G replaces signal 0's elements in their registers -------------------------
+    // g[i][0 .. 3] = G at the bins q, M - q, M2 - q, M2 + q
+    C g[NQ][4];
+    double gmax2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int q = tid + i * NT;
+        const bool valid = P::quad_full(i) || q <= M2 / 2;
+        const int qc = res_opaque(valid ? q : 0, gmax2);
+        const int eb = qc == 0 ? 0 : M2 - qc;
+        const uint32_t oq = (uint32_t)qc * 16u, om = (uint32_t)(M2 - qc) * 16u;
+        const C t = res_load16(twm_rs, oq, 0), tk = res_load16(twl_rs, oq, 0);
+        const C dwq[4] = {res_load16(dw_rs, oq, 0), res_load16(dw_rs, om, M2 * 16u), res_load16(dw_rs, om, 0), res_load16(dw_rs, oq, M2 * 16u)};
+        C a1, c1;
+        if (2 * i < SPS) a1 = sp[(2 * i) * NT + tid];
+        else a1 = e10r[2 * i < SPS ? 0 : 2 * i - SPS];
+        if (2 * i + 1 < SPS) c1 = sp[(2 * i + 1) * NT + tid];
+        else c1 = e10r[2 * i + 1 < SPS ? 0 : 2 * i + 1 - SPS];
+        const C b1 = buf[qc], d1 = buf[eb];
+        const C tkm = {-tk.x, tk.y};                     // twl[M - q]  = -conj(twl[q])
+        const C tk2m = {-tk.y, -tk.x};                   // twl[M2 - q] = -i conj(twl[q])
+        const C tk2p = {tk.y, -tk.x};                    // twl[M2 + q] = -i twl[q]
+        C D[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const C sa = s == 0 ? e00[2 * i] : a1, sb = s == 0 ? e01[2 * i] : b1, sc = s == 0 ? e00[2 * i + 1] : c1,
+                    sd = s == 0 ? e01[2 * i + 1] : d1;
+            const double mean = s == 0 ? mean0 : mean1;
+            const C tb = cmul(t, sb), td = cmul(cconj(t), sd);
+            const C Zq = sa + tb, Z2p = sa - tb, ZMq = sc + td, Z2m = sc - td;
+            D[s][0] = gcc_unpack(Zq, ZMq, tk);
+            D[s][1] = gcc_unpack(ZMq, Zq, tkm);
+            D[s][2] = gcc_unpack(Z2m, Z2p, tk2m);
+            D[s][3] = gcc_unpack(Z2p, Z2m, tk2p);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) D[s][n] = {D[s][n].x - mean * dwq[n].x, D[s][n].y - mean * dwq[n].y};
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            g[i][n] = valid ? cmul(cconj(D[0][n]), D[1][n]) : C{0.0, 0.0};
+            gmax2 = fmax(gmax2, g[i][n].x * g[i][n].x + g[i][n].y * g[i][n].y);
+        }
+    }
+    // block maximum (its barriers: every read of the transform array is done)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gmax2 = fmax(gmax2, __shfl_down(gmax2, o, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = gmax2;
+    __syncthreads();
+    gmax2 = red[0];
+#pragma unroll
+    for (int w = 1; w < P::NW; ++w) gmax2 = fmax(gmax2, red[w]);
+    const double gmax = sqrt(gmax2);
+    GCC_STAMP(5);
+    // ---- PHAT weights, Hermitian packing, the radix-2 step of the inverse: all inside the quad --------------------------
+    // (zk, zm) = Zi[k], Zi[M - k] from the weighted cross spectrum at (k, M - k); tk, tm = conj(twl[k]), conj(twl[M - k])
+    auto pack = [&](C A, C B, C tk, C tm, bool edge, C& zk, C& zm) {
+        const double wa = 1.0 / (1e-10 * gmax + sqrt(A.x * A.x + A.y * A.y));
+        const double wb = 1.0 / (1e-10 * gmax + sqrt(B.x * B.x + B.y * B.y));
+        A = {A.x * wa, A.y * wa};
+        B = {B.x * wb, B.y * wb};
+        if (edge) A.y = B.y = 0.0;                       // irfft ignores the imaginary part of the edge bins 0 and M
+        {
+            const C Bc = cconj(B), Sm = A + Bc, Dd = A - Bc, u = cmul(tk, Dd);
+            zk = {0.5 * (Sm.x - u.y), 0.5 * (Sm.y + u.x)};
+        }
+        {
+            const C Ac = cconj(A), Sm = B + Ac, Dd = B - Ac, u = cmul(tm, Dd);
+            zm = {0.5 * (Sm.x - u.y), 0.5 * (Sm.y + u.x)};
+        }
+    };
+    C x1[NE];                                            // the r = 1 inverse input at q and M2 - q, conjugated
+    double chain = gmax;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int q = tid + i * NT;
+        const bool valid = P::quad_full(i) || q <= M2 / 2;
+        const uint32_t oq = (uint32_t)res_opaque(valid ? q : 0, chain) * 16u;
+        const C t = res_load16(twm_rs, oq, 0), tk = res_load16(twl_rs, oq, 0);
+        C zq, zMq, z2m, z2p;
+        // conj(twl[q]), conj(twl[M - q]) = -twl[q]
+        pack(g[i][0], g[i][1], cconj(tk), C{-tk.x, -tk.y}, q == 0, zq, zMq);
+        // conj(twl[M2 - q]) = i twl[q], conj(twl[M2 + q]) = i conj(twl[q])
+        pack(g[i][2], g[i][3], C{-tk.y, tk.x}, C{tk.y, tk.x}, false, z2m, z2p);
+        // element q: Zi[q] +- Zi[M2 + q]; element M2 - q: Zi[M2 - q] +- Zi[M - q]; W_M^{-(M2 - q)} = -twm[q]
+        const C s0q = zq + z2p, s1q = cmul(cconj(t), zq - z2p);
+        const C s0m = z2m + zMq, s1m = cmul(C{-t.x, -t.y}, z2m - zMq);
+        x1[2 * i] = cconj(s1q);
+        x1[2 * i + 1] = cconj(s1m);
+        chain = x1[2 * i + 1].y;                         // (the next quad's table loads wait for this quad's arithmetic)
+        if (valid) {
+            buf[q] = cconj(s0q);
+            if (q > 0) buf[M2 - q] = cconj(s0m);
+        }
+    }
+    __syncthreads();
+    GCC_STAMP(6);
+    // ---- inverse sub-transforms: z[2 m + r] = (1/M) conj(FFT_M2(conj input_r))[m] ---------------------------------------
+    static_fft_forward<double, NT, 6, 10, 10, 10>(buf, tws, tid);
+    const double inv = 1.0 / (double)M;
+    C o0[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int m = tid + j * NT;
+        o0[j] = C{0.0, 0.0};
+        if (P::slot_full(j) || m < M2) {
+            const C v = buf[m];
+            o0[j] = C{v.x * inv, -v.y * inv};
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int q = tid + i * NT;
+        if (P::quad_full(i) || q <= M2 / 2) {
+            buf[q] = x1[2 * i];
+            if (q > 0) buf[M2 - q] = x1[2 * i + 1];
+        }
+    }
+    __syncthreads();
+    static_fft_forward<double, NT, 6, 10, 10, 10>(buf, tws, tid);
+    GCC_STAMP(7);
+    const res_rsrc out_rs = res_make_rsrc(a.xcorr + (size_t)pair * L);
+    double best = -1.0;
+    int besti = 0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int m = tid + j * NT;
+        if (P::slot_full(j) || m < M2) {
+            const C v = buf[m];
+            const C o1 = C{v.x * inv, -v.y * inv};
+            const int t = 4 * m;                          // samples t .. t + 3 = (z[2 m], z[2 m + 1])
+            const uint32_t soff = (uint32_t)j * (NT * 32u);
+            res_store16(out_rs, (uint32_t)tid * 32u, soff, o0[j].x, o0[j].y);
+            res_store16(out_rs, (uint32_t)tid * 32u + 16u, soff, o1.x, o1.y);
+            // ascending t within a thread: a later equal magnitude does not replace the first
+            if (fabs(o0[j].x) > best) { best = fabs(o0[j].x); besti = t; }
+            if (fabs(o0[j].y) > best) { best = fabs(o0[j].y); besti = t + 1; }
+            if (fabs(o1.x) > best) { best = fabs(o1.x); besti = t + 2; }
+            if (fabs(o1.y) > best) { best = fabs(o1.y); besti = t + 3; }
+        }
+    }
+    // ---- argmax |xcorr| (first index on ties, as numpy.argmax) -----------------------------------------------------------
+    if (a.argmax) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_down(best, o, 64);
+            const int oi = __shfl_down(besti, o, 64);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { red[tid >> 6] = best; redi[tid >> 6] = besti; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < P::NW; ++w)
+                if (red[w] > best || (red[w] == best && redi[w] < besti)) { best = red[w]; besti = redi[w]; }
+            a.argmax[pair] = besti;
+        }
+    }
+    GCC_STAMP(8);
+}
+
+}  // namespace frt

@@ -50,6 +50,10 @@ int frt_is_device_pointer(const void* p);
  * rule).  Both paths of every option compute the same reference function and are held to the same parity bar:
  *   "gcc_one_workgroup"    frt_gcc_phat: 1 = one workgroup per window pair whatever the batch size, 0 = a pair as launches
  *                          of its phases (default: by batch size)
+ *                          (also read by frt_gcc_create: a handle of at most CUs / 8 pairs of the default window made while the
+ *                          option is 1 gets the two-way plan of the large batches instead of the four-way plan of the small ones)
+ *   "gcc_resident"         frt_gcc_phat, default window (24000 samples), one workgroup per pair: 0 = the kernel that parks the
+ *                          sub-spectra in a scratch slab in HBM instead of the one that keeps them in registers and LDS
  *   "gcc_any_length"       frt_gcc_create: 1 = the chirp-z transform also for lengths the mixed-radix plan serves
  *   "ola_chunk_kernels"    frt_octbank_filter (mode 1, one block of <= 1024 host samples): 0 = per-stage transform launches
  *                          instead of the two running-convolution launches

@@ -103,6 +103,27 @@ def test_bench_rank_logic_two_ranks_gloo():
         assert v["value"] > 0 and v["cores"] == 1 and v["all_cores"]["value"] > 0 and v["sample"]
 
 
+def test_bench_gpus_2_starts_itself_without_a_launcher():
+    """plain `python bench.py --gpus 2` (no torchrun, WORLD_SIZE unset) re-executes itself under
+    torch.distributed.run — one JSON line from rank 0 with both ranks seen, the same record as the contract's launch line."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--stub-engine", "--log2-samples", "14", "--batches", "2", "--cpu-budget", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(root), env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == [0, 1] and rec["steps"] == 3 and rec["warmup"] == 1
+    F = (2 ** 14 - 1024) // 512 + 1
+    assert rec["config"]["channels"] == 2 and rec["config"]["spectra_per_step"] == 2 * F
+
+
 def test_bench_two_ranks_gloo_with_slab_gather():
     """The optional slab all-gather of SURVEY.md §8e (--gather-slabs): issued asynchronously behind every step, one receive
     buffer per rotating batch, verified against every rank's own slab; per-rank step times are reported next to the

@@ -404,3 +404,59 @@ def test_gcc_four_way_handle_forced_onto_the_one_workgroup_kernel(hip, option):
     assert list(am_phases) == list(am_one) == [11, 11]
     ref, _, _ = dsp.gcc_phat(d0[0].copy(), d1[0].copy())
     assert np.max(np.abs(x_one[0] - ref)) <= 1e-9 * np.max(np.abs(ref))
+
+
+def test_gcc_resident_kernel_equals_the_slab_kernel_and_the_oracle(hip, option):
+    """The default window with one workgroup per pair runs gcc_phat_resident_kernel (csrc/gcc_resident.h): nothing passes through HBM
+    between the signals and the correlation — bins owned by quads, signal 0's sub-spectra parked in registers, signal 1's in LDS.
+    Against gcc_phat_kernel (option gcc_resident = 0: the sub-spectra through a scratch slab) on the same pairs — large and opposite
+    means, an inverted pair, a pair of impulses (a flat cross spectrum) — 1e-12 of the correlation's scale, identical arg-max and means; and
+    the oracle on every pair."""
+    from friture_amd.signal.correlation import GccPhat
+    L, P = 24000, 5
+    rng = np.random.default_rng(606)
+    d0 = 0.25 * rng.standard_normal((P, L)) + rng.uniform(-3.0, 3.0, (P, 1))
+    d1 = np.roll(d0, 37, axis=1) + 0.05 * rng.standard_normal((P, L)) - 1.5
+    d1[2] = -d1[2]
+    d0[4] = 0.0
+    d0[4, 5000] = 1.0
+    d1[4] = 0.0
+    d1[4, 5063] = 0.5
+    option("gcc_one_workgroup", 1)
+    g = GccPhat(L, P)
+    x_res, am_res = g.correlate(d0.copy(), d1.copy())
+    option("gcc_resident", 0)
+    x_slab, am_slab = g.correlate(d0.copy(), d1.copy())
+    option("gcc_resident", -1)
+    scale = np.max(np.abs(x_slab))
+    assert np.max(np.abs(x_res - x_slab)) <= 1e-12 * scale, np.max(np.abs(x_res - x_slab)) / scale
+    assert list(am_res) == list(am_slab)
+    for p in range(P):
+        ref, _, _ = dsp.gcc_phat(d0[p].copy(), d1[p].copy())
+        assert np.max(np.abs(x_res[p] - ref)) <= 1e-9 * np.max(np.abs(ref)), p
+        assert int(am_res[p]) == int(np.argmax(np.abs(ref)))
+    assert list(am_res[:4]) == [37] * 4 and int(am_res[4]) == 63 and x_res[2, 37] < 0 < x_res[0, 37]
+
+
+def test_gcc_resident_kernel_on_windows_that_are_views(hip, option):
+    """Device windows that start 8 bytes off a 16-byte boundary (views into a ring): the resident kernel's 16-byte buffer accesses
+    need 4-byte alignment only — same correlation as the aligned copy, bit for bit."""
+    import torch
+    from friture_amd.signal.correlation import GccPhat
+    L, P = 24000, 3
+    rng = np.random.default_rng(11)
+    d0 = 0.25 * rng.standard_normal((P, L))
+    d1 = np.roll(d0, 21, axis=1) + 0.05 * rng.standard_normal((P, L))
+    option("gcc_one_workgroup", 1)
+    g = GccPhat(L, P)
+    dev = torch.device("cuda", 0)
+    a0, a1 = torch.from_numpy(d0).to(dev), torch.from_numpy(d1).to(dev)
+    x_al, am_al = g.correlate(a0, a1)
+    x_al = x_al.clone()
+    pad0, pad1 = torch.zeros(P * L + 1, dtype=torch.float64, device=dev), torch.zeros(P * L + 1, dtype=torch.float64, device=dev)
+    pad0[1:] = a0.reshape(-1)
+    pad1[1:] = a1.reshape(-1)
+    v0, v1 = pad0[1:].view(P, L), pad1[1:].view(P, L)
+    assert v0.data_ptr() % 16 == 8
+    x_un, am_un = g.correlate(v0, v1)
+    assert torch.equal(x_un, x_al) and list(am_un.cpu().numpy()) == list(am_al.cpu().numpy()) == [21] * P

@@ -1,4 +1,4 @@
-"""GCC-PHAT batch throughput (kernel K5): windows/s against the batch size, both launch shapes (one workgroup per pair /
+"""GCC-PHAT batch throughput (kernel K5): windows/s against the batch size, the launch shapes (one workgroup per pair: the resident kernel and the one with the scratch slab /
 a pair's sub-transforms as workgroups of their own), device-resident float64 windows of L samples.
 
     python tools/bench_gcc.py [--length 24000] [--pairs 1 4 16 32 64 100 256 1024]
@@ -32,8 +32,9 @@ def main():
         d1 = np.roll(d0, 37, axis=1) + 0.025 * rng.standard_normal((pairs, L))
         a0, a1 = torch.from_numpy(d0).to(dev), torch.from_numpy(d1).to(dev)
         row = {}
-        for shape, opt in (("default", -1), ("one_workgroup", 1), ("split", 0)):
+        for shape, opt, res in (("default", -1, -1), ("one_workgroup", 1, -1), ("one_workgroup_slab", 1, 0), ("split", 0, -1)):
             _lib.set_option("gcc_one_workgroup", opt)
+            _lib.set_option("gcc_resident", res)
             g = GccPhat(L, pairs)
             for _ in range(3):
                 _, am = g.correlate(a0, a1)
@@ -47,6 +48,7 @@ def main():
             ms = e0.elapsed_time(e1) / args.iters
             row[shape] = {"ms": ms, "windows_per_s": pairs / ms * 1e3, "delay_found": bool(int(am[0]) == 37)}
         _lib.set_option("gcc_one_workgroup", -1)
+        _lib.set_option("gcc_resident", -1)
         res[str(pairs)] = row
         print(pairs, {k: (round(v["ms"], 4), round(v["windows_per_s"])) for k, v in row.items()}, flush=True)
     print(json.dumps(res))
