@@ -83,9 +83,57 @@ def kernel_source_digest() -> str:
     return h.hexdigest()[:16]
 
 
+# Kernel sources behind each leg: a leg's PMC traffic figure (profiles/r06_leg_traffic.json, tools/leg_traffic.py) is quoted only while
+# the code of these files is what it was measured on.
+LEG_SOURCES = {
+    "configs4_gcc_phat_1024_pairs": ["gcc.hip", "gcc_resident.h", "fft_static.h", "fft_mixed.h"],
+    "configs4_gcc_phat": ["gcc.hip", "gcc_resident.h", "fft_static.h", "fft_mixed.h"],
+    "configs2_bank_iir_time_parallel": ["iir.hip", "octbank.h"],
+    "configs4_bank_iir_time_parallel": ["iir.hip", "octbank.h"],
+    "configs2_bank_fir_overlap_add": ["ola.hip", "ola_wave.h", "octbank.h"],
+    "configs4_bank_fir_overlap_add": ["ola.hip", "ola_wave.h", "octbank.h"],
+    "configs3_stft16384_psd": ["stft_pk16.h", "stft_pk.h", "fft_core.h"],
+    "configs3_stft16384_image": ["stft_pk16.h", "stft_pk.h", "fft_core.h"],
+    "configs3_stft16384_hop4096_psd": ["stft_pk16.h", "stft_pk.h", "fft_core.h"],
+    "configs3_stft16384_hop4096_image": ["stft_pk16.h", "stft_pk.h", "fft_core.h"],
+    "configs1_f64_psd": ["stft_wave.h", "fft_core.h"],
+    "configs1_f64_image": ["stft_wave.h", "fft_core.h"],
+}
+
+
+def sources_digest(names) -> str:
+    """sha256 of the code (comments and blank lines removed) of the named files under friture_amd/csrc, 16 hex digits."""
+    import re
+    h = hashlib.sha256()
+    for name in names:
+        text = (ROOT / "friture_amd" / "csrc" / name).read_text()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        lines = [re.sub(r"//[^\n]*", "", ln).rstrip() for ln in text.splitlines()]
+        h.update("\n".join(ln for ln in lines if ln.strip()).encode())
+    return h.hexdigest()[:16]
+
+
+_LEG_TRAFFIC = None
+
+
+def leg_traffic(leg_name: str):
+    """HBM bytes per step of a leg's kernels from the committed PMC record (profiles/r06_leg_traffic.json), or None when the record
+    is missing or was measured on other kernel sources (tests/test_evidence_fresh.py keeps it fresh)."""
+    global _LEG_TRAFFIC
+    if _LEG_TRAFFIC is None:
+        try:
+            _LEG_TRAFFIC = json.loads((ROOT / "profiles" / "r06_leg_traffic.json").read_text()).get("legs", {})
+        except Exception:
+            _LEG_TRAFFIC = {}
+    for rec in _LEG_TRAFFIC.values():
+        if leg_name in rec.get("bench_legs", []) and rec.get("kernel_sources") == sources_digest(LEG_SOURCES[leg_name]):
+            return rec.get("hbm_bytes_per_call")
+    return None
+
+
 # Keys whose values are prose: they say how a figure was obtained, which DESIGN.md §6 and this file's docstrings also say.  They
 # stay in the full record (--full-json) and leave the printed line, which the driver keeps only the last ~8 KB of.
-PROSE_KEYS = frozenset({"mode", "model", "f64_note", "note", "traffic_note"})
+PROSE_KEYS = frozenset({"mode", "model", "f64_note", "note", "traffic_note", "bytes_model"})
 LINE_BUDGET = 7000
 
 
@@ -105,7 +153,7 @@ def compact_line(result: dict) -> dict:
     for k in ("value", "ms_per_step"):              # the contract's own figures keep their digits (value x ms_per_step is checked)
         if k in result:
             out[k] = result[k]
-    roof_keys = ("bound", "kernel", "achieved", "frac", "kernel_ms", "hbm_frac", "f64_frac")      # (unit and peak follow from `bound`)
+    roof_keys = ("bound", "kernel", "achieved", "frac", "traffic", "frac_on_survey_bytes", "kernel_ms", "hbm_frac", "f64_frac")      # (unit and peak follow from `bound`)
     parity_keys = ("frames_checked", "pixels_mismatched", "mismatch_unaccounted", "epilogue_mismatch_outside_edge",
                    "psd_rel_max", "gate")
 
@@ -292,7 +340,7 @@ def octave_legs(dev, world, rank, ch, bpo, log2n, tag, with_sequential):
         dt, ev_ms = leg(lambda k: bank.energies(x, 1024, alphas, out=out), steps, dev, distributed, torch)
         legs[f"{tag}_{name}"] = {"value": units / dt, "unit": "octave-bands/s", "ms_per_step": dt * 1e3, "mode": mode,
                                  "config": f"{ch} ch x 2^{log2n}, {9 * bpo} bands, energies / 1024 samples",
-                                 "roofline": dict({"algorithmic_bytes_per_step": alg_bytes,
+                                 "roofline": dict({"algorithmic_bytes_per_step": alg_bytes, "traffic": leg_traffic(f"{tag}_{name}"),
                                                    "hbm_frac": alg_bytes / dt / 1e9 / HBM_PEAK_GBS,
                                                    "algorithmic_flops_per_step": survey_flops,
                                                    "f64_tflops": survey_flops / dt / 1e12,
@@ -358,6 +406,7 @@ def stft16384_leg(dev, world, rank, consts):
                 "config": f"{ch} ch x 2^20, N {n_fft}, hop {hop}, {'pixels' if kind == 3 else 'PSD'}",
                 "roofline": {"bound": "hbm", "kernel": "stft_pk16_kernel", "unit": "GB/s", "achieved": bytes_per_launch / (ev_ms * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "frac": bytes_per_launch / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": leg_traffic(f"configs3_stft16384{tag}_{name}"),
                              "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": ev_ms}}
             del outs
         del eng
@@ -393,6 +442,7 @@ def stft1024_f64_leg(dev, world, rank, consts):
                "config": f"1 ch x 2^25, N {n_fft}, hop {hop}, f64 -> {'pixels' if kind == 3 else 'f64 PSD'}, split rows",
                "roofline": {"bound": "hbm", "kernel": "stft_kernel<double>", "unit": "GB/s", "achieved": bytes_per_launch / (ev_ms * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "frac": bytes_per_launch / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "traffic": leg_traffic(f"configs1_f64_{name}"),
                             "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_spectrum": 8 * hop + out_bytes * nb,
                             "kernel_ms": ev_ms}}
         if rank == 0:
@@ -438,8 +488,12 @@ def gcc_leg(dev, world, rank):
         flops = pairs * 3 * 5.0 * 12000 * np.log2(12000.0)
         out[name] = {"value": world * pairs / dt, "unit": "windows/s", "ms_per_step": dt * 1e3,
                      "config": f"{pairs} pairs, L {L}, f64", "delay_37_found": bool(int(am[0]) == 37),
-                     "roofline": {"bound": "hbm", "kernel": "gcc_fwd/cross/pack/inv kernels" if pairs <= 160 else "gcc_phat_kernel",
-                                  "unit": "GB/s", "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBS, "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS,
+                     "roofline": {"bound": "hbm", "kernel": "gcc_phat_resident_kernel", "unit": "GB/s", "achieved": nbytes / dt / 1e9,
+                                  "peak": HBM_PEAK_GBS, "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS,
+                                  "traffic": leg_traffic(name),
+                                  "bytes_model": "24 L per window pair: two float64 windows read, one float64 correlation written (576 000 B); "
+                                                 "SURVEY.md §8d's 288 000 B counts float32 samples, the reference computes in float64",
+                                  "frac_on_survey_bytes": pairs * 12 * L / dt / 1e9 / HBM_PEAK_GBS,
                                   "algorithmic_bytes_per_step": nbytes, "algorithmic_flops_per_step": flops,
                                   "f64_tflops": flops / dt / 1e12, "f64_frac": flops / dt / 1e12 / F64_VECTOR_PEAK_TFLOPS}}
         del a0, a1, g
@@ -632,6 +686,15 @@ def main():
     same_batch_ms = None
     if nbatch > 1:
         same_batch_ms = distributed.max_over_ranks(timed(lambda k: step(k, False), args.steps, dev, distributed, torch)[1], dev)
+    # the same launches into packed rows [F][N/2+1] (frt_stft_run, the layout the drop-in classes hand on): both layouts in one line
+    packed_ms = None
+    if split and not stub:
+        packed = [torch.empty((len(my_channels), F, n_fft // 2 + 1), dtype=odt, device=dev) for _ in range(nbatch)]
+        pstep = lambda k: eng.run(kind, xs[k % nbatch], packed[k % nbatch])       # noqa: E731
+        for k in range(args.warmup):
+            pstep(k)
+        packed_ms = distributed.max_over_ranks(timed(pstep, args.steps, dev, distributed, torch)[1], dev)
+        del packed
     # the same transform with its plain PSD output (no dB / weighting / colour epilogue), for reference
     psd_ms = None
     if kind == 3 and not stub:
@@ -699,6 +762,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "layout": "split" if split else "packed",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -735,6 +799,10 @@ def main():
             result["psd_output"] = {"kernel_ms": psd_ms, "spectra_per_s": spectra_per_step / (psd_ms * 1e-3),
                                     "frac_of_hbm_peak": bytes_per_launch / (psd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "note": "same batches, float PSD written instead of colour pixels (same byte counts); on aligned rows this kind runs the LDS-ring instance of the kernel, the colour kind the register-window instance — bit-identical spectra"}
+        if packed_ms is not None:
+            result["packed_rows"] = {"kernel_ms": packed_ms, "spectra_per_s": spectra_per_step / (packed_ms * 1e-3),
+                                     "frac_of_hbm_peak": bytes_per_launch / (packed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "note": "same batches and kind through frt_stft_run: rows [F][N/2+1], the layout of rounds 1-4's headline and of the drop-in classes"}
         if same_batch_ms is not None:
             result["same_batch"] = {"kernel_ms": same_batch_ms, "spectra_per_s": spectra_per_step / (same_batch_ms * 1e-3) / 1.0,
                                     "note": "the same batch every step (what a naive loop measures); not the headline"}

@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) gcc_window_rfft_kernel(const double* __re
 }  // namespace frt
 #include "gcc_resident.h"
 #ifndef FRT_GCC_RES_THREADS
-#define FRT_GCC_RES_THREADS 768
+#define FRT_GCC_RES_THREADS 512
 #endif
 constexpr int kResThreads = FRT_GCC_RES_THREADS;
 namespace frt {
@@ -1334,13 +1334,17 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
     a.psum = st == 2 ? h->psum.as<double>() : nullptr;
     a.n_pairs = h->n_pairs;
     const int force = option(kOptGccOneWorkgroup);
-    const bool split = force >= 0 ? force == 0 : (long long)h->n_pairs * 8 <= 5ll * device_cu_count();
     // the default window, one workgroup per pair: nothing passes through HBM between the signals and the correlation (gcc_resident.h)
-    const bool resident = !split && st == 1 && h->R == 2 && option(kOptGccResident) != 0;
+    const bool can_reside = st == 1 && h->R == 2 && option(kOptGccResident) != 0;
+    // A pair as launches of its own phases while the batch leaves most CUs idle: below a quarter of a workgroup per CU when the
+    // resident kernel serves the window (measured, profiles/r06_gcc_batch.txt: 32 pairs 57 against 69 us, 64 pairs 73 = 73, 100 pairs
+    // 84 against 77, 160 pairs 136 against 82), below 5/8 with the slab kernel (round 3: crossover between 100 and 256 pairs)
+    const bool split = force >= 0 ? force == 0 : can_reside ? (long long)h->n_pairs * 4 < (long long)device_cu_count()
+                                                             : (long long)h->n_pairs * 8 <= 5ll * device_cu_count();
+    const bool resident = !split && can_reside;
     if (!resident && (rc = h->scratch.reserve((size_t)h->n_pairs * (4 * (size_t)h->M + 2) * 2 * sizeof(double)))) return rc;
     a.scratch = h->scratch.as<double>();
     if (split) {
-        // up to 5/8 of a workgroup per CU (160 pairs on 256 CUs; measured crossover between 100 and 256): a pair as launches of its own phases
         if ((rc = h->gmax.reserve((size_t)h->n_pairs * 8))) return rc;
         unsigned long long* gm = h->gmax.as<unsigned long long>();
         if ((rc = h->part_val.reserve((size_t)h->n_pairs * h->R * sizeof(double))) || (rc = h->part_idx.reserve((size_t)h->n_pairs * h->R * sizeof(int))))

@@ -71,6 +71,55 @@ __device__ __forceinline__ int res_opaque(int v, double& chain) {
     return v;
 }
 
+// The 6000-point transform, 6 x 10 x 10 x 10 as fft_static.h has it (same tables), with the powers of a butterfly's twiddle formed as a
+// chain w, w w1, ... and applied as they are formed: two factors alive instead of the ten of the log-depth scheme — the transform
+// runs in 106 / 74 registers (512 / 768 threads) instead of 120 / 80, which is what the parked sub-spectra leave it.
+template <int NT, int R, int P>
+__device__ __forceinline__ void res_pass(cpx<double>* buf, const cpx<double>* __restrict__ tw, int tid) {
+    using C = cpx<double>;
+    constexpr int NB = kResM2 / R;                     // butterflies
+    constexpr int B = (NB + NT - 1) / NT;              // per thread
+    C v[B][R];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const int j = tid + b * NT;
+        if (B * NT == NB || j < NB) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) v[b][q] = buf[j + q * NB];
+            if constexpr (P > 1) {
+                const C w1 = tw[j % P];
+                C w = w1;
+                v[b][1] = cmul(v[b][1], w);
+#pragma unroll
+                for (int q = 2; q < R; ++q) {
+                    w = cmul(w, w1);
+                    v[b][q] = cmul(v[b][q], w);
+                }
+            }
+            dft_static<double, R>(v[b]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const int j = tid + b * NT;
+        if (B * NT == NB || j < NB) {
+            const int k = P > 1 ? j % P : 0;
+            const int base = (j - k) * R + k;
+#pragma unroll
+            for (int q = 0; q < R; ++q) buf[base + q * P] = v[b][q];
+        }
+    }
+    __syncthreads();
+}
+template <int NT>
+__device__ __forceinline__ void res_fft(cpx<double>* buf, const cpx<double>* __restrict__ tws, int tid) {
+    res_pass<NT, 6, 1>(buf, tws, tid);
+    res_pass<NT, 10, 6>(buf, tws, tid);               // tables of the passes concatenated (make_static_twiddles): 6, 60, 600 entries
+    res_pass<NT, 10, 60>(buf, tws + 6, tid);
+    res_pass<NT, 10, 600>(buf, tws + 66, tid);
+}
+
 // One signal, read once: (x w) of the even sample pairs into the transform array, of the odd ones into the thread's slots of the
 // second array (the last slots: registers).  Returns the sum of the thread's samples (the mean leaves in the spectrum: rfft((x - m) w)
 // = rfft(x w) - m rfft(w)).  Two batches of slots: 2 x 2 x NS / 2 loads of 16 bytes in flight per thread.
@@ -177,20 +226,20 @@ __global__ void __launch_bounds__(NT) gcc_phat_resident_kernel(const GccArgs a) 
     leave_sum(res_load_signal<NT>(sig0, wrs, buf, sp, Y, tid), 0);
     __syncthreads();
     GCC_STAMP(1);
-    static_fft_forward<double, NT, 6, 10, 10, 10>(buf, tws, tid);
+    res_fft<NT>(buf, tws, tid);
     GCC_STAMP(2);
     res_take_quads<NT>(buf, e00, tid);
     __syncthreads();
     res_second_half<NT>(buf, sp, Y, tid);
     __syncthreads();
-    static_fft_forward<double, NT, 6, 10, 10, 10>(buf, tws, tid);
+    res_fft<NT>(buf, tws, tid);
     res_take_quads<NT>(buf, e01, tid);
     __syncthreads();
     GCC_STAMP(3);
     // ---- signal 1: first sub-spectrum into the second LDS array (the thread's first SPS elements) and registers (the others) --
     leave_sum(res_load_signal<NT>(sig1, wrs, buf, sp, Y, tid), 16);
     __syncthreads();
-    static_fft_forward<double, NT, 6, 10, 10, 10>(buf, tws, tid);
+    res_fft<NT>(buf, tws, tid);
     C e10r[NE - SPS];
     {
         C te[NE];
@@ -204,7 +253,7 @@ __global__ void __launch_bounds__(NT) gcc_phat_resident_kernel(const GccArgs a) 
         }
     }
     __syncthreads();
-    static_fft_forward<double, NT, 6, 10, 10, 10>(buf, tws, tid);
+    res_fft<NT>(buf, tws, tid);
     GCC_STAMP(4);
     // ---- the means ---------------------------------------------------------------------------------------------------------
     double mean0 = 0.0, mean1 = 0.0;                     // (the sums were left before barriers long past)
@@ -317,7 +366,7 @@ __global__ void __launch_bounds__(NT) gcc_phat_resident_kernel(const GccArgs a) 
     __syncthreads();
     GCC_STAMP(6);
     // ---- inverse sub-transforms: z[2 m + r] = (1/M) conj(FFT_M2(conj input_r))[m] ---------------------------------------
-    static_fft_forward<double, NT, 6, 10, 10, 10>(buf, tws, tid);
+    res_fft<NT>(buf, tws, tid);
     const double inv = 1.0 / (double)M;
     C o0[NS];
 #pragma unroll
@@ -339,7 +388,7 @@ __global__ void __launch_bounds__(NT) gcc_phat_resident_kernel(const GccArgs a) 
         }
     }
     __syncthreads();
-    static_fft_forward<double, NT, 6, 10, 10, 10>(buf, tws, tid);
+    res_fft<NT>(buf, tws, tid);
     GCC_STAMP(7);
     const res_rsrc out_rs = res_make_rsrc(a.xcorr + (size_t)pair * L);
     double best = -1.0;

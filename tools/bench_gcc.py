@@ -32,9 +32,9 @@ def main():
         d1 = np.roll(d0, 37, axis=1) + 0.025 * rng.standard_normal((pairs, L))
         a0, a1 = torch.from_numpy(d0).to(dev), torch.from_numpy(d1).to(dev)
         row = {}
-        for shape, opt, res in (("default", -1, -1), ("one_workgroup", 1, -1), ("one_workgroup_slab", 1, 0), ("split", 0, -1)):
+        for shape, opt, resident in (("default", -1, -1), ("one_workgroup", 1, -1), ("one_workgroup_slab", 1, 0), ("split", 0, -1)):
             _lib.set_option("gcc_one_workgroup", opt)
-            _lib.set_option("gcc_resident", res)
+            _lib.set_option("gcc_resident", resident)
             g = GccPhat(L, pairs)
             for _ in range(3):
                 _, am = g.correlate(a0, a1)

@@ -11,8 +11,8 @@ for leg in $LEGS; do
   mkdir -p $OUT/$leg
   for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
     n=$(echo $pass | cut -d' ' -f1)
-    timeout 300 rocprofv3 --kernel-trace --pmc $pass -d $OUT/$leg/$n -o p --output-format csv -- python $R/tools/leg_traffic.py run $leg --calls 4 --out $OUT/$leg > $OUT/$leg/$n.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $pass -d $OUT/$leg/$n -o p --output-format csv -- python $R/tools/leg_traffic.py run $leg --calls 4 --out $OUT/$leg ${LEG_TRAFFIC_ARGS:-} > $OUT/$leg/$n.log 2>&1
     echo "leg $leg pass $n rc=$?"
   done
 done
-cd $R && python tools/leg_traffic.py collect $OUT && cp profiles/r06_leg_traffic.json $OUT/
+cd $R && python tools/leg_traffic.py collect $OUT ${LEG_TRAFFIC_JSON:-} && cp ${LEG_TRAFFIC_JSON:-profiles/r06_leg_traffic.json} $OUT/

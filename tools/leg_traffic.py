@@ -14,7 +14,6 @@ number of calls): one-off table kernels of handle creation are listed apart."""
 import collections
 import csv
 import glob
-import hashlib
 import json
 import os
 import re
@@ -27,39 +26,20 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 CSRC = ROOT / "friture_amd" / "csrc"
 
-# leg -> (bench.py leg names it serves, kernel sources whose code the figure belongs to)
-LEGS = {
-    "gcc1024": (["configs4_gcc_phat_1024_pairs"], ["gcc.hip", "gcc_resident.h", "fft_static.h", "fft_mixed.h"]),
-    "gcc100": (["configs4_gcc_phat"], ["gcc.hip", "gcc_resident.h", "fft_static.h", "fft_mixed.h"]),
-    "iir3": (["configs2_bank_iir_time_parallel"], ["iir.hip", "octbank.h"]),
-    "iir24": (["configs4_bank_iir_time_parallel"], ["iir.hip", "octbank.h"]),
-    "ola3": (["configs2_bank_fir_overlap_add"], ["ola.hip", "ola_wave.h", "octbank.h"]),
-    "ola24": (["configs4_bank_fir_overlap_add"], ["ola.hip", "ola_wave.h", "octbank.h"]),
-    "stft16384_psd": (["configs3_stft16384_psd"], ["stft_pk16.h", "stft_pk.h", "fft_core.h"]),
-    "stft16384_image": (["configs3_stft16384_image"], ["stft_pk16.h", "stft_pk.h", "fft_core.h"]),
-    "stft16384_hop4096_psd": (["configs3_stft16384_hop4096_psd"], ["stft_pk16.h", "stft_pk.h", "fft_core.h"]),
-    "stft16384_hop4096_image": (["configs3_stft16384_hop4096_image"], ["stft_pk16.h", "stft_pk.h", "fft_core.h"]),
-    "f64_psd": (["configs1_f64_psd"], ["stft_wave.h", "fft_core.h"]),
-    "f64_image": (["configs1_f64_image"], ["stft_wave.h", "fft_core.h"]),
-}
+import bench  # noqa: E402  (LEG_SOURCES, sources_digest: the digest bench.py checks before quoting a figure)
 
-
-def source_digest(names) -> str:
-    """sha256 of the code (comments and blank lines removed) of the named files under friture_amd/csrc, 16 hex digits."""
-    h = hashlib.sha256()
-    for name in names:
-        text = (CSRC / name).read_text()
-        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        lines = [re.sub(r"//[^\n]*", "", ln).rstrip() for ln in text.splitlines()]
-        h.update("\n".join(ln for ln in lines if ln.strip()).encode())
-    return h.hexdigest()[:16]
+# leg of this tool -> the bench.py leg it serves
+LEGS = {"gcc1024": "configs4_gcc_phat_1024_pairs", "gcc100": "configs4_gcc_phat", "iir3": "configs2_bank_iir_time_parallel",
+        "iir24": "configs4_bank_iir_time_parallel", "ola3": "configs2_bank_fir_overlap_add", "ola24": "configs4_bank_fir_overlap_add",
+        "stft16384_psd": "configs3_stft16384_psd", "stft16384_image": "configs3_stft16384_image",
+        "stft16384_hop4096_psd": "configs3_stft16384_hop4096_psd", "stft16384_hop4096_image": "configs3_stft16384_hop4096_image",
+        "f64_psd": "configs1_f64_psd", "f64_image": "configs1_f64_image"}
 
 
 def workload(leg):
     """(callable of one call, algorithmic HBM bytes per call) — the same shapes as bench.py's legs."""
     import torch
 
-    import bench
     from friture_amd import _lib, filter_design, palette, tables
     dev = torch.device("cuda", 0)
     _lib.init(0)
@@ -130,9 +110,10 @@ def run(leg, calls, out_dir=None):
     print(f"leg {leg}: {calls} calls")
 
 
-def collect(root):
+def collect(root, out_path=None):
     rec = {}
-    for leg, (bench_legs, sources) in LEGS.items():
+    for leg, bench_leg in LEGS.items():
+        bench_legs, sources = [bench_leg], bench.LEG_SOURCES[bench_leg]
         files = glob.glob(os.path.join(root, leg, "*", "**", "*counter_collection.csv"), recursive=True)
         if not files:
             continue
@@ -161,7 +142,7 @@ def collect(root):
         dominant = max(kernels, key=lambda k: kernels[k]["read_bytes_per_call"] + kernels[k]["write_bytes_per_call"])
         alg_file = Path(root) / leg / "algorithmic_bytes"
         alg = float(alg_file.read_text()) if alg_file.exists() else None
-        rec[leg] = {"bench_legs": bench_legs, "kernel_sources": source_digest(sources), "sources": sources, "calls": calls,
+        rec[leg] = {"bench_legs": bench_legs, "kernel_sources": bench.sources_digest(sources), "sources": sources, "calls": calls,
                     "hbm_bytes_per_call": total, "read_bytes_per_call": sum(k["read_bytes_per_call"] for k in kernels.values()),
                     "write_bytes_per_call": sum(k["write_bytes_per_call"] for k in kernels.values()),
                     "algorithmic_bytes_per_call": alg, "ratio": total / alg if alg else None,
@@ -170,7 +151,7 @@ def collect(root):
                      "of the kernels launched in every call, summed per call; FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md "
                      "(128-byte requests tallied at 64 B), WRITE_SIZE (KB) as is; check_* from TCC_EA0_RDREQ / WRREQ request counts",
            "legs": rec}
-    (ROOT / "profiles" / "r06_leg_traffic.json").write_text(json.dumps(out, indent=1) + "\n")
+    Path(out_path or ROOT / "profiles" / "r06_leg_traffic.json").write_text(json.dumps(out, indent=1) + "\n")
     for leg, r in rec.items():
         print(f"{leg:26s} {r['hbm_bytes_per_call'] / 1e6:10.2f} MB/call  algorithmic {(r['algorithmic_bytes_per_call'] or 0) / 1e6:9.2f} MB  "
               f"x{r['ratio'] or 0:.3f}  dominant {r['dominant_kernel'][:60]}")
@@ -183,9 +164,14 @@ def main():
     if sys.argv[1] == "run":
         leg = sys.argv[2]
         calls = int(sys.argv[sys.argv.index("--calls") + 1]) if "--calls" in sys.argv else 4
+        for i, a in enumerate(sys.argv):             # --set-option name=value: force a product code path (A/B records)
+            if a == "--set-option":
+                from friture_amd import _lib
+                name, value = sys.argv[i + 1].split("=")
+                _lib.set_option(name, int(value))
         run(leg, calls, sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None)
     elif sys.argv[1] == "collect":
-        collect(sys.argv[2])
+        collect(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
     else:
         raise SystemExit(__doc__)
 
