@@ -84,6 +84,13 @@ struct IirStageArgs {
     int vec_xnext;                  // likewise the decimated output rows
     int row_energy, quad_energy;    // does any filter of the class feed a band energy?  (the decimator does not: its wavefronts,
                                     // more than half of a 1/3-octave stage, skip the two energy instructions per sample)
+    // lane kernel, look-back form (no iir_scan_kernel launch for the stage): a chunk's true initial state is
+    // e[q-1] + A^L e[q-2] + ... + (A^L)^(K-1) e[q-K] over the zero-state end states of its K predecessors (chunk_end), e[-1] = the
+    // carried state, K = the chunks the filters' decay spans (|A^(L K)| < 1e-20)
+    int lookback;                   // K, or 0: initial states from chunk_init
+    const double* power_l;          // [nfilt][kStates][kStates] row-major A^L of this stage
+    const double* state_in;         // [C][nfilt][kStates] the carried state as it was when the stage began (a snapshot: the last
+                                    // chunk's lane replaces `state` while the first chunks' lanes may still be reading)
 };
 
 __device__ __forceinline__ double dpp_row_bcast0(double v) {
@@ -445,15 +452,58 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
     static_assert(ORD % 2 == 0, "states are read as pairs of doubles");
     double z[NF][ORD], acc[NF], alpha[NF], decay[NF];
     int bandv[NF];
+    typedef const double __attribute__((address_space(4))) * ktable;
 #pragma unroll
     for (int m = 0; m < NF; ++m) {
         const int f = f0 + m;
-        const double* init = a.chunk_init + (((size_t)c * a.nfilt + f) * a.nchunks + qc) * kStates;
+        if (LPC == 1 && a.lookback > 0) {
+            // Round 6: the look-back form — no scan launch in front of this one (19 / 15 us of the two highest-rate stages, nearly
+            // independent of their size).  Horner over the K predecessors' zero-state end states: K - 1 products with the wave-uniform
+            // A^L (scalar loads), a lane's end states 128 contiguous bytes each; ~1-2 % of the chunk's own arithmetic at K = 6 .. 12.
+            const double* ends = a.chunk_end + ((size_t)c * a.nfilt + f) * a.nchunks * kStates;
+            const double* carried = a.state_in + ((size_t)c * a.nfilt + f) * kStates;
+            unsigned long long pw_at = (unsigned long long)(uintptr_t)(a.power_l + (size_t)f * kStates * kStates);
+            auto end_state = [&](int i, double (&e)[ORD]) {       // e[i]: chunk i's zero-state end state; the carried state for i = -1
+                const double* src = i >= 0 ? ends + (size_t)i * kStates : carried;
 #pragma unroll
-        for (int t = 0; t < ORD; t += 2) {
-            const double2 iv = *(const double2*)(init + t);
-            z[m][t] = iv.x;
-            z[m][t + 1] = iv.y;
+                for (int t = 0; t < ORD; t += 2) {
+                    const double2 v = i >= -1 ? *(const double2*)(src + t) : double2{0.0, 0.0};
+                    e[t] = v.x;
+                    e[t + 1] = v.y;
+                }
+            };
+            double zz[ORD], en[ORD];
+            end_state(qc - a.lookback, zz);
+            if (a.lookback > 1) end_state(qc - a.lookback + 1, en);
+            for (int k = a.lookback - 1; k >= 1; --k) {
+                double e[ORD];
+#pragma unroll
+                for (int t = 0; t < ORD; ++t) e[t] = en[t];
+                if (k > 1) end_state(qc - k + 1, en);             // the next step's end state is on its way during this product
+                // (the table's address as a value made in this trip: hoisted out of the loop its ORD x ORD entries — 288 scalar
+                // registers for the decimator — are spilled into vector-register lanes, the pass's coefficients with them)
+                asm volatile("" : "+s"(pw_at));
+                const ktable pw = (ktable)pw_at;
+#pragma unroll
+                for (int r = 0; r < ORD; ++r) {
+                    double sum = e[r];
+#pragma unroll
+                    for (int t = 0; t < ORD; ++t) sum = __builtin_fma(pw[r * kStates + t], zz[t], sum);
+                    e[r] = sum;
+                }
+#pragma unroll
+                for (int t = 0; t < ORD; ++t) zz[t] = e[t];
+            }
+#pragma unroll
+            for (int t = 0; t < ORD; ++t) z[m][t] = zz[t];
+        } else {
+            const double* init = a.chunk_init + (((size_t)c * a.nfilt + f) * a.nchunks + qc) * kStates;
+#pragma unroll
+            for (int t = 0; t < ORD; t += 2) {
+                const double2 iv = *(const double2*)(init + t);
+                z[m][t] = iv.x;
+                z[m][t + 1] = iv.y;
+            }
         }
         // (a stage's band filters carry consecutive band indices: a lane's own is the group's first plus its offset, no
         // lane-indexed read of the argument block)
@@ -466,7 +516,6 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
     // coefficients: wave-uniform, read ONCE through the constant address space (s_load: the table is never written by a
     // kernel; as plain global loads the compiler re-reads all of them every iteration, next to stores it cannot prove
     // disjoint) and used as scalar operands of the multiply-adds
-    typedef const double __attribute__((address_space(4))) * ktable;
     double cb[NF][ORD + 1], ca[NF][ORD + 1];
 #pragma unroll
     for (int m = 0; m < NF; ++m) {
@@ -739,6 +788,15 @@ static bool lane_kernel_serves(const IirStageArgs& a, const int* orders) {
 
 enum LaneWhich { kWhichAll, kWhichBands, kWhichDec };      // the launch's filter groups: every one, the band groups, the decimator
 
+// Does launch_iir_lane take the lane-split form (a filter per lane, the decimator on lane pairs) for this stage?  (Those bodies read
+// their chunks' initial states from chunk_init: no look-back form.)
+static bool lane_split_serves(const IirStageArgs& a, int n_channels, LaneWhich which) {
+    const int n_band = a.dec_filter, groups = (n_band + kLaneBands - 1) / kLaneBands;
+    const long long bx = (long long)n_channels * ((a.nchunks + 63) / 64);
+    const int gy = which == kWhichAll ? groups + 1 : which == kWhichBands ? groups : 1;
+    return which == kWhichAll && bx * gy <= (long long)exp_int("FRT_LANE_SPLIT_BELOW", device_cu_count());
+}
+
 static int launch_iir_lane(const IirStageArgs& a, int n_channels, hipStream_t stream, LaneWhich which) {
     const int n_band = a.dec_filter, groups = (n_band + kLaneBands - 1) / kLaneBands;
     const long long bx = (long long)n_channels * ((a.nchunks + 63) / 64);
@@ -752,7 +810,7 @@ static int launch_iir_lane(const IirStageArgs& a, int n_channels, hipStream_t st
     // it pays only while the chip is mostly idle: with 2.5 wavefronts per SIMD stage 0 of 8 ch x 27 bands takes 168 us against 136 (a
     // filter per LANE means coefficients in vector registers and permutes in the decimator's chain: more issue slots per sample
     // in total), but stages 6-8 go 9.8 / 10.0 / 10.6 -> 7.8 / 7.2 / 6.8 us and a 2-channel call 0.43 -> 0.365 ms.
-    if (which == kWhichAll && bx * gy <= (long long)exp_int("FRT_LANE_SPLIT_BELOW", device_cu_count())) {
+    if (lane_split_serves(a, n_channels, which)) {
         const int sgroups = (n_band + 2) / 3;
         const long long sbx = (long long)n_channels * ((a.nchunks + 20) / 21);
         if (a.in_f32) hipLaunchKernelGGL(iir_lane_split_kernel<true>, dim3((unsigned)sbx, sgroups + 1), dim3(64), 0, stream, a, n_band, sgroups);
@@ -810,6 +868,10 @@ static_assert(kZsRows % kZsRowsPerPass == 0, "row groups tile the padded table")
 #define FRT_ZS_BATCH 8
 #endif
 constexpr int kMaxSlices = 8;
+#ifndef FRT_IIR_LOOKBACK_MAX
+#define FRT_IIR_LOOKBACK_MAX 8
+#endif
+constexpr int kLookbackMax = FRT_IIR_LOOKBACK_MAX;      // chunks an output pass looks back over instead of waiting for a scan launch
 
 struct ZeroStateArgs {
     const void* x;
@@ -825,6 +887,9 @@ struct ZeroStateArgs {
     double* partial;           // [n_slices][C][nfilt][nchunks][kStates]
     long long partial_stride;
     int rt_base, rt_count;     // MFMA kernel: the launch serves row tiles rt_base .. rt_base + rt_count - 1 (tile 0: the decimator)
+    const double* snap_src;    // MFMA kernel: the stage's carried state is copied to snap_dst (snap_count doubles) for the look-back
+    double* snap_dst;          // form of the output pass (IirStageArgs::state_in); null: no copy
+    int snap_count;
 };
 
 // ROWS states x COLS (channel, chunk) columns per lane.  The table row g[k][.] reaches the FMAs through scalar registers,
@@ -943,6 +1008,8 @@ __host__ __device__ inline size_t zs_mfma_index(int k, int row, int row_tiles) {
 template <int kZsTiles>
 __global__ void __launch_bounds__(64) iir_zero_state_mfma_kernel(const ZeroStateArgs a) {
     const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+    if (a.snap_dst && blockIdx.y == 0 && blockIdx.z == 0)                 // (the launch's first plane of workgroups shares the copy)
+        for (long long i = (long long)blockIdx.x * 64 + lane; i < a.snap_count; i += (long long)gridDim.x * 64) a.snap_dst[i] = a.snap_src[i];
     const long long ncols = (long long)a.n_channels * a.nchunks;
     const long long col = (long long)blockIdx.x * 16 + j;
     const bool valid = col < ncols;
@@ -1593,7 +1660,7 @@ extern "C" void frt_octbank_destroy(frt_octbank* h) {
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     frt_ola_destroy(h);
-    DeviceBuffer* bufs[] = {&h->coef, &h->order, &h->state, &h->xin, &h->ypacked, &h->chunk_end, &h->chunk_init, &h->power, &h->zs_table, &h->zs_table_m, &h->zs_rowmap, &h->eseg,
+    DeviceBuffer* bufs[] = {&h->coef, &h->order, &h->state, &h->state_snap, &h->xin, &h->ypacked, &h->chunk_end, &h->chunk_init, &h->power, &h->zs_table, &h->zs_table_m, &h->zs_rowmap, &h->eseg,
                             &h->eblock, &h->alpha, &h->decay_n, &h->smooth, &h->weight, &h->eout};
     for (auto* b : bufs) b->release();
     for (auto& b : h->xbuf) b.release();
@@ -1707,6 +1774,7 @@ static int ensure_powers(frt_octbank* h, int n) {
     std::vector<double> p(2 * per);
     h->sgroup.assign(kNOctave, 1);
     h->shalo.assign(kNOctave, 2);
+    h->slook.assign(kNOctave, 65);
     for (int j = 0; j < kNOctave; ++j) {
         const int cj = stage_chunk(h->chunk0, j);
         const int nj = (len[j] + cj - 1) / cj;
@@ -1714,6 +1782,20 @@ static int ensure_powers(frt_octbank* h, int n) {
         const int g = scan_group_for(h, cj, nj);
         int rg = kScanRowMax;
         while ((2 * g + rg - 1) / rg > kScanRows / 2) rg *= 2;              // at most half of a workgroup's rows are halo
+        // chunks the decay spans, for the look-back form of the output pass: the smallest K with max |A^(L K)| < 1e-20 over the filters
+        {
+            std::vector<double> MK(kStates * kStates);
+            int K = 1;
+            for (; K <= 64; ++K) {
+                double worst = 0.0;
+                for (int f = 0; f < h->nfilt; ++f) {
+                    transition_power(&h->h_coef[(size_t)f * kCoefStride + kMaxOrder + 1], h->h_order[f], (long long)cj * K, MK.data());
+                    for (double v : MK) worst = std::fmax(worst, std::fabs(v));
+                }
+                if (worst < 1e-20) break;
+            }
+            h->slook[j] = K;
+        }
         h->sgroup[j] = g <= rg || exp_env("FRT_IIR_LONG_SCAN_ROWS") ? g : rg;
         h->shalo[j] = g <= rg || exp_env("FRT_IIR_LONG_SCAN_ROWS") ? 2 : (2 * g + rg - 1) / rg;
         for (int f = 0; f < h->nfilt; ++f) {
@@ -1910,6 +1992,19 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
             a.fused = (d_y == nullptr && d_eblock != nullptr && !exact_ops) ? 1 : 0;
             a.n_channels = h->n_channels;
             const bool lane_serves = lane_kernel_serves(a, h->h_order.data());
+            // The look-back form of the output pass (no scan launch) while the decay spans few chunks.  Measured (profiles/r06_iir_lookback.txt,
+            // 8 ch x 27 bands, chunks of 1024): stage 0 (K = 6) output pass 135 -> 142 us for a scan launch of 19 us less; stage 1 (K = 13)
+            // 65 -> 88 us for 15 us less — a Horner step costs a lane 1.4-1.9 us (192 multiply-adds fed through the scalar cache) against
+            // 0.3 us in the scan's DPP rows: it pays up to K = 8 only.
+            static const int look_max = exp_int("FRT_IIR_LOOKBACK_MAX", kLookbackMax);
+            const bool look = lane_serves && !beside && !h->zero_state_by_recurrence && !use_vector_alu && h->slook[j] <= look_max && option(kOptIirLookback) != 0 &&
+                              !lane_split_serves(a, h->n_channels, kWhichAll);
+            if (look) {
+                if ((rc = h->state_snap.reserve((size_t)kNOctave * h->stage_state_elems() * sizeof(double)))) return rc;
+                a.lookback = h->slook[j];
+                a.power_l = h->power.as<double>() + (size_t)j * h->nfilt * kStates * kStates;
+                a.state_in = h->state_snap.as<double>() + (size_t)j * h->stage_state_elems();
+            }
             ZeroStateArgs z{};
             z.x = a.x; z.x_stride = a.x_stride; z.n = a.n; z.in_f32 = a.in_f32;
             z.chunk = a.chunk; z.nchunks = a.nchunks; z.n_channels = h->n_channels; z.nfilt = h->nfilt;
@@ -1923,6 +2018,11 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
             double* const cinit = h->chunk_init.as<double>() + off_init[j];
             z.partial = cend;
             z.partial_stride = slice_stride;
+            if (look) {
+                z.snap_src = a.state;
+                z.snap_dst = h->state_snap.as<double>() + (size_t)j * h->stage_state_elems();
+                z.snap_count = (int)h->stage_state_elems();
+            }
             const long long colwaves = ((long long)h->n_channels * a.nchunks + 15) / 16;
             const size_t per = (size_t)kNOctave * h->nfilt * kStates * kStates, off = (size_t)j * h->nfilt * kStates * kStates;
             const int halo = h->shalo[j], nseg = (a.scan_rows + (kScanRows - halo) - 1) / (kScanRows - halo);
@@ -1941,9 +2041,10 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
                     hipLaunchKernelGGL(iir_slice_sum_range_kernel, dim3((unsigned)((cnt + 255) / 256), h->n_channels), dim3(256), 0, st, cend,
                                        slice_stride, n_slices, h->nfilt, a.nchunks, f0, nf);
                 }
-                hipLaunchKernelGGL(iir_scan_kernel, dim3((unsigned)(h->n_channels * nf * nseg)), dim3(kScanRows * 16), 0, st,
-                                   h->power.as<double>() + off, h->power.as<double>() + per + off, a.state, cend,
-                                   h->order.as<int>(), cinit, h->nfilt, a.nchunks, a.scan_group, a.scan_rows, nseg, halo, f0, nf);
+                if (!look)
+                    hipLaunchKernelGGL(iir_scan_kernel, dim3((unsigned)(h->n_channels * nf * nseg)), dim3(kScanRows * 16), 0, st,
+                                       h->power.as<double>() + off, h->power.as<double>() + per + off, a.state, cend,
+                                       h->order.as<int>(), cinit, h->nfilt, a.nchunks, a.scan_group, a.scan_rows, nseg, halo, f0, nf);
             };
             if (h->zero_state_by_recurrence || use_vector_alu) {
                 // A/B paths of the table product: a second run of the recurrence, or the vector-ALU kernel; every filter in one chain

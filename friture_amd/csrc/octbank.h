@@ -49,6 +49,8 @@ struct frt_octbank {
     std::vector<int> h_order;
     frt::DeviceBuffer coef, order, state;        // state: [9][C][nfilt][16]
     frt::DeviceBuffer xin, ypacked, xbuf[frt::kNOctave], chunk_end, chunk_init, power;
+    frt::DeviceBuffer state_snap;                         // [9][C][nfilt][16] carried states as a stage found them (look-back output pass)
+    std::vector<int> slook;                               // per stage: chunks the filters' decay spans
     std::vector<int> sgroup, shalo;                       // per stage: chunks per scan row, rows the filters' decay spans (iir_scan_kernel)
     frt::DeviceBuffer eseg;                               // per-split carries of the block-energy recurrence (long batches)
     frt::DeviceBuffer zs_table, zs_table_m, zs_rowmap;   // zero-state response tables of the time-parallel mode (iir.hip)

@@ -46,6 +46,12 @@ def _solo() -> bool:
     return dist.get_world_size() == 1 and os.environ.get("FRT_DIST_FORCE", "") != "1"
 
 
+def world_is_one() -> bool:
+    """True when the job is ONE process and nothing forces the collective library (bench.py's timed region then brackets its steps
+    with synchronize alone; with FRT_DIST_FORCE=1 the group of one still goes through RCCL, barriers included)."""
+    return _solo()
+
+
 def init_process_group(backend: str | None = None, device=None):
     """Join the job's process group (RCCL on GPU, gloo on CPU).  No-op for single-process runs (unless FRT_DIST_FORCE=1)."""
     import torch

@@ -468,3 +468,29 @@ def test_randomised_streaming_bit_exact(tabs):
                 assert list(dec) == list(deco)
                 for k in range(9 * bpo):
                     assert np.array_equal(y[c][k], yo[k]), (trial, bpo, C, blk, n, c, k)
+
+
+@pytest.mark.parametrize("bpo,chunk,nblocks", [(3, 1024, 96), (3, 1024, 3), (3, 2048, 40), (24, 512, 64)])
+def test_look_back_output_pass_equals_the_scan_launches(tabs, option, bpo, chunk, nblocks):
+    """Round 6: at the high-rate stages the output pass forms a chunk's true initial state itself — Horner over the zero-state end
+    states of the K chunks the filters' decay spans, the carried state standing in front of chunk 0 — instead of waiting for a
+    chunk-scan launch (csrc/iir.hip, iir_lane_body).  Same recurrence, another association order: the energies of three
+    consecutive calls (carried filter states and smoothed energies; a call shorter than K chunks among the shapes) against the same
+    calls with the option off — 1e-9 relative (measured ~1e-13), far inside the 1e-5 bar the oracle comparisons hold both to."""
+    import torch
+    from friture_amd.filter import IirBank
+    C = 2
+    boct, aoct = list(tabs[f"boct_{bpo}"]), list(tabs[f"aoct_{bpo}"])
+    n = 1024 * nblocks
+    x32 = np.stack([synth("noise", 3 * n, 31), synth("chirp", 3 * n, 32)])
+    alphas, _ = dsp.band_smoothing_setup(bpo, 0.125)
+    xd = torch.from_numpy(x32).cuda()
+    outs = {}
+    for look in (-1, 0):
+        option("iir_lookback", look)
+        bank = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, C)
+        bank.set_chunk(chunk)
+        outs[look] = torch.cat([bank.energies(xd[:, i * n:(i + 1) * n].contiguous(), 1024, alphas) for i in range(3)], dim=1).cpu().numpy().astype(np.float64)
+    a, b = outs[-1], outs[0]
+    assert a.shape == (C, 3 * nblocks, 9 * bpo)
+    assert np.all(np.abs(a - b) <= 1e-9 * np.abs(b) + 1e-14 * b.max()), float(np.max(np.abs(a - b) / (np.abs(b) + 1e-14 * b.max())))

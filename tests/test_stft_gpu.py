@@ -539,3 +539,33 @@ def test_split_rows_full_size_headline_image(engine_cls):
         assert rows.shape == (1, 131071, 512) and rows.data_ptr() % 64 == 0 and rows.stride(1) * rows.element_size() % 64 == 0
         assert torch.equal(rows.view(torch.int32), packed[..., :512].view(torch.int32))
         assert torch.equal(nyq.view(torch.int32), packed[..., 512].view(torch.int32))
+
+
+def test_prepared_launches_equal_run_and_run_split(hip):
+    """StftEngine.prepare: a repeated launch whose shapes, pointers and stream were taken once — the callable is one
+    frt_stft_run / frt_stft_run_split call.  Bit-identical to run() / run_split() on the same buffers, both layouts, two kinds; wrong
+    shapes are refused at prepare time."""
+    import torch
+    from friture_amd import palette, tables
+    from friture_amd.stft import StftEngine
+    N, hop, C, T = 1024, 512, 2, 1024 + 512 * 99
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy((0.25 * rng.standard_normal((C, T))).astype(np.float32)).cuda()
+    eng = StftEngine(N, hop, C, 32)
+    eng.set_epilogue(tables.weighting_db(tables.rfft_frequencies(N), 1e-50)[0], -140.0, 0.0, palette.cmr_lut())
+    F = eng.frames_for(T)
+    for kind, dt in ((0, torch.float32), (3, torch.int32)):
+        want = eng.run(kind, x)
+        out = torch.zeros((C, F, N // 2 + 1), dtype=dt, device="cuda")
+        go = eng.prepare(kind, x, out)
+        go()
+        go()
+        assert torch.equal(out, want)
+        rows, nyq = torch.zeros((C, F, N // 2), dtype=dt, device="cuda"), torch.zeros((C, F), dtype=dt, device="cuda")
+        go = eng.prepare(kind, x, rows, nyq)
+        go()
+        assert torch.equal(rows, want[:, :, :N // 2]) and torch.equal(nyq, want[:, :, N // 2])
+    with pytest.raises(ValueError):
+        eng.prepare(0, x, torch.zeros((C, F + 1, N // 2 + 1), dtype=torch.float32, device="cuda"))
+    with pytest.raises(ValueError):
+        eng.prepare(3, x, torch.zeros((C, F, N // 2 + 1), dtype=torch.float32, device="cuda"))
