@@ -51,6 +51,7 @@ enum Option {
     kOptGccAnyLength,         // GCC-PHAT: 1 = the chirp-z path even for lengths the mixed-radix plan serves (at frt_gcc_create)
     kOptOlaChunkKernels,      // FFT overlap-add bank, one block of <= 1024 host samples: 0 = the per-stage transform launches
     kOptPitchGridTwoPass,     // pitch tracker: 1 = the two-pass log-grid kernel on the widget's grid too
+    kOptOlaDefer,             // FFT overlap-add bank, batched, >= 6 bands per octave: 0 = a launch per stage (no deferred band filters)
     kOptIirLookback,          // exact IIR bank, time-parallel energies: 0 = a chunk-scan launch at every stage (no look-back output pass)
     kOptGccResident,          // GCC-PHAT, default window, one workgroup per pair: 0 = the kernel with the scratch slab (gcc_phat_kernel)
     kOptCount

@@ -30,6 +30,7 @@
 //     the sequential ones to ~1e-10 of the input scale after nine stages (the direct-form decimator
 //     amplifies rounding), and the parallelism is C x filters x chunks.
 #include <cmath>
+#include <mutex>
 
 #include "common.h"
 #include "octbank.h"
@@ -827,12 +828,14 @@ static int launch_iir_lane(const IirStageArgs& a, int n_channels, hipStream_t st
     {
         const long long waves = bx * gy, nwg = (waves + 3) / 4;
         if (which == kWhichAll && nwg <= device_cu_count() && nwg * 2 > device_cu_count() && a.chunk >= 512 && !exp_env("FRT_LANE_NO_WG4")) {
-            static bool raised = false;
-            if (!raised) {
-                FRT_HIP_CHECK(hipFuncSetAttribute((const void*)iir_lane_wg4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                FRT_HIP_CHECK(hipFuncSetAttribute((const void*)iir_lane_wg4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                raised = true;
-            }
+            static std::once_flag raised;                   // (handles may be driven from different threads)
+            static hipError_t raise_rc = hipSuccess;
+            std::call_once(raised, [] {
+                raise_rc = hipFuncSetAttribute((const void*)iir_lane_wg4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (raise_rc == hipSuccess)
+                    raise_rc = hipFuncSetAttribute((const void*)iir_lane_wg4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            });
+            FRT_HIP_CHECK(raise_rc);
             const size_t lds = (size_t)96 * 1024;            // more than half of a CU's 160 KB: a second workgroup does not fit
             if (a.in_f32) hipLaunchKernelGGL(iir_lane_wg4_kernel<true>, dim3((unsigned)nwg), dim3(256), lds, stream, a, n_band, gb, (int)bx, gy);
             else hipLaunchKernelGGL(iir_lane_wg4_kernel<false>, dim3((unsigned)nwg), dim3(256), lds, stream, a, n_band, gb, (int)bx, gy);
@@ -1314,6 +1317,12 @@ __global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* 
     else if (ord <= 12) iir_scan_body<12>(power_l, power_g, state, chunk_end, chunk_init, gid, seg, f, live, nchunks, group, nrows, halo, gend);
     else iir_scan_body<16>(power_l, power_g, state, chunk_end, chunk_init, gid, seg, f, live, nchunks, group, nrows, halo, gend);
 }
+
+// (Round 6: the same scan with sixteen rows per wavefront as the columns of Z <- E + P Z on v_mfma_f64_16x16x4_f64 was built, parity-
+// green against this kernel, and measured SLOWER — 15-22 us per launch against 10-19 (profiles/r06_iir_mfma_scan.txt).  A float64 MFMA
+// occupies gfx950's matrix pipe for 64 cycles, four dependent ones per step cost what the twelve broadcast + multiply-add pairs of a
+// DPP row cost, and what a scan launch lasts is its fixed part — launch, the tables' and end states' round trips, the exchange through
+// LDS, the stores: ~10 us with either arithmetic.)
 
 // sp_blk = E_blk + sp_{blk-1} * (1-alpha)^n  (exp_smoothing.py:52-54), optional dB + weighting.
 // One workgroup per channel.  The recurrence is two dependent operations per block; what costs is fetching
@@ -2041,10 +2050,10 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
                     hipLaunchKernelGGL(iir_slice_sum_range_kernel, dim3((unsigned)((cnt + 255) / 256), h->n_channels), dim3(256), 0, st, cend,
                                        slice_stride, n_slices, h->nfilt, a.nchunks, f0, nf);
                 }
-                if (!look)
-                    hipLaunchKernelGGL(iir_scan_kernel, dim3((unsigned)(h->n_channels * nf * nseg)), dim3(kScanRows * 16), 0, st,
-                                       h->power.as<double>() + off, h->power.as<double>() + per + off, a.state, cend,
-                                       h->order.as<int>(), cinit, h->nfilt, a.nchunks, a.scan_group, a.scan_rows, nseg, halo, f0, nf);
+                if (look) return;
+                hipLaunchKernelGGL(iir_scan_kernel, dim3((unsigned)(h->n_channels * nf * nseg)), dim3(kScanRows * 16), 0, st,
+                                   h->power.as<double>() + off, h->power.as<double>() + per + off, a.state, cend,
+                                   h->order.as<int>(), cinit, h->nfilt, a.nchunks, a.scan_group, a.scan_rows, nseg, halo, f0, nf);
             };
             if (h->zero_state_by_recurrence || use_vector_alu) {
                 // A/B paths of the table product: a second run of the recurrence, or the vector-ALU kernel; every filter in one chain

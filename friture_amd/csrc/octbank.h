@@ -31,6 +31,7 @@ struct frt_ola_state {
     frt::DeviceBuffer btw, btwl, bH, bHw, ewt;
     frt::DeviceBuffer multi_tab[2];     // argument tables of ola_pair_multi_kernel, one per parity of the tails' swap
     std::vector<char> multi_host[2];    // what each holds
+    void* multi_pin[2] = {nullptr, nullptr};   // page-locked staging of the tables' uploads (an async copy keeps its source pointer)
     int multi_parity = 0;
     std::vector<long long> ewt_off;     // per band: offset of its smoothing weights in ewt
     int ewt_block = 0;

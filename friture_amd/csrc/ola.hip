@@ -204,6 +204,10 @@ void frt_ola_destroy(frt_octbank* h) {
     h->ola->taps.release();
     h->ola->ewt_off_dev.release();
     h->ola->xs.release();
+    for (int p = 0; p < 2; ++p) {
+        h->ola->multi_tab[p].release();
+        if (h->ola->multi_pin[p]) (void)hipHostFree(h->ola->multi_pin[p]);
+    }
     delete h->ola;
     h->ola = nullptr;
 }
@@ -760,7 +764,10 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
             // and with 2 (bpo 1) more: one launch per stage there.
             long long defer_below = h->bpo >= 6 ? 4 * slots : 0;
             if (const char* e = exp_env("FRT_OLA_DEFER_BELOW")) defer_below = atoll(e);
-            const bool split_stage = nsets * h->n_channels <= defer_below && exp_env("FRT_OLA_NO_DEFER") == nullptr;
+            // (not while the caller's stream is being captured: the deferred launch's argument table is uploaded by a copy whose node
+            // would keep pointing at this handle's staging block; option "ola_defer" = 0: tests, a launch per stage)
+            const bool split_stage = nsets * h->n_channels <= defer_below && exp_env("FRT_OLA_NO_DEFER") == nullptr &&
+                                     option(kOptOlaDefer) != 0 && !CaptureScope::active();
             if (!split_stage) {
                 launch(0, h->nfilt);
             } else {
@@ -785,7 +792,8 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
     if (!deferred.empty()) {
         // the deferred band filters: ONE launch over all their stages (ola_pair_multi_kernel).  Its argument table lives in device
         // memory; it changes only with the call's buffers and with the parity of the tails' swap, so a steady stream of calls
-        // uploads it twice.  (The copy is from pageable memory: the runtime has taken the bytes when it returns.)
+        // uploads it a few times (a byte-wise mismatch — padding included — costs an upload, never a wrong table).  The upload
+        // is staged through a page-locked block of the handle: an asynchronous copy reads its source when it executes.
         OlaMultiIndex m{};
         m.nstage = (int)deferred.size();
         int best_groups = 1;
@@ -816,8 +824,11 @@ int frt_ola_filter_batch(frt_octbank* h, const void* d_x, int x_f32, int64_t n, 
         std::vector<char>& held = o->multi_host[parity];
         if (held.size() != bytes || memcmp(held.data(), deferred.data(), bytes) != 0) {
             if ((rc = o->multi_tab[parity].reserve(kNOctave * sizeof(OlaBatchArgs)))) return rc;
+            if (!o->multi_pin[parity]) FRT_HIP_CHECK(hipHostMalloc(&o->multi_pin[parity], kNOctave * sizeof(OlaBatchArgs), hipHostMallocDefault));
+            else FRT_HIP_CHECK(hipStreamSynchronize(h->stream));      // (an earlier upload from this block may still be queued)
             held.assign((const char*)deferred.data(), (const char*)deferred.data() + bytes);
-            FRT_HIP_CHECK(hipMemcpyAsync(o->multi_tab[parity].ptr, held.data(), bytes, hipMemcpyHostToDevice, h->stream));
+            memcpy(o->multi_pin[parity], held.data(), bytes);
+            FRT_HIP_CHECK(hipMemcpyAsync(o->multi_tab[parity].ptr, o->multi_pin[parity], bytes, hipMemcpyHostToDevice, h->stream));
         }
         hipLaunchKernelGGL(ola_pair_multi_kernel, dim3((unsigned)at, best_groups, h->n_channels), dim3(kOwThreads), 0, h->stream,
                            o->multi_tab[parity].as<OlaBatchArgs>(), m);

@@ -54,6 +54,8 @@ int frt_is_device_pointer(const void* p);
  *                          option is 1 gets the two-way plan of the large batches instead of the four-way plan of the small ones)
  *   "gcc_resident"         frt_gcc_phat, default window (24000 samples), one workgroup per pair: 0 = the kernel that parks the
  *                          sub-spectra in a scratch slab in HBM instead of the one that keeps them in registers and LDS
+ *   "ola_defer"            frt_octbank_filter / _energies (mode 1, batched, >= 6 bands per octave): 0 = every stage's band filters in the
+ *                          stage's own launch instead of one deferred launch over the low-rate stages
  *   "iir_lookback"         frt_octbank_energies (mode 0, time-parallel): 0 = every stage's chunk start states from a scan launch
  *                          instead of the output pass's own look-back over its predecessors' end states at the high-rate stages
  *   "gcc_any_length"       frt_gcc_create: 1 = the chirp-z transform also for lengths the mixed-radix plan serves

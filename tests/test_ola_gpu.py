@@ -245,3 +245,29 @@ def test_chunk_filter_equals_transform_path(hip, bpo, option):
             scale = max(np.max(np.abs(yb[k])), 1e-3)
             assert np.max(np.abs(ya[k] - yb[k])) <= 1e-12 * scale, (bpo, n, k)
             assert np.max(np.abs(ym[k] - yb[k])) <= 1e-12 * scale, (bpo, n, k)
+
+
+@pytest.mark.parametrize("bpo", [6, 12, 24])
+def test_deferred_band_filters_equal_the_per_stage_launches(hip, option, bpo):
+    """From 6 bands per octave the batched FFT bank runs the low-rate stages' decimators ahead and their band filters in ONE deferred
+    launch (ola_pair_multi_kernel, sub-ranges of the filters per workgroup); option "ola_defer" = 0 keeps a launch per stage.  The same
+    three consecutive calls (the 511-sample tails carried from call to call, band signals and energies) through both: 1e-12 of the
+    signal's scale — the two forms differ only in which workgroup repeats a forward transform."""
+    from friture_amd.filter import FirBank
+    C, n = 2, 8 * 1024
+    x = np.stack([synth("noise", 3 * n, 500 + c) for c in range(C)]).astype(np.float64)
+    alphas, _ = dsp.band_smoothing_setup(bpo, 0.125)
+    got = {}
+    for defer in (-1, 0):
+        option("ola_defer", defer)
+        bank, ebank = FirBank(bpo, C), FirBank(bpo, C)
+        ys = [bank.filter(x[:, i * n:(i + 1) * n])[0] for i in range(3)]        # [channel][band] arrays
+        es = [ebank.energies(x[:, i * n:(i + 1) * n].astype(np.float32), 1024, alphas) for i in range(3)]
+        got[defer] = (ys, es)
+    for i in range(3):
+        ya, yb = got[-1][0][i], got[0][0][i]
+        for c in range(C):
+            for a, b in zip(ya[c], yb[c]):
+                assert a.shape == b.shape and np.max(np.abs(a - b)) <= 1e-12 * max(1.0, np.max(np.abs(b))), (i, c)
+        ea, eb = got[-1][1][i].astype(np.float64), got[0][1][i].astype(np.float64)
+        assert np.all(np.abs(ea - eb) <= 1e-6 * np.abs(eb) + 1e-20), i          # (float32 outputs of float64 energies equal to 1e-12)
