@@ -158,7 +158,7 @@ def compact_line(result: dict) -> dict:
                    "psd_rel_max", "gate")
 
     def base(b):
-        short = {k: b[k] for k in ("value", "cores", "sample") if k in b}          # (unit = the leg's, kind = the headline's)
+        short = {k: b[k] for k in ("value", "cores") if k in b}          # (unit = the leg's, kind = the headline's; `sample`: --full-json)
         if isinstance(b.get("all_cores"), dict):
             short["all_cores"] = {k: b["all_cores"][k] for k in ("value", "cores") if k in b["all_cores"]}
         return short
@@ -169,6 +169,8 @@ def compact_line(result: dict) -> dict:
             lg["parity"] = {k: lg["parity"][k] for k in parity_keys if k in lg["parity"]}
         if isinstance(lg.get("cpu_baseline"), dict):
             lg["cpu_baseline"] = base(lg["cpu_baseline"])
+    if isinstance(out.get("parity"), dict):
+        out["parity"].pop("layout", None)             # (says what config.layout says)
     ob = out.get("octave_bands")
     if isinstance(ob, dict) and "legs" in out:
         out["octave_bands"] = {"leg": "configs2_bank_iir_time_parallel", "value": ob.get("value"), "unit": ob.get("unit"),
@@ -357,7 +359,7 @@ def octave_legs(dev, world, rank, ch, bpo, log2n, tag, with_sequential):
     iir = IirBank(t["bdec"], t["adec"], list(t[f"boct_{bpo}"]), list(t[f"aoct_{bpo}"]), ch)
     chunk = 1024 if bpo <= 3 else 512      # measured 2048 / 1024 / 512 / 256 (tools/exp/chunk_sweep.sh): 0.74 / 0.62 / 0.64 / 0.76 ms at bpo 3, 0.82 / 0.66 / 0.64 / 0.75 at bpo 24
     iir.set_chunk(chunk)
-    record("iir_time_parallel", iir, 5,
+    record("iir_time_parallel", iir, 10,
            f"exact IIR bank, time-parallel chunks of {chunk} samples: the same recurrences re-associated; output pass with one lane "
            f"per (channel, chunk) and contracted multiply-adds (energy-only call); band energies equal to the bit-exact "
            f"sequential mode's at float32 output precision (bar 1e-5)",
@@ -376,7 +378,7 @@ def octave_legs(dev, world, rank, ch, bpo, log2n, tag, with_sequential):
     nfilt = bpo + 1
     tiles = sum(-(-(n >> j) // 3072) for j in range(9)) * ch
     flops = tiles * (1 + nfilt) * (5 * 2048 * 11 + 16 * 2048)       # complex FFTs of 2048 points + pack / unpack / multiply
-    record("fir_overlap_add", fir, 5,
+    record("fir_overlap_add", fir, 10,
            "FFT overlap-add bank (the reference's production bank, 512-tap FIRs): batched, 1e-11 of the band maximum from the "
            "reference fed in 1024-sample blocks",
            lambda dt: {"bound": "f64_flops", "unit": "TFLOP/s", "achieved": flops / dt / 1e12, "peak": F64_VECTOR_PEAK_TFLOPS,
@@ -486,7 +488,7 @@ def gcc_leg(dev, world, rank):
         d1 = np.roll(d0, 37, axis=1) + 0.025 * rng.standard_normal((pairs, L))
         g = GccPhat(L, pairs)
         a0, a1 = torch.from_numpy(d0).to(dev), torch.from_numpy(d1).to(dev)
-        dt, ev_ms = leg(lambda k: g.correlate(a0, a1), 10, dev, distributed, torch)
+        dt, ev_ms = leg(lambda k: g.correlate(a0, a1), 20, dev, distributed, torch)
         _, am = g.correlate(a0, a1)
         nbytes = pairs * 24 * L
         # real transforms of 24000 samples as complex transforms of 12000: 3 per pair (two forward, one inverse), 5 n log2 n
@@ -803,7 +805,11 @@ def main():
                          "traffic_note": "HBM bytes per launch from the rocprofv3 PMC passes of this command (tools/gpu_session.sh -> "
                                          "profiles/pmc_traffic.json), quoted only when that file was measured on these kernel sources",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernel_ms": kernel_ms_max, "kernel_ms_repeats": repeats},
+                         "kernel_ms": kernel_ms_max, "kernel_ms_repeats": repeats,
+                         # what the wall clock of the K timed steps holds beside the K launches' own time: the first launch's way to
+                         # the device and the wake-up behind the last one (profiles/r06_host_fixed.txt: ~20 us per timed region,
+                         # spinning on the completion signal instead of sleeping changes nothing); `value` stays on the wall clock
+                         "host_fixed_us": (elapsed - kernel_ms_max * 1e-3 * args.steps) * 1e6},
             "ranks_seen": ranks_seen,
             "per_rank": {"ms_per_step_min": min(per_rank_wall) / args.steps * 1e3, "ms_per_step_max": max(per_rank_wall) / args.steps * 1e3,
                          "ms_per_step": [w / args.steps * 1e3 for w in per_rank_wall],

@@ -1163,8 +1163,12 @@ __global__ void __launch_bounds__(256) iir_slice_sum_range_kernel(double* __rest
 // A^L z for the states of a filter held by the lanes of a DPP row, lane s owning row s of the matrix.  NT: number of
 // (leading) non-zero columns, i.e. the filter order rounded up to 4; four interleaved partial sums (the serial part
 // of the scan is this dependency chain).
+#ifndef FRT_SCAN_ABLATE          // experiment builds: 1 = no arithmetic in the walks (z <- e + z), 2 = no end-state loads (timing only: wrong results)
+#define FRT_SCAN_ABLATE 0
+#endif
 template <int NT>
 __device__ __forceinline__ double row_matvec(const double (&m)[kStates], double z) {
+    if (FRT_SCAN_ABLATE & 1) return z * m[0];
     double p[4] = {0.0, 0.0, 0.0, 0.0};
     static_assert(kStates == 16 && NT % 4 == 0 && NT <= 16, "one 16-lane row per filter");
     // (contracted: the scan belongs to the time-parallel mode, which re-associates the recurrence anyway)
@@ -1230,7 +1234,7 @@ __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l
     // strided reads of four slices, the halo rows' included, cost more than the streaming kernel's 5 us.)
     auto end_states = [&](int q, double (&e)[kScanBatch]) {
 #pragma unroll
-        for (int j = 0; j < kScanBatch; ++j) e[j] = (live && q + j < q1) ? ce[(size_t)(q + j) * kStates] : 0.0;
+        for (int j = 0; j < kScanBatch; ++j) e[j] = (live && q + j < q1 && !(FRT_SCAN_ABLATE & 2)) ? ce[(size_t)(q + j) * kStates] : 0.0;
     };
     // the row's chunks from a zero state.  Rows of at most kScanRowMax chunks (every shape but a workgroup short of halo rows) keep
     // their end states in registers for the second walk below.
