@@ -303,10 +303,14 @@ def timed(fn, steps, dev, distributed, torch):
     return t1 - t0, ev0.elapsed_time(ev1) / steps
 
 
-def prewarm(fn, seconds, torch):
+def prewarm(fn, seconds, torch, batch=4):
+    """Untimed launches for `seconds` before the warm-up steps (the clock ramp), `batch` of them between two synchronisations.
+    Measured (profiles/r06_prewarm_ab.txt, headline only, alternating runs on one box): batches of 4 (the device idles for the
+    host's wake-up every 0.45 ms) give value 1.153 / 1.126 / 1.148 x10^9, batches of 32 (the queue never runs dry) 1.133 / 1.130 /
+    1.133 — the hotter pre-warm costs the timed region about a percent of clock; 4 stays."""
     t0, k = time.perf_counter(), 0
     while time.perf_counter() - t0 < seconds:
-        for _ in range(4):
+        for _ in range(batch):
             fn(k)
             k += 1
         torch.cuda.synchronize()
@@ -564,6 +568,7 @@ def main():
                          "layout); packed = [F][N/2+1] (frt_stft_run, what the drop-in classes hand on).  Same values, same byte counts")
     ap.add_argument("--batches", type=int, default=3, help="distinct input batches the steps rotate over (1 = same batch every step)")
     ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed launches before the warm-up steps (GPU clock ramp)")
+    ap.add_argument("--prewarm-batch", type=int, default=4, help="launches queued between two synchronisations of the pre-warm")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for cpu_baseline (0 = skip)")
     ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--gather-slabs", action="store_true", help="all-gather every step's output slab over the job's process group, "
@@ -685,7 +690,7 @@ def main():
     # clocks; 55 launches (8 ms) straight after start-up read ~17 % slow.  Pre-warm with the same launches for
     # --prewarm-ms (default 300 ms, untimed), then the contract's W warm-up steps, then the K timed steps.
     if not stub:
-        prewarm(step, args.prewarm_ms * 1e-3, torch)
+        prewarm(step, args.prewarm_ms * 1e-3, torch, args.prewarm_batch)
     for k in range(args.warmup):
         step(k)
     # One HIP event pair brackets the K launches on the launch stream (torch's current stream, which the C ABI launches

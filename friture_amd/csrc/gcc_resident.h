@@ -74,6 +74,8 @@ __device__ __forceinline__ int res_opaque(int v, double& chain) {
 // The 6000-point transform, 6 x 10 x 10 x 10 as fft_static.h has it (same tables), with the powers of a butterfly's twiddle formed as a
 // chain w, w w1, ... and applied as they are formed: two factors alive instead of the ten of the log-depth scheme — the transform
 // runs in 106 / 74 registers (512 / 768 threads) instead of 120 / 80, which is what the parked sub-spectra leave it.
+// (Requesting a pass's table entry one pass ahead — a pass opens with a wait for it — costs 8 registers = 16 spilled, and measures equal:
+// 100 / 256 / 1024 pairs 75.0 / 89.5 / 357 us against 74.7 / 87.3 / 358, session r6h.)
 template <int NT, int R, int P>
 __device__ __forceinline__ void res_pass(cpx<double>* buf, const cpx<double>* __restrict__ tw, int tid) {
     using C = cpx<double>;
