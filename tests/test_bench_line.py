@@ -1,6 +1,6 @@
 """bench.py prints ONE JSON line and the driver keeps about the last 8 KB of stdout: the printed line of a full run (every leg,
 parity, cpu_baseline, ranks_seen) must stay under bench.LINE_BUDGET characters.  Checked on the full record of this round's GPU run
-(profiles/r05_bench_full.json, written by --full-json) pushed through the same compaction the line goes through."""
+(profiles/r06_bench_full.json, written by --full-json) pushed through the same compaction the line goes through."""
 import json
 import sys
 from pathlib import Path
@@ -11,7 +11,7 @@ sys.path.insert(0, str(ROOT))
 
 def test_compacted_line_of_a_full_run_fits_the_drivers_tail():
     import bench
-    full = json.loads((ROOT / "profiles" / "r05_bench_full.json").read_text())
+    full = json.loads((ROOT / "profiles" / "r06_bench_full.json").read_text())
     assert len(full["legs"]) >= 13 and "parity" in full and "cpu_baseline" in full
     compact = bench.compact_line(full)
     line = json.dumps(compact, separators=(",", ":"))
@@ -28,8 +28,12 @@ def test_compacted_line_of_a_full_run_fits_the_drivers_tail():
             assert abs(c["roofline"]["frac"] / leg["roofline"]["frac"] - 1) < 1e-4
         if "parity" in leg:
             assert c["parity"]["gate"] == leg["parity"]["gate"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "host_fixed_us"):
         assert k in compact["roofline"]
+    assert compact["layout"] == "split" and "packed_rows" in compact
+    # every leg with a kernel of its own carries measured traffic (profiles/r06_leg_traffic.json)
+    for name in bench.LEG_SOURCES:
+        assert compact["legs"][name]["roofline"]["traffic"] > 0, name
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in compact["cpu_baseline"]
 

@@ -3,13 +3,13 @@
 # (Round 5: the shipped library reads no environment switches; A/B of kernel generations are tools/exp sessions on variant builds.)
 set -u
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 echo "== selftest"; timeout 300 tools/bin/stft_selftest check | tail -2
 echo "== pytest -m gpu"; timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-echo "== bench (image, all legs)"; timeout 900 python bench.py --steps 50 --warmup 5 --full-json gpurun_out/${TAG}_bench_full.json 2>gpurun_out/bench_image.err | tail -1 | tee gpurun_out/${TAG}_bench_image.json | cut -c1-400; wc -c gpurun_out/${TAG}_bench_image.json
+echo "== bench (image, all legs)"; timeout 900 python bench.py --steps 20 --warmup 5 --full-json gpurun_out/${TAG}_bench_full.json 2>gpurun_out/bench_image.err | tail -1 | tee gpurun_out/${TAG}_bench_image.json | cut -c1-400; wc -c gpurun_out/${TAG}_bench_image.json
 echo "== bench (psd)"; timeout 600 python bench.py --steps 50 --warmup 5 --kind psd --cpu-budget 0 --no-legs 2>&1 | tail -1 | tee gpurun_out/${TAG}_bench_psd.json | cut -c1-300
 echo "== bench (packed rows, for comparison)"; timeout 600 python bench.py --steps 50 --warmup 5 --layout packed --cpu-budget 0 --no-legs 2>&1 | tail -1 | tee gpurun_out/${TAG}_bench_packed.json | cut -c1-300
 echo "== rocprofv3 kernel stats of the bench command"
@@ -58,3 +58,9 @@ print(f"{b-a} launches, span {(rows[b-1][1]-t0)/1e3:.1f} us")
 PY
   tail -2 gpurun_out/${TAG}_ola_launches_$tag.txt
 done
+echo "== PMC traffic of every leg's kernels (tools/leg_traffic.py -> profiles/r06_leg_traffic.json)"
+bash tools/gpu_leg_traffic.sh ${TAG}_leg_traffic 2>&1 | tail -14
+echo "== bench once more: every leg with the traffic figures of this session"
+timeout 900 python bench.py --steps 20 --warmup 5 --full-json gpurun_out/${TAG}_bench_full.json 2>>gpurun_out/bench_image.err | tail -1 > gpurun_out/${TAG}_bench_image.json; wc -c gpurun_out/${TAG}_bench_image.json
+echo "== GCC phases (experiments build)"
+for p in 1 256 1024; do FRT_GCC_PROFILE=1 FRT_LIB_VARIANT=bx timeout 300 python tools/exp/gcc_variant_bench.py --pairs $p --iters 2 2>&1 | grep "resident_kernel phases" | tail -1; done | tee gpurun_out/${TAG}_gcc_phases.txt
