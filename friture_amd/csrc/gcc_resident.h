@@ -74,6 +74,9 @@ __device__ __forceinline__ int res_opaque(int v, double& chain) {
 // The 6000-point transform, 6 x 10 x 10 x 10 as fft_static.h has it (same tables), with the powers of a butterfly's twiddle formed as a
 // chain w, w w1, ... and applied as they are formed: two factors alive instead of the ten of the log-depth scheme — the transform
 // runs in 106 / 74 registers (512 / 768 threads) instead of 120 / 80, which is what the parked sub-spectra leave it.
+// (Signal 1's 24 sample loads requested before signal 0's second transform — 96 registers in flight across it, 16 spilled — measure
+// equal too: 100 / 256 / 1024 pairs 75.4 / 90.7 / 358 us against 74.4 / 86.9 / 349, session r6i: with every CU in the same phase the load
+// phase is the chip's memory stream, not a latency.)
 // (Requesting a pass's table entry one pass ahead — a pass opens with a wait for it — costs 8 registers = 16 spilled, and measures equal:
 // 100 / 256 / 1024 pairs 75.0 / 89.5 / 357 us against 74.7 / 87.3 / 358, session r6h.)
 template <int NT, int R, int P>
