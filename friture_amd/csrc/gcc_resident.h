@@ -74,6 +74,11 @@ __device__ __forceinline__ int res_opaque(int v, double& chain) {
 // The 6000-point transform, 6 x 10 x 10 x 10 as fft_static.h has it (same tables), with the powers of a butterfly's twiddle formed as a
 // chain w, w w1, ... and applied as they are formed: two factors alive instead of the ten of the log-depth scheme — the transform
 // runs in 106 / 74 registers (512 / 768 threads) instead of 120 / 80, which is what the parked sub-spectra leave it.
+// (Round 6, sessions r6i-r6l, all measured equal within 1-3 % and not kept: signal 1's samples requested before signal 0's second
+// transform — also with the transform's tables in LDS and no spill reload in between, so that nothing waits for vector memory while
+// they are in flight: the phase that issues them grows by what the load phase shrinks (the requests queue at the chip's memory, the
+// issuing wave with them); the first round of workgroups started in eight groups 0.8-7 us apart: 1024 pairs ±2 %, 4096 pairs −4 %.
+// A pair costs a CU 83-88 us with the chip full whether or not its neighbours are in the same phase, 60 alone.)
 // (Signal 1's 24 sample loads requested before signal 0's second transform — 96 registers in flight across it, 16 spilled — measure
 // equal too: 100 / 256 / 1024 pairs 75.4 / 90.7 / 358 us against 74.4 / 86.9 / 349, session r6i: with every CU in the same phase the load
 // phase is the chip's memory stream, not a latency.)
@@ -188,6 +193,8 @@ __device__ __forceinline__ void res_second_half(cpx<double>* buf, const cpx<doub
 template <int NT>
 __device__ __forceinline__ void res_take_quads(const cpx<double>* buf, cpx<double> (&E)[ResPlan<NT>::NE], int tid) {
     using P = ResPlan<NT>;
+    asm volatile("" : "+v"(tid));       // (the mirrored elements' addresses re-made per call: kept across the kernel one of them was the
+                                        // kernel's last spilled register — a scratch allocation for 4 bytes per lane)
 #pragma unroll
     for (int i = 0; i < P::NQ; ++i) {
         const int q = tid + i * NT;
