@@ -19,6 +19,9 @@
 //   * a signal is loaded ONCE, whole lines (both 16-byte words of a 32-byte slot in one phase): the r = 0 half goes into the
 //     transform array, the r = 1 half waits in the second LDS array (+ a few registers) for the first transform to end.
 //   * the r = 0 half of the correlation waits in registers for the r = 1 half, so a thread stores 32 contiguous bytes per slot.
+//   * a forward transform's FIRST pass is taken where its input is formed (a thread loads the six points of its own butterflies: no
+//     write of the input into the transform array and no gather of it back), an inverse transform's LAST pass ends in the registers
+//     the correlation is stored from (no scatter, no read-back): 100 / 1024 pairs 75.6 / 360 -> 71.4 / 335 us.
 //
 // HBM traffic per pair = the algorithmic 24 L bytes (+ table reads that hit in L2).
 #pragma once
@@ -130,6 +133,67 @@ __device__ __forceinline__ void res_fft(cpx<double>* buf, const cpx<double>* __r
     res_pass<NT, 10, 600>(buf, tws + 66, tid);
 }
 
+// The last pass of an INVERSE transform without its scatter: butterfly j leaves the points j + 600 q (q < 10) in the thread's registers
+// — consecutive threads, consecutive points — and the correlation's rows are stored from there: no write of the pass's output into the
+// transform array, no read of it back, one barrier fewer.  (A forward transform's output is wanted by quads: it goes through LDS.)
+template <int NT>
+struct ResLast {
+    static constexpr int R = 10, PP = 600, NB = kResM2 / R;        // 600 butterflies
+    static constexpr int B = (NB + NT - 1) / NT;
+    static constexpr bool full(int b) { return (b + 1) * NT <= NB; }
+};
+template <int NT>
+__device__ __forceinline__ void res_last_pass(const cpx<double>* buf, const cpx<double>* __restrict__ tw, int tid,
+                                              cpx<double> (&v)[ResLast<NT>::B][10]) {
+    using C = cpx<double>;
+    using LP = ResLast<NT>;
+#pragma unroll
+    for (int b = 0; b < LP::B; ++b) {
+        const int j = tid + b * NT;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) v[b][q] = C{0.0, 0.0};
+        if (LP::full(b) || j < LP::NB) {
+#pragma unroll
+            for (int q = 0; q < 10; ++q) v[b][q] = buf[j + q * LP::NB];
+            const C w1 = tw[j];                                  // j mod 600 = j
+            C w = w1;
+            v[b][1] = cmul(v[b][1], w);
+#pragma unroll
+            for (int q = 2; q < 10; ++q) {
+                w = cmul(w, w1);
+                v[b][q] = cmul(v[b][q], w);
+            }
+            dft_static<double, 10>(v[b]);
+        }
+    }
+}
+template <int NT>
+__device__ __forceinline__ void res_fft_head(cpx<double>* buf, const cpx<double>* __restrict__ tws, int tid) {      // passes 1 .. 3
+    res_pass<NT, 6, 1>(buf, tws, tid);
+    res_pass<NT, 10, 6>(buf, tws, tid);
+    res_pass<NT, 10, 60>(buf, tws + 6, tid);
+}
+
+// Passes 2 .. 4 (the first pass was taken where the transform's input was formed: res_load_signal / res_second_half)
+template <int NT>
+__device__ __forceinline__ void res_fft_tail(cpx<double>* buf, const cpx<double>* __restrict__ tws, int tid) {
+    res_pass<NT, 10, 6>(buf, tws, tid);
+    res_pass<NT, 10, 60>(buf, tws + 6, tid);
+    res_pass<NT, 10, 600>(buf, tws + 66, tid);
+}
+
+// The first pass of a forward transform has no twiddles and its butterflies are a thread's own to choose: butterfly j' takes the
+// points j' + 1000 q (q < 6) — so a thread LOADS those points (consecutive threads, consecutive points: whole lines all the same),
+// takes the 6-point DFT in registers and writes the pass's output 6 j' + q.  No write of the input into the transform array, no gather
+// of it back, one barrier pair fewer per forward transform.  Slot s = 6 b + q of a thread: point (tid + NT b) + 1000 q.
+template <int NT>
+struct ResFirst {
+    static constexpr int NB = kResM2 / 6;                           // 1000 butterflies
+    static constexpr int B = (NB + NT - 1) / NT;                    // per thread
+    static_assert(6 * B == ResPlan<NT>::NS, "a thread's first-pass inputs are its NS slots");
+    static constexpr bool full(int b) { return (b + 1) * NT <= NB; }
+};
+
 // One signal, read once: (x w) of the even sample pairs into the transform array, of the odd ones into the thread's slots of the
 // second array (the last slots: registers).  Returns the sum of the thread's samples (the mean leaves in the spectrum: rfft((x - m) w)
 // = rfft(x w) - m rfft(w)).  Two batches of slots: 2 x 2 x NS / 2 loads of 16 bytes in flight per thread.
@@ -138,37 +202,42 @@ __device__ __forceinline__ double res_load_signal(const double* __restrict__ sig
                                                   cpx<double> (&Y)[ResPlan<NT>::NS - ResPlan<NT>::SPS], int tid) {
     using C = cpx<double>;
     using P = ResPlan<NT>;
-    constexpr int HB = (P::NS + 1) / 2;
+    using F = ResFirst<NT>;
     const res_rsrc srs = res_make_rsrc(sig);
-    uint32_t lane = (uint32_t)tid * 32u;                                            // slot j of thread tid: bytes 32 (tid + NT j) ...
+    uint32_t lane = (uint32_t)tid * 32u;                                            // point m of the signal: bytes 32 m ...
     asm volatile("" : "+v"(lane));      // (or the second signal re-uses the first one's window values: 2 NS x 4 registers kept from here to there)
     uint32_t lane_hi = lane + 16u;
     double acc = 0.0;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        C x0[HB], x1[HB], w0[HB], w1[HB];
+    for (int b = 0; b < F::B; ++b) {                                                // a batch = one first-pass butterfly: 4 x 6 loads in flight
+        C x0[6], x1[6], w0[6], w1[6];
+        const int jb = tid + b * NT;
+        const bool live = F::full(b) || jb < F::NB;
 #pragma unroll
-        for (int i = 0; i < HB; ++i) {
-            const int j = HB * h + i, m = tid + j * NT;
-            const uint32_t soff = (uint32_t)j * (NT * 32u);
-            x0[i] = x1[i] = w0[i] = w1[i] = C{0.0, 0.0};
-            if (j < P::NS && (P::slot_full(j) || m < kResM2)) {
-                x0[i] = res_load16(srs, lane, soff);
-                x1[i] = res_load16(srs, lane_hi, soff);
-                w0[i] = res_load16(wrs, lane, soff);
-                w1[i] = res_load16(wrs, lane_hi, soff);
+        for (int q = 0; q < 6; ++q) {
+            const uint32_t soff = (uint32_t)(b * NT + 1000 * q) * 32u;
+            x0[q] = x1[q] = w0[q] = w1[q] = C{0.0, 0.0};
+            if (live) {
+                x0[q] = res_load16(srs, lane, soff);
+                x1[q] = res_load16(srs, lane_hi, soff);
+                w0[q] = res_load16(wrs, lane, soff);
+                w1[q] = res_load16(wrs, lane_hi, soff);
             }
         }
+        C v[6];
 #pragma unroll
-        for (int i = 0; i < HB; ++i) {
-            const int j = HB * h + i, m = tid + j * NT;
-            if (j < P::NS) {
-                acc += (x0[i].x + x0[i].y) + (x1[i].x + x1[i].y);
-                const C y1 = {x1[i].x * w1[i].x, x1[i].y * w1[i].y};
-                if (P::slot_full(j) || m < kResM2) buf[m] = {x0[i].x * w0[i].x, x0[i].y * w0[i].y};
-                if (j < P::SPS) sp[m] = y1;                         // (a thread's slots of the second array are its own: no barrier)
-                else Y[j - P::SPS] = y1;
-            }
+        for (int q = 0; q < 6; ++q) {
+            const int slot = 6 * b + q;
+            acc += (x0[q].x + x0[q].y) + (x1[q].x + x1[q].y);
+            v[q] = {x0[q].x * w0[q].x, x0[q].y * w0[q].y};
+            const C y1 = {x1[q].x * w1[q].x, x1[q].y * w1[q].y};
+            if (slot < P::SPS) sp[slot * NT + tid] = y1;             // (a thread's slots of the second array are its own: no barrier)
+            else Y[slot - P::SPS] = y1;
+        }
+        dft_static<double, 6>(v);
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) buf[6 * jb + q] = v[q];
         }
         asm volatile("" : "+v"(lane), "+v"(lane_hi), "+v"(acc));   // the second batch's loads behind the first batch's arithmetic (the
                                                                    // scheduler otherwise issues all 4 NS loads first and spills them)
@@ -176,16 +245,28 @@ __device__ __forceinline__ double res_load_signal(const double* __restrict__ sig
     return acc;
 }
 
-// The waiting r = 1 half into the transform array (the array's readers are behind a barrier)
+// The waiting r = 1 half: its first pass straight from the thread's slots into the transform array (the array's readers are behind a
+// barrier)
 template <int NT>
 __device__ __forceinline__ void res_second_half(cpx<double>* buf, const cpx<double>* sp, const cpx<double> (&Y)[ResPlan<NT>::NS - ResPlan<NT>::SPS],
                                                 int tid) {
+    using C = cpx<double>;
     using P = ResPlan<NT>;
+    using F = ResFirst<NT>;
 #pragma unroll
-    for (int j = 0; j < P::NS; ++j) {
-        const int m = tid + j * NT;
-        if (j < P::SPS) buf[m] = sp[m];
-        else if (P::slot_full(j) || m < kResM2) buf[m] = Y[j - P::SPS];
+    for (int b = 0; b < F::B; ++b) {
+        const int jb = tid + b * NT;
+        C v[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int slot = 6 * b + q;
+            v[q] = slot < P::SPS ? sp[slot * NT + tid] : Y[slot < P::SPS ? 0 : slot - P::SPS];
+        }
+        dft_static<double, 6>(v);
+        if (F::full(b) || jb < F::NB) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) buf[6 * jb + q] = v[q];
+        }
     }
 }
 
@@ -238,20 +319,20 @@ __global__ void __launch_bounds__(NT) gcc_phat_resident_kernel(const GccArgs a) 
     leave_sum(res_load_signal<NT>(sig0, wrs, buf, sp, Y, tid), 0);
     __syncthreads();
     GCC_STAMP(1);
-    res_fft<NT>(buf, tws, tid);
+    res_fft_tail<NT>(buf, tws, tid);
     GCC_STAMP(2);
     res_take_quads<NT>(buf, e00, tid);
     __syncthreads();
     res_second_half<NT>(buf, sp, Y, tid);
     __syncthreads();
-    res_fft<NT>(buf, tws, tid);
+    res_fft_tail<NT>(buf, tws, tid);
     res_take_quads<NT>(buf, e01, tid);
     __syncthreads();
     GCC_STAMP(3);
     // ---- signal 1: first sub-spectrum into the second LDS array (the thread's first SPS elements) and registers (the others) --
     leave_sum(res_load_signal<NT>(sig1, wrs, buf, sp, Y, tid), 16);
     __syncthreads();
-    res_fft<NT>(buf, tws, tid);
+    res_fft_tail<NT>(buf, tws, tid);
     C e10r[NE - SPS];
     {
         C te[NE];
@@ -265,7 +346,7 @@ __global__ void __launch_bounds__(NT) gcc_phat_resident_kernel(const GccArgs a) 
         }
     }
     __syncthreads();
-    res_fft<NT>(buf, tws, tid);
+    res_fft_tail<NT>(buf, tws, tid);
     GCC_STAMP(4);
     // ---- the means ---------------------------------------------------------------------------------------------------------
     double mean0 = 0.0, mean1 = 0.0;                     // (the sums were left before barriers long past)
@@ -393,19 +474,14 @@ __global__ void __launch_bounds__(NT) gcc_phat_resident_kernel(const GccArgs a) 
     __syncthreads();
     GCC_STAMP(6);
     // ---- inverse sub-transforms: z[2 m + r] = (1/M) conj(FFT_M2(conj input_r))[m] ---------------------------------------
-    res_fft<NT>(buf, tws, tid);
+    // The last pass leaves butterfly j's points m = j + 600 q in registers (res_last_pass): the r = 0 half waits there for the r = 1
+    // half, and a thread stores the 32 contiguous bytes of every m it holds.
+    using LP = ResLast<NT>;
+    res_fft_head<NT>(buf, tws, tid);
     const double inv = 1.0 / (double)M;
-    C o0[NS];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int m = tid + j * NT;
-        o0[j] = C{0.0, 0.0};
-        if (P::slot_full(j) || m < M2) {
-            const C v = buf[m];
-            o0[j] = C{v.x * inv, -v.y * inv};
-        }
-    }
-    __syncthreads();
+    C o0[LP::B][10];
+    res_last_pass<NT>(buf, tws + 66, tid, o0);
+    __syncthreads();                                     // every read of the transform array is done
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int q = tid + i * NT;
@@ -415,26 +491,30 @@ __global__ void __launch_bounds__(NT) gcc_phat_resident_kernel(const GccArgs a) 
         }
     }
     __syncthreads();
-    res_fft<NT>(buf, tws, tid);
+    res_fft_head<NT>(buf, tws, tid);
+    C o1[LP::B][10];
+    res_last_pass<NT>(buf, tws + 66, tid, o1);
     GCC_STAMP(7);
     const res_rsrc out_rs = res_make_rsrc(a.xcorr + (size_t)pair * L);
     double best = -1.0;
     int besti = 0;
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int m = tid + j * NT;
-        if (P::slot_full(j) || m < M2) {
-            const C v = buf[m];
-            const C o1 = C{v.x * inv, -v.y * inv};
-            const int t = 4 * m;                          // samples t .. t + 3 = (z[2 m], z[2 m + 1])
-            const uint32_t soff = (uint32_t)j * (NT * 32u);
-            res_store16(out_rs, (uint32_t)tid * 32u, soff, o0[j].x, o0[j].y);
-            res_store16(out_rs, (uint32_t)tid * 32u + 16u, soff, o1.x, o1.y);
-            // ascending t within a thread: a later equal magnitude does not replace the first
-            if (fabs(o0[j].x) > best) { best = fabs(o0[j].x); besti = t; }
-            if (fabs(o0[j].y) > best) { best = fabs(o0[j].y); besti = t + 1; }
-            if (fabs(o1.x) > best) { best = fabs(o1.x); besti = t + 2; }
-            if (fabs(o1.y) > best) { best = fabs(o1.y); besti = t + 3; }
+    for (int b = 0; b < LP::B; ++b) {
+        const int jb = tid + b * NT;
+        if (LP::full(b) || jb < LP::NB) {
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+                const int t = 4 * (jb + LP::NB * q);            // samples t .. t + 3 = (z[2 m], z[2 m + 1]), m = j + 600 q
+                const uint32_t soff = (uint32_t)(b * NT + LP::NB * q) * 32u;
+                const double r0 = o0[b][q].x * inv, i0 = -o0[b][q].y * inv, r1 = o1[b][q].x * inv, i1 = -o1[b][q].y * inv;
+                res_store16(out_rs, (uint32_t)tid * 32u, soff, r0, i0);
+                res_store16(out_rs, (uint32_t)tid * 32u + 16u, soff, r1, i1);
+                // (a thread's points do not come in ascending order: ties go to the smaller index explicitly)
+                if (fabs(r0) > best || (fabs(r0) == best && t < besti)) { best = fabs(r0); besti = t; }
+                if (fabs(i0) > best || (fabs(i0) == best && t + 1 < besti)) { best = fabs(i0); besti = t + 1; }
+                if (fabs(r1) > best || (fabs(r1) == best && t + 2 < besti)) { best = fabs(r1); besti = t + 2; }
+                if (fabs(i1) > best || (fabs(i1) == best && t + 3 < besti)) { best = fabs(i1); besti = t + 3; }
+            }
         }
     }
     // ---- argmax |xcorr| (first index on ties, as numpy.argmax) -----------------------------------------------------------
