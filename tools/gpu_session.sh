@@ -32,7 +32,7 @@ echo "== kernel stats of the screen-space / widget / GCC kernels (their GPU test
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/widgets -o w -- python -m pytest $R/tests/test_pipeline_gpu.py $R/tests/test_widgets_gpu.py $R/tests/test_gcc_gpu.py -q -m gpu -p no:cacheprovider > $R/gpurun_out/prof/widgets.log 2>&1 )
 python tools/prof_summary.py stats gpurun_out/prof/widgets/w_results.db > gpurun_out/${TAG}_widgets_kernel_stats.txt 2>/dev/null; head -5 gpurun_out/${TAG}_widgets_kernel_stats.txt | cut -c1-160
 echo "== GCC-PHAT against the batch size"
-python tools/bench_gcc.py 2>/dev/null | grep -v "^{" > gpurun_out/${TAG}_gcc_batch.txt; cat gpurun_out/${TAG}_gcc_batch.txt
+python tools/bench_gcc.py --pairs 1 4 16 32 40 48 56 64 100 160 256 1024 2>/dev/null | grep -v "^{" > gpurun_out/${TAG}_gcc_batch.txt; cat gpurun_out/${TAG}_gcc_batch.txt
 echo "== banks and latency"
 python tools/bench_firbank.py > gpurun_out/${TAG}_banks.json 2>/dev/null; cut -c1-250 gpurun_out/${TAG}_banks.json
 python tools/stream_latency.py > gpurun_out/${TAG}_stream_latency.json 2>gpurun_out/stream_latency.err; head -c 300 gpurun_out/${TAG}_stream_latency.json
