@@ -1336,10 +1336,11 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
     const int force = option(kOptGccOneWorkgroup);
     // the default window, one workgroup per pair: nothing passes through HBM between the signals and the correlation (gcc_resident.h)
     const bool can_reside = st == 1 && h->R == 2 && option(kOptGccResident) != 0;
-    // A pair as launches of its own phases while the batch leaves most CUs idle: below a quarter of a workgroup per CU when the
-    // resident kernel serves the window (measured, profiles/r06_gcc_batch.txt: 32 pairs 57 against 69 us, 64 pairs 73 = 73, 100 pairs
-    // 84 against 77, 160 pairs 136 against 82), below 5/8 with the slab kernel (round 3: crossover between 100 and 256 pairs)
-    const bool split = force >= 0 ? force == 0 : can_reside ? (long long)h->n_pairs * 4 < (long long)device_cu_count()
+    // A pair as launches of its own phases while the batch leaves most CUs idle: below a sixth of a workgroup per CU when the
+    // resident kernel serves the window (measured, profiles/r06_gcc_batch.txt, us per call: 32 pairs 57 against 64, 40 pairs 65 = 65,
+    // 48 pairs 67 against 65, 64 pairs 72 against 67, 100 pairs 84 against 71, 160 pairs 135 against 75), below 5/8 with the slab kernel
+    // (round 3: crossover between 100 and 256 pairs)
+    const bool split = force >= 0 ? force == 0 : can_reside ? (long long)h->n_pairs * 6 < (long long)device_cu_count()
                                                              : (long long)h->n_pairs * 8 <= 5ll * device_cu_count();
     const bool resident = !split && can_reside;
     if (!resident && (rc = h->scratch.reserve((size_t)h->n_pairs * (4 * (size_t)h->M + 2) * 2 * sizeof(double)))) return rc;
