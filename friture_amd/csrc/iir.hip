@@ -1166,11 +1166,24 @@ __global__ void __launch_bounds__(256) iir_slice_sum_range_kernel(double* __rest
 #ifndef FRT_SCAN_ABLATE          // experiment builds: 1 = no arithmetic in the walks (z <- e + z), 2 = no end-state loads (timing only: wrong results)
 #define FRT_SCAN_ABLATE 0
 #endif
+// lane T of every quad, to its quad
+template <int T>
+__device__ __forceinline__ double dpp_quad_bcast(double v) {
+    constexpr int ctrl = T | (T << 2) | (T << 4) | (T << 6);       // quad_perm [T, T, T, T]
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// NT: the filter's order rounded up to 4; a 4th-order filter's row is a QUAD of lanes (round 6: its 16-lane row had twelve idle lanes —
+// 24 of a 1/24-octave stage's 25 filters), everything above it a 16-lane DPP row
 template <int NT>
-__device__ __forceinline__ double row_matvec(const double (&m)[kStates], double z) {
+__device__ __forceinline__ double row_matvec(const double (&m)[NT], double z) {
     if (FRT_SCAN_ABLATE & 1) return z * m[0];
     double p[4] = {0.0, 0.0, 0.0, 0.0};
-    static_assert(kStates == 16 && NT % 4 == 0 && NT <= 16, "one 16-lane row per filter");
+    static_assert(kStates == 16 && NT % 4 == 0 && NT <= 16, "one 16-lane row or one quad per filter");
+    if constexpr (NT == 4)
+        return __builtin_fma(m[1], dpp_quad_bcast<1>(z), m[0] * dpp_quad_bcast<0>(z)) + __builtin_fma(m[3], dpp_quad_bcast<3>(z), m[2] * dpp_quad_bcast<2>(z));
     // (contracted: the scan belongs to the time-parallel mode, which re-associates the recurrence anyway)
 #define FRT_SCAN_TERM(T) if (T < NT) p[(T) & 3] = __builtin_fma(m[T], dpp_row_bcast<T>(z), p[(T) & 3]);
     FRT_SCAN_TERM(0) FRT_SCAN_TERM(1) FRT_SCAN_TERM(2) FRT_SCAN_TERM(3) FRT_SCAN_TERM(4) FRT_SCAN_TERM(5)
@@ -1215,15 +1228,16 @@ __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l
                                               const double* __restrict__ state, const double* __restrict__ chunk_end,
                                               double* __restrict__ chunk_init, int gid, int seg, int f,
                                               bool live, int nchunks, int group, int nrows, int halo, double (*gend)[kStates]) {
-    const int row = threadIdx.x >> 4, s = threadIdx.x & 15;
+    constexpr int LPR = NT == 4 ? 4 : 16;                      // lanes per row
+    const int row = threadIdx.x / LPR, s = threadIdx.x & (LPR - 1);
     const int r = seg * (kScanRows - halo) - halo + row;      // global row; the first `halo` rows of the workgroup are the halo
     const bool row_ok = r >= 0 && r < nrows;
     const bool owned = row >= halo && row_ok;
-    double m[kStates], mg[kStates];                            // (both requested up front: the second table is needed after the rows' walk)
+    double m[NT], mg[NT];                                      // (both requested up front: the second table is needed after the rows' walk)
 #pragma unroll
-    for (int t = 0; t < kStates; ++t) m[t] = power_l[((size_t)f * kStates + s) * kStates + t];
+    for (int t = 0; t < NT; ++t) m[t] = power_l[((size_t)f * kStates + s) * kStates + t];
 #pragma unroll
-    for (int t = 0; t < kStates; ++t) mg[t] = power_g[((size_t)f * kStates + s) * kStates + t];
+    for (int t = 0; t < NT; ++t) mg[t] = power_g[((size_t)f * kStates + s) * kStates + t];
     const double s0 = live ? state[(size_t)gid * kStates + s] : 0.0;
     const double* ce = chunk_end + (size_t)gid * nchunks * kStates + s;
     double* ci = chunk_init + (size_t)gid * nchunks * kStates + s;
@@ -1316,7 +1330,9 @@ __global__ void __launch_bounds__(kScanRows * 16) iir_scan_kernel(const double* 
     const int lid = blockIdx.x / nseg, seg = blockIdx.x - lid * nseg;
     const int f = f0 + lid % nf, gid = (lid / nf) * nfilt + f;
     const int ord = order[f];                                 // uniform in the workgroup
-    const bool live = (int)(threadIdx.x & 15) < ord;
+    if (ord <= 4 && threadIdx.x >= kScanRows * 4) return;     // a 4th-order filter's rows are quads: the first two wavefronts hold all 32
+                                                              // (whole wavefronts leave: the barriers below count the ones that stay)
+    const bool live = ord <= 4 ? (int)(threadIdx.x & 3) < ord : (int)(threadIdx.x & 15) < ord;
     if (ord <= 4) iir_scan_body<4>(power_l, power_g, state, chunk_end, chunk_init, gid, seg, f, live, nchunks, group, nrows, halo, gend);
     else if (ord <= 12) iir_scan_body<12>(power_l, power_g, state, chunk_end, chunk_init, gid, seg, f, live, nchunks, group, nrows, halo, gend);
     else iir_scan_body<16>(power_l, power_g, state, chunk_end, chunk_init, gid, seg, f, live, nchunks, group, nrows, halo, gend);

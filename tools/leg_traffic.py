@@ -147,11 +147,19 @@ def collect(root, out_path=None):
                     "write_bytes_per_call": sum(k["write_bytes_per_call"] for k in kernels.values()),
                     "algorithmic_bytes_per_call": alg, "ratio": total / alg if alg else None,
                     "dominant_kernel": dominant, "kernels": kernels, "one_off_kernels": sorted(oneoff)}
+    target = Path(out_path or ROOT / "profiles" / "r06_leg_traffic.json")
+    if target.exists():                     # a session that re-measures some legs keeps the others' records
+        try:
+            old = json.loads(target.read_text()).get("legs", {})
+            rec = {**{k: v for k, v in old.items() if k not in rec}, **rec}
+            rec = {k: rec[k] for k in LEGS if k in rec}
+        except Exception:
+            pass
     out = {"method": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python tools/leg_traffic.py run <leg>; all dispatches "
                      "of the kernels launched in every call, summed per call; FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md "
                      "(128-byte requests tallied at 64 B), WRITE_SIZE (KB) as is; check_* from TCC_EA0_RDREQ / WRREQ request counts",
            "legs": rec}
-    Path(out_path or ROOT / "profiles" / "r06_leg_traffic.json").write_text(json.dumps(out, indent=1) + "\n")
+    target.write_text(json.dumps(out, indent=1) + "\n")
     for leg, r in rec.items():
         print(f"{leg:26s} {r['hbm_bytes_per_call'] / 1e6:10.2f} MB/call  algorithmic {(r['algorithmic_bytes_per_call'] or 0) / 1e6:9.2f} MB  "
               f"x{r['ratio'] or 0:.3f}  dominant {r['dominant_kernel'][:60]}")
