@@ -42,6 +42,11 @@ namespace frt {
 #define FRT_IIR_VEC_OUT 0
 #endif
 
+// chunk_end / chunk_init hold, per (channel, filter), nchunks state vectors in a block of nchunks x kStates doubles.  A filter of order
+// > 4 uses kStates doubles per chunk; a 4th-order filter packs its four at the front of the block (round 6: a 128-byte line then carries
+// four chunks' states instead of one's — the 216-band bank's scans moved 577 MB per call, three quarters of it unused lanes' bytes).
+__host__ __device__ constexpr int chunk_state_stride(int order) { return order <= 4 ? 4 : kStates; }
+
 struct IirStageArgs {
     const void* x;             // [C][x_stride] stage input
     long long x_stride;
@@ -219,7 +224,7 @@ __device__ __forceinline__ void iir_stage_body(const IirStageArgs& a, long long 
     const double keep = (LPS == 4 && s == 3) ? 0.0 : 1.0;
 
     const size_t sidx = ((size_t)c * a.nfilt + f) * kStates + s;
-    const size_t cidx = (((size_t)c * a.nfilt + f) * a.nchunks + q) * kStates + s;
+    const size_t cidx = ((size_t)c * a.nfilt + f) * a.nchunks * kStates + (size_t)q * (LPS == 4 ? 4 : kStates) + s;      // (quad slots: order <= 4)
     double z = 0.0;
     if (live) {
         if (a.pass == 0) z = a.state[sidx];
@@ -465,7 +470,7 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
             const double* carried = a.state_in + ((size_t)c * a.nfilt + f) * kStates;
             unsigned long long pw_at = (unsigned long long)(uintptr_t)(a.power_l + (size_t)f * kStates * kStates);
             auto end_state = [&](int i, double (&e)[ORD]) {       // e[i]: chunk i's zero-state end state; the carried state for i = -1
-                const double* src = i >= 0 ? ends + (size_t)i * kStates : carried;
+                const double* src = i >= 0 ? ends + (size_t)i * chunk_state_stride(ORD) : carried;
 #pragma unroll
                 for (int t = 0; t < ORD; t += 2) {
                     const double2 v = i >= -1 ? *(const double2*)(src + t) : double2{0.0, 0.0};
@@ -498,7 +503,7 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
 #pragma unroll
             for (int t = 0; t < ORD; ++t) z[m][t] = zz[t];
         } else {
-            const double* init = a.chunk_init + (((size_t)c * a.nfilt + f) * a.nchunks + qc) * kStates;
+            const double* init = a.chunk_init + ((size_t)c * a.nfilt + f) * a.nchunks * kStates + (size_t)qc * chunk_state_stride(ORD);
 #pragma unroll
             for (int t = 0; t < ORD; t += 2) {
                 const double2 iv = *(const double2*)(init + t);
@@ -887,6 +892,7 @@ struct ZeroStateArgs {
     const double* table_m;     // the same values in the MFMA kernel's operand order (zs_mfma_index)
     int rows, rows_padded;
     const int* rowmap;         // [rows_padded]: f * kStates + s of each row, -1 for padding
+    const int* order;          // [nfilt]: a filter's order decides how its chunk states are packed (chunk_state_stride)
     double* partial;           // [n_slices][C][nfilt][nchunks][kStates]
     long long partial_stride;
     int rt_base, rt_count;     // MFMA kernel: the launch serves row tiles rt_base .. rt_base + rt_count - 1 (tile 0: the decimator)
@@ -984,7 +990,7 @@ __global__ void __launch_bounds__(64) iir_zero_state_kernel(const ZeroStateArgs 
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int m = a.rowmap[r0 + r];                               // uniform
-            if (m >= 0) out[(((size_t)ch[j] * a.nfilt + (m >> 4)) * a.nchunks + cq[j]) * kStates + (m & 15)] = acc[j][r];
+            if (m >= 0) out[((size_t)ch[j] * a.nfilt + (m >> 4)) * a.nchunks * kStates + (size_t)cq[j] * chunk_state_stride(a.order[m >> 4]) + (m & 15)] = acc[j][r];
         }
     }
 }
@@ -1136,7 +1142,7 @@ __global__ void __launch_bounds__(64) iir_zero_state_mfma_kernel(const ZeroState
         for (int v = 0; v < 4; ++v) {
             if (rt0 + rt >= a.rt_base + a.rt_count) continue;              // the second tile of an odd range's last workgroup
             const int m = a.rowmap[(rt0 + rt) * 16 + 4 * v + g];
-            if (m >= 0) out[(((size_t)c * a.nfilt + (m >> 4)) * a.nchunks + q) * kStates + (m & 15)] = acc[rt][v];
+            if (m >= 0) out[((size_t)c * a.nfilt + (m >> 4)) * a.nchunks * kStates + (size_t)q * chunk_state_stride(a.order[m >> 4]) + (m & 15)] = acc[rt][v];
         }
 }
 
@@ -1239,6 +1245,7 @@ __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l
 #pragma unroll
     for (int t = 0; t < NT; ++t) mg[t] = power_g[((size_t)f * kStates + s) * kStates + t];
     const double s0 = live ? state[(size_t)gid * kStates + s] : 0.0;
+    constexpr int CS = chunk_state_stride(NT);                // doubles per chunk of this filter's block
     const double* ce = chunk_end + (size_t)gid * nchunks * kStates + s;
     double* ci = chunk_init + (size_t)gid * nchunks * kStates + s;
     const int q0 = row_ok ? r * group : 0;
@@ -1248,7 +1255,7 @@ __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l
     // strided reads of four slices, the halo rows' included, cost more than the streaming kernel's 5 us.)
     auto end_states = [&](int q, double (&e)[kScanBatch]) {
 #pragma unroll
-        for (int j = 0; j < kScanBatch; ++j) e[j] = (live && q + j < q1 && !(FRT_SCAN_ABLATE & 2)) ? ce[(size_t)(q + j) * kStates] : 0.0;
+        for (int j = 0; j < kScanBatch; ++j) e[j] = (live && q + j < q1 && !(FRT_SCAN_ABLATE & 2)) ? ce[(size_t)(q + j) * CS] : 0.0;
     };
     // the row's chunks from a zero state.  Rows of at most kScanRowMax chunks (every shape but a workgroup short of halo rows) keep
     // their end states in registers for the second walk below.
@@ -1296,7 +1303,7 @@ __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l
                 for (int j = 0; j < kScanBatch; ++j) {
                     const int q = q0 + b * kScanBatch + j;
                     if (q < q1) {
-                        ci[(size_t)q * kStates] = zt;
+                        ci[(size_t)q * CS] = zt;
                         zt = ek[b][j] + row_matvec<NT>(m, zt);
                     }
                 }
@@ -1308,7 +1315,7 @@ __device__ __forceinline__ void iir_scan_body(const double* __restrict__ power_l
 #pragma unroll
                 for (int j = 0; j < kScanBatch; ++j) {
                     if (q + j < q1) {
-                        ci[(size_t)(q + j) * kStates] = zt;
+                        ci[(size_t)(q + j) * CS] = zt;
                         zt = e[j] + row_matvec<NT>(m, zt);
                     }
                 }
@@ -2043,6 +2050,7 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
             z.table_m = h->zs_table_m.as<double>() + h->zs_offset[j];
             z.rows = h->zs_rows; z.rows_padded = h->zs_rows_padded;
             z.rowmap = h->zs_rowmap.as<int>();
+            z.order = h->order.as<int>();
             double* const cend = h->chunk_end.as<double>() + off_end[j];
             double* const cinit = h->chunk_init.as<double>() + off_init[j];
             z.partial = cend;
