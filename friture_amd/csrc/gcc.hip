@@ -51,7 +51,6 @@ struct GccArgs {
     double* scratch;       // [pairs][4 M + 2] complex
     MixedPlan plan;        // for M2
     int L, M, M2, R;
-    int n_pairs;           // gcc_phat_resident_kernel: a workgroup takes the pairs blockIdx.x, blockIdx.x + gridDim.x, ...
     int vec;               // d0, d1 and xcorr are 16-byte aligned
     long long* prof;       // FRT_GCC_PROFILE: phase time stamps of workgroup 0 (100 MHz counter), else null
 };
@@ -285,10 +284,7 @@ __global__ void __launch_bounds__(256) gcc_window_rfft_kernel(const double* __re
 
 }  // namespace frt
 #include "gcc_resident.h"
-#ifndef FRT_GCC_RES_THREADS
-#define FRT_GCC_RES_THREADS 512
-#endif
-constexpr int kResThreads = FRT_GCC_RES_THREADS;
+constexpr int kResThreads = 512;      // (768 threads — the transform in 74 registers — was measured 4 % slower: 23 spilled, profiles/r06_gcc_batch.txt)
 namespace frt {
 
 // One window pair per workgroup, everything between the two signals and the correlation in this launch.  What passes
@@ -1332,7 +1328,6 @@ extern "C" int frt_gcc_phat(frt_gcc* h, const double* d0, const double* d1, doub
     a.vec = ((uintptr_t)a.d0 % 16 == 0) && ((uintptr_t)a.d1 % 16 == 0) && ((uintptr_t)a.xcorr % 16 == 0);
     const int st = h->static_plan;
     a.psum = st == 2 ? h->psum.as<double>() : nullptr;
-    a.n_pairs = h->n_pairs;
     const int force = option(kOptGccOneWorkgroup);
     // the default window, one workgroup per pair: nothing passes through HBM between the signals and the correlation (gcc_resident.h)
     const bool can_reside = st == 1 && h->R == 2 && option(kOptGccResident) != 0;
