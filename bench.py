@@ -751,6 +751,7 @@ def main():
     exit_code = 0
     legs = {}
     if not stub and not args.no_legs and n_fft == 1024:
+        prepared.clear()                          # (the prepared launches hold their buffers)
         del xs, outs, out
         if split:
             del slabs, rows, nyqs
