@@ -21,6 +21,7 @@ from friture_amd.signal.lfilter import lfilter_float64_1D
 from friture_amd.signal.correlation import generalized_cross_correlation, GccPhat
 from friture_amd.audioproc import audioproc
 from friture_amd.octavefilters import Octave_Filters
+from friture_amd.filter import IirBank
 from oracle import dsp
 _lib.init(0)
 t = filter_design.load_tables()
@@ -56,6 +57,26 @@ def work(tid):
             assert max(np.max(np.abs(a - b)) for a, b in zip(yb, yo)) <= 1e-9, ("ola", tid, rep)
             g = GccPhat(2400, 1 + rep)                              # a handle created and destroyed inside the thread
             del g
+            if rep %% 3 == 0:
+                # round 6's kernels under the same concurrency: the resident GCC-PHAT kernel (default window, >= CUs / 6 pairs: 160 KB of
+                # LDS and a whole CU's registers per workgroup) and the time-parallel exact bank (look-back output pass, packed chunk states)
+                P = 44 + tid
+                e0 = rng.standard_normal((P, 24000)); e1 = np.roll(e0, 5 + tid, axis=1) + 0.05 * rng.standard_normal((P, 24000))
+                xg, am = GccPhat(24000, P).correlate(e0, e1)
+                rr, _, _ = dsp.gcc_phat(e0[P - 1].copy(), e1[P - 1].copy())
+                assert list(am) == [5 + tid] * P and np.max(np.abs(xg[P - 1] - rr)) <= 1e-9 * np.max(np.abs(rr)), ("gcc resident", tid, rep)
+                ib = IirBank(t["bdec"], t["adec"], list(t["boct_3"]), list(t["aoct_3"]), 1)
+                ib.set_chunk(1024)
+                xe = (0.25 * rng.standard_normal((1, 16 * 1024))).astype(np.float32)
+                al, ker = dsp.band_smoothing_setup(3, 0.125)
+                import torch
+                en = ib.energies(torch.from_numpy(xe).cuda(), 1024, al).cpu().numpy()
+                zs = dsp.iir_bank_filtic(t["bdec"], t["adec"], list(t["boct_3"]), list(t["aoct_3"])); prev = [0.0] * 27
+                for b in range(16):
+                    yy, _, zs = dsp.iir_bank(t["bdec"], t["adec"], list(t["boct_3"]), list(t["aoct_3"]), xe[0, b * 1024:(b + 1) * 1024].astype(np.float64), zs)
+                    prev = dsp.band_energies(yy, ker, al, prev)
+                assert np.all(np.abs(en[0, 15] - np.array(prev)) <= 1e-5 * np.array(prev) + 1e-14 * max(prev)), ("iir energies", tid, rep)
+                del ib
         del ap, bank
     except BaseException as exc:
         errors.append(repr(exc))
