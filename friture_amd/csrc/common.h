@@ -54,6 +54,7 @@ enum Option {
     kOptOlaDefer,             // FFT overlap-add bank, batched, >= 6 bands per octave: 0 = a launch per stage (no deferred band filters)
     kOptIirLookback,          // exact IIR bank, time-parallel energies: 0 = a chunk-scan launch at every stage (no look-back output pass)
     kOptGccResident,          // GCC-PHAT, default window, one workgroup per pair: 0 = the kernel with the scratch slab (gcc_phat_kernel)
+    kOptIirLaneColumns,       // exact IIR bank, time-parallel energies: output pass as chunk columns with LDS-staged samples — 1 = wherever it can, 0 = nowhere
     kOptCount
 };
 int option(Option o);         // -1 = not set: the shape rule decides

@@ -437,9 +437,27 @@ constexpr int kLaneBands = FRT_LANE_BANDS;      // measured: one band filter per
 // LPC (lanes per chunk) > 1: the band filters of a group on LPC neighbouring lanes of ONE chunk, a filter per lane (NF = 1; `nlive`
 // of them exist), 64 / LPC chunks per wavefront — a third of the dependent float64 instructions per sample and wave and three
 // times the wavefronts of the filter-group-per-lane form (iir_lane_split_kernel).  The lanes of a chunk read the same samples.
-template <int NF, int ORD, bool DEC, bool F32, int LPC = 1>
-__device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_group, int bx, int lane, int nlive = NF) {
+// STAGED (round 6, iir_lane_col_kernel): the samples come from a tile in LDS that the wavefronts of the chunk column — every filter
+// group of the same 64 chunks, one workgroup — fill together with coalesced loads, instead of from requests in which every lane
+// walks its own cache lines (64 lines per load instruction, again per filter group).
+#ifndef FRT_COL_F64_PIECES
+#define FRT_COL_F64_PIECES 16
+#endif
+constexpr int kColRows = 64;                                      // a tile: 64 chunks (rows) x PIECES pieces of 16 bytes
+template <bool F32> struct ColTile {
+    static constexpr int kPieces = F32 ? 16 : FRT_COL_F64_PIECES; // 64 floats; 32 or 64 doubles
+    static constexpr int kRowBytes = kPieces * 16;                // rows are contiguous: an LDS-DMA instruction (1 KB) fills 1024 / kRowBytes of them
+    static constexpr int kBytes = kColRows * kRowBytes;
+    static constexpr int kSamples = kRowBytes / (F32 ? 4 : 8);
+};
+// piece j of row r sits in slot j ^ (r & 15) of the row: sixteen lanes reading piece j of sixteen consecutive rows hit sixteen
+// different 16-byte bank groups (unswizzled, rows 256 or 512 bytes apart, they would all hit the same one)
+
+template <int NF, int ORD, bool DEC, bool F32, int LPC = 1, bool STAGED = false>
+__device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_group, int bx, int lane, int nlive = NF, char* lds = nullptr,
+                                              int tid_col = 0, int nt_col = 64, bool live = true) {
     static_assert(LPC == 1 || (NF == 1 && !DEC), "a filter per lane");
+    static_assert(!STAGED || LPC == 1, "staged tiles hold a chunk per lane");
     constexpr int CPW = 64 / LPC;                               // chunks per wavefront
     const int cl = LPC == 1 ? lane : (lane * 43) >> 7;          // lane / 3 for lane < 64 (LPC is 1 or 3)
     static_assert(LPC == 1 || LPC == 3, "lane / LPC by multiply-shift");
@@ -447,7 +465,7 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
     const int nblk = (a.nchunks + CPW - 1) / CPW;
     const int c = bx / nblk;
     const int q = (bx - c * nblk) * CPW + cl;
-    const bool valid = q < a.nchunks && cl < CPW && ml < nlive;
+    const bool valid = q < a.nchunks && cl < CPW && ml < nlive && live;
     const int qc = (q < a.nchunks && cl < CPW) ? q : a.nchunks - 1;      // lanes past the end shadow the last chunk, store nothing
     const int f0 = f0_group + (LPC > 1 && ml < nlive ? ml : 0);          // (per lane when LPC > 1)
     const int L = a.chunk;
@@ -551,9 +569,22 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
     static_assert(64 % (G * D) == 0, "a chunk is whole rounds of the prefetch ring");
     float4 rf[D][4];
     double2 rd[D][8];
+    double ydp[G / 2] = {};
+    typedef ColTile<F32> Tile;
+    constexpr int S = Tile::kSamples, ESZ = F32 ? 4 : 8;       // (staged) samples of a tile row, bytes of a sample
+    const char* tile_row = lds + lane * Tile::kRowBytes;        // (staged) this lane's row of the tile being filtered
     auto request = [&](auto slot, int k) {
         constexpr int d = decltype(slot)::value;
-        if (f32) {
+        if constexpr (STAGED) {
+            const int pj = (k & (S - 1)) * ESZ / 16, sw = lane & 15;
+            if (f32) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rf[d][i] = *(const float4*)(tile_row + (((pj + i) ^ sw) << 4));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rd[d][i] = *(const double2*)(tile_row + (((pj + i) ^ sw) << 4));
+            }
+        } else if (f32) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) rf[d][i] = *(const float4*)(xf + k + 4 * i);
         } else {
@@ -564,6 +595,7 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
     auto trip = [&](auto slot, int k0) {
         constexpr int d = decltype(slot)::value;
         double xg[G];
+        if constexpr (STAGED) request(slot, k0);                 // an LDS read: ~100 cycles in front of ~3000 of arithmetic
         if (f32) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { xg[4 * i] = rf[d][i].x; xg[4 * i + 1] = rf[d][i].y; xg[4 * i + 2] = rf[d][i].z; xg[4 * i + 3] = rf[d][i].w; }
@@ -571,7 +603,23 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
 #pragma unroll
             for (int i = 0; i < 8; ++i) { xg[2 * i] = rd[d][i].x; xg[2 * i + 1] = rd[d][i].y; }
         }
-        if (k0 + G * D < L) request(slot, k0 + G * D);
+        // The next piece is requested on EVERY trip (the last one re-reads its own: the address stays inside the chunk) and only after
+        // this trip's samples exist as doubles.  Round 6: behind `if (k0 + G D < L)` the ring's registers were a merge of "loaded" and
+        // "kept", the compiler put the merge's copies into the conditional block right behind the loads, and every trip of every lane
+        // pass began with a wait for the memory round trip it had just started — the prefetch never ran ahead (which is also why one,
+        // two and four trips of distance measured equal in round 4).
+#pragma unroll
+        for (int i = 0; i < G; ++i) asm volatile("" : "+v"(xg[i]));
+        // the decimator's outputs of the PREVIOUS trip leave here, in front of the request: stored at the end of their own trip, the
+        // next trip's wait for its samples (one counter for loads and stores) would wait for the write acknowledgements too
+        if (DEC && xn && valid && k0 > 0) {
+#pragma unroll
+            for (int i = 0; i < G / 4; ++i) *(double2*)(xn + ((k0 - G) >> 1) + 2 * i) = double2{ydp[2 * i], ydp[2 * i + 1]};
+        }
+        if constexpr (!STAGED) {
+            request(slot, k0 + G * D < L ? k0 + G * D : k0);
+            asm volatile("" ::: "memory");      // (nothing but arithmetic follows in the trip: without this the request moves to the top of the NEXT trip)
+        }
         double yd[G / 2];
 #pragma unroll
         for (int u4 = 0; u4 < G; u4 += 4) {
@@ -606,24 +654,61 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
                 }
             }
         }
-        if (DEC && xn && valid) {
+        if (DEC) {
 #pragma unroll
-            for (int i = 0; i < G / 4; ++i) *(double2*)(xn + (k0 >> 1) + 2 * i) = double2{yd[2 * i], yd[2 * i + 1]};
+            for (int i = 0; i < G / 2; ++i) ydp[i] = yd[i];
         }
     };
-    request(std::integral_constant<int, 0>{}, 0);
-    if constexpr (D > 1) request(std::integral_constant<int, 1>{}, G);
-    if constexpr (D > 2) {
-        request(std::integral_constant<int, 2>{}, 2 * G);
-        request(std::integral_constant<int, 3>{}, 3 * G);
-    }
-    for (int k0 = 0; k0 < L; k0 += G * D) {
-        trip(std::integral_constant<int, 0>{}, k0);
-        if constexpr (D > 1) trip(std::integral_constant<int, 1>{}, k0 + G);
-        if constexpr (D > 2) {
-            trip(std::integral_constant<int, 2>{}, k0 + 2 * G);
-            trip(std::integral_constant<int, 3>{}, k0 + 3 * G);
+    if constexpr (STAGED) {
+        // The NEXT tile is copied while this one is filtered, global memory -> LDS without registers (global_load_lds_dwordx4: 64 lanes x
+        // 16 bytes land contiguously at M0): an instruction fills four rows, lane = 16 x (row of the four) + slot, and fetches piece
+        // slot ^ (row & 15) of its row — sixteen lanes read one chunk's 256 contiguous bytes, 8 cache lines per instruction instead
+        // of 64.  The column's wavefronts (wave_col of nw_col) deal the tile's sixteen instructions round-robin.  Issued from inline
+        // assembly (the compiler's wait counting does not see them): vmcnt(0) by hand in front of the barrier that ends a tile.
+        const int q0 = (bx - c * nblk) * CPW;
+        const char* xcol = (const char*)a.x + (long long)c * a.x_stride * ESZ;
+        const uint32_t lds_at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+        const int wave_col = __builtin_amdgcn_readfirstlane(tid_col >> 6), nw_col = __builtin_amdgcn_readfirstlane(nt_col >> 6);
+        auto fetch = [&](int t0, int buf) {
+            constexpr int LPR = Tile::kPieces, RPI = 64 / LPR;   // lanes per row, rows per instruction
+            for (int n = wave_col; n < kColRows / RPI; n += nw_col) {
+                const int row = RPI * n + lane / LPR, slot = lane % LPR;
+                const int qq = q0 + row < a.nchunks ? q0 + row : a.nchunks - 1;          // rows past the end shadow the last chunk
+                const char* src = xcol + ((long long)qq * L + t0) * ESZ + ((slot ^ (row & 15)) << 4);
+                const uint32_t dst = lds_at + buf * Tile::kBytes + n * 1024;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory", "m0");
+            }
+        };
+        fetch(0, 0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+        __syncthreads();
+        int buf = 0;
+        for (int t0 = 0; t0 < L; t0 += S, buf ^= 1) {
+            if (t0 + S < L) fetch(t0 + S, buf ^ 1);
+            tile_row = lds + buf * Tile::kBytes + lane * Tile::kRowBytes;
+            for (int k0 = t0; k0 < t0 + S; k0 += G) trip(std::integral_constant<int, 0>{}, k0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);                 // the next tile has landed (and this wavefront's stores have left)
+            __syncthreads();
         }
+    } else {
+        request(std::integral_constant<int, 0>{}, 0);
+        if constexpr (D > 1) request(std::integral_constant<int, 1>{}, G);
+        if constexpr (D > 2) {
+            request(std::integral_constant<int, 2>{}, 2 * G);
+            request(std::integral_constant<int, 3>{}, 3 * G);
+        }
+        for (int k0 = 0; k0 < L; k0 += G * D) {
+            trip(std::integral_constant<int, 0>{}, k0);
+            if constexpr (D > 1) trip(std::integral_constant<int, 1>{}, k0 + G);
+            if constexpr (D > 2) {
+                trip(std::integral_constant<int, 2>{}, k0 + 2 * G);
+                trip(std::integral_constant<int, 3>{}, k0 + 3 * G);
+            }
+        }
+    }
+    if (DEC && xn && valid) {
+#pragma unroll
+        for (int i = 0; i < G / 4; ++i) *(double2*)(xn + ((L - G) >> 1) + 2 * i) = double2{ydp[2 * i], ydp[2 * i + 1]};
     }
     if (valid && q == a.nchunks - 1) {                          // the stage's carried state: end of the channel's last chunk
 #pragma unroll
@@ -696,6 +781,7 @@ __device__ __forceinline__ void iir_lane_dec_pair_body(const IirStageArgs& a, in
         }
     };
     request(0);
+    double ydp[G / 2] = {};
     for (int k0 = 0; k0 < L; k0 += G) {
         double xg[G];
         if (F32) {
@@ -705,7 +791,14 @@ __device__ __forceinline__ void iir_lane_dec_pair_body(const IirStageArgs& a, in
 #pragma unroll
             for (int i = 0; i < 8; ++i) { xg[2 * i] = rd[i].x; xg[2 * i + 1] = rd[i].y; }
         }
-        if (k0 + G < L) request(k0 + G);
+#pragma unroll
+        for (int i = 0; i < G; ++i) asm volatile("" : "+v"(xg[i]));
+        if (xn && valid && is_a && k0 > 0) {              // the previous trip's outputs, in front of the request: see iir_lane_body
+#pragma unroll
+            for (int i = 0; i < G / 4; ++i) *(double2*)(xn + ((k0 - G) >> 1) + 2 * i) = double2{ydp[2 * i], ydp[2 * i + 1]};
+        }
+        request(k0 + G < L ? k0 + G : k0);              // unconditional, behind the conversions: see iir_lane_body
+        asm volatile("" ::: "memory");
         double yd[G / 2];
 #pragma unroll
         for (int t = 0; t < G; ++t) {
@@ -718,10 +811,12 @@ __device__ __forceinline__ void iir_lane_dec_pair_body(const IirStageArgs& a, in
             u[H - 1] = __builtin_fma(ca[H - 1], y, __builtin_fma(cb[H - 1], x, tail));
             if (!(t & 1)) yd[t / 2] = y;                                            // decimate.py:41: samples 0, 2, 4, ...
         }
-        if (xn && valid && is_a) {
 #pragma unroll
-            for (int i = 0; i < G / 4; ++i) *(double2*)(xn + (k0 >> 1) + 2 * i) = double2{yd[2 * i], yd[2 * i + 1]};
-        }
+        for (int i = 0; i < G / 2; ++i) ydp[i] = yd[i];
+    }
+    if (xn && valid && is_a) {
+#pragma unroll
+        for (int i = 0; i < G / 4; ++i) *(double2*)(xn + ((L - G) >> 1) + 2 * i) = double2{ydp[2 * i], ydp[2 * i + 1]};
     }
     if (valid && q == a.nchunks - 1) {
 #pragma unroll
@@ -755,6 +850,30 @@ __device__ __forceinline__ void iir_lane_wave(const IirStageArgs& a, int n_band,
         else iir_lane_body<1, 4, false, F32>(a, f0, bx, lane);
     } else {
         iir_lane_body<1, 12, true, F32>(a, a.dec_filter, bx, lane);
+    }
+}
+
+// The column form: a workgroup = `cols` chunk columns x every filter group of the launch (ngy wavefronts per column, at most
+// kColWaves in all); the wavefronts of a column share its staged sample tiles (iir_lane_body, STAGED).  Wavefronts past the
+// launch's last column shadow it and store nothing — every wavefront of a workgroup meets the same barriers.
+constexpr int kColWaves = 9;
+template <bool F32>
+__global__ void __launch_bounds__(kColWaves * 64) iir_lane_col_kernel(const IirStageArgs a, int n_band, int n_band_groups, int nbx, int ngy, int cols) {
+    extern __shared__ __attribute__((aligned(16))) char col_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wc = wave / ngy, g = wave - wc * ngy;
+    const long long col = (long long)blockIdx.x * cols + wc;
+    const bool live = col < nbx;
+    const int bx = live ? (int)col : nbx - 1;
+    char* lds = col_lds + (size_t)wc * 2 * ColTile<F32>::kBytes;
+    const int tid_col = g * 64 + lane, nt_col = ngy * 64;
+    if (g < n_band_groups) {
+        const int f0 = g * kLaneBands, left = n_band - f0;
+        if (left >= 3) iir_lane_body<3, 4, false, F32, 1, true>(a, f0, bx, lane, 3, lds, tid_col, nt_col, live);
+        else if (left == 2) iir_lane_body<2, 4, false, F32, 1, true>(a, f0, bx, lane, 2, lds, tid_col, nt_col, live);
+        else iir_lane_body<1, 4, false, F32, 1, true>(a, f0, bx, lane, 1, lds, tid_col, nt_col, live);
+    } else {
+        iir_lane_body<1, 12, true, F32, 1, true>(a, a.dec_filter, bx, lane, 1, lds, tid_col, nt_col, live);
     }
 }
 
@@ -810,6 +929,33 @@ static int launch_iir_lane(const IirStageArgs& a, int n_channels, hipStream_t st
     // the kernel takes its group from the launch's second axis: y < gb are band groups, the rest the decimator
     const int gy = which == kWhichAll ? groups + 1 : which == kWhichBands ? groups : 1;
     const int gb = which == kWhichDec ? 0 : groups;
+    // The column form (round 6): the filter groups of a chunk column in one workgroup, samples staged through LDS.
+    // Measured (profiles/r06_iir_lane_col.txt): it pays where the launch fills the chip and the column's wavefronts share enough samples
+    // — 8 ch x 216 bands (nine wavefronts per column) 123.6 / 68.7 / 38.7 / 23.3 -> 114.2 / 61.8 / 35.3 / 20.9 us at stages 0-3, 8 ch x 27
+    // bands (two per column) 120.0 / 71.1 / 37.9 -> 116.4 / 65.4 / 37.3 us at stages 0-2; with fewer workgroups than CUs a column's
+    // wavefronts crowd one CU while others idle (216 bands, stages 4-6: 16.2 / 11.7 / 10.6 -> 18.3 / 16.8 / 17.1 us).  Tiles of 64
+    // doubles instead of 32 (half the barriers, -DFRT_COL_F64_PIECES=32): equal at 216 bands, slower at 27 (two columns' 128 KB of LDS).
+    const int cols = gy <= 2 ? 2 : 1;                            // at least four wavefronts per workgroup while a column has two
+    const long long nwg = (bx + cols - 1) / cols;
+    const int col_forced = option(kOptIirLaneColumns);
+    const bool col_pays = nwg >= exp_int("FRT_LANE_COL_WGS", device_cu_count()) && (long long)gy * a.chunk >= exp_int("FRT_LANE_COL_SHARE", 512);
+    if (which == kWhichAll && gy <= kColWaves && bx < (1ll << 30) && (col_forced > 0 || (col_forced < 0 && col_pays))) {
+        static std::once_flag raised;                           // (handles may be driven from different threads)
+        static hipError_t raise_rc = hipSuccess;
+        std::call_once(raised, [] {
+            raise_rc = hipFuncSetAttribute((const void*)iir_lane_col_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (raise_rc == hipSuccess)
+                raise_rc = hipFuncSetAttribute((const void*)iir_lane_col_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+        FRT_HIP_CHECK(raise_rc);
+        size_t lds = (size_t)cols * 2 * (a.in_f32 ? ColTile<true>::kBytes : ColTile<false>::kBytes);
+        // a launch of at most one workgroup per CU: a reservation of more than half of the CU's LDS keeps a second one off it (see below)
+        if (nwg <= device_cu_count() && lds < (size_t)96 * 1024) lds = (size_t)96 * 1024;
+        if (a.in_f32) hipLaunchKernelGGL(iir_lane_col_kernel<true>, dim3((unsigned)nwg), dim3(cols * gy * 64), lds, stream, a, n_band, gb, (int)bx, gy, cols);
+        else hipLaunchKernelGGL(iir_lane_col_kernel<false>, dim3((unsigned)nwg), dim3(cols * gy * 64), lds, stream, a, n_band, gb, (int)bx, gy, cols);
+        FRT_HIP_CHECK(hipGetLastError());
+        return FRT_OK;
+    }
     // Few wavefronts (at most one per CU in the form above: the low-rate stages, calls of a few channels): the lane-split form — a band
     // filter per lane on three lanes of a chunk, the decimator on a pair — has three / two times the wavefronts with a third / two
     // thirds of the dependent float64 instructions per sample each (iir_lane_split_kernel).  Measured (profiles/r05_iir_lane_split.txt),

@@ -23,7 +23,7 @@ struct Options {                                   // every option starts at -1 
     Options() { for (auto& o : v) o.store(-1, std::memory_order_relaxed); }
     std::atomic<int>& operator[](int o) { return v[o]; }
 } g_options;
-const char* const kOptionNames[kOptCount] = {"gcc_one_workgroup", "gcc_any_length", "ola_chunk_kernels", "pitch_grid_two_pass", "ola_defer", "iir_lookback", "gcc_resident"};
+const char* const kOptionNames[kOptCount] = {"gcc_one_workgroup", "gcc_any_length", "ola_chunk_kernels", "pitch_grid_two_pass", "ola_defer", "iir_lookback", "gcc_resident", "iir_lane_columns"};
 std::mutex g_retired_mutex;
 std::vector<void*> g_retired;
 size_t g_retired_bytes = 0;

@@ -58,6 +58,9 @@ int frt_is_device_pointer(const void* p);
  *                          stage's own launch instead of one deferred launch over the low-rate stages
  *   "iir_lookback"         frt_octbank_energies (mode 0, time-parallel): 0 = every stage's chunk start states from a scan launch
  *                          instead of the output pass's own look-back over its predecessors' end states at the high-rate stages
+ *   "iir_lane_columns"     frt_octbank_energies (mode 0, time-parallel): the output pass with the filter groups of 64 chunks in one
+ *                          workgroup and their samples staged through LDS — 1 = at every stage it serves, 0 = at none (default:
+ *                          where the launch has a workgroup per compute unit and the groups share enough samples)
  *   "gcc_any_length"       frt_gcc_create: 1 = the chirp-z transform also for lengths the mixed-radix plan serves
  *   "ola_chunk_kernels"    frt_octbank_filter (mode 1, one block of <= 1024 host samples): 0 = per-stage transform launches
  *                          instead of the two running-convolution launches

@@ -56,7 +56,7 @@ def test_path_selection_options_need_no_gpu_and_reject_unknown_names(lib):
     """frt_set_option / frt_get_option (the library never reads the environment): the documented names round-trip, a
     negative value restores the shape rule (-1), anything else is FRT_ERR_INVALID with a message."""
     from friture_amd import _lib
-    for name in ("gcc_one_workgroup", "gcc_any_length", "ola_chunk_kernels", "pitch_grid_two_pass", "gcc_resident", "iir_lookback", "ola_defer"):
+    for name in ("gcc_one_workgroup", "gcc_any_length", "ola_chunk_kernels", "pitch_grid_two_pass", "gcc_resident", "iir_lookback", "ola_defer", "iir_lane_columns"):
         assert _lib.get_option(name) == -1
         _lib.set_option(name, 1)
         assert _lib.get_option(name) == 1

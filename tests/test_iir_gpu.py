@@ -494,3 +494,28 @@ def test_look_back_output_pass_equals_the_scan_launches(tabs, option, bpo, chunk
     a, b = outs[-1], outs[0]
     assert a.shape == (C, 3 * nblocks, 9 * bpo)
     assert np.all(np.abs(a - b) <= 1e-9 * np.abs(b) + 1e-14 * b.max()), float(np.max(np.abs(a - b) / (np.abs(b) + 1e-14 * b.max())))
+
+
+@pytest.mark.parametrize("bpo,chunk,nblocks,C", [(3, 1024, 96, 2), (3, 512, 67, 3), (24, 512, 64, 2), (6, 256, 33, 1), (12, 1024, 16, 5), (1, 256, 9, 3)])
+def test_column_form_of_the_output_pass_equals_the_lane_per_wavefront_form(tabs, option, bpo, chunk, nblocks, C):
+    """Round 6: the output pass with every filter group of 64 chunks in ONE workgroup, the samples copied global -> LDS (LDS-DMA,
+    swizzled rows) once per column instead of requested lane by lane by every group (csrc/iir.hip, iir_lane_col_kernel).  The
+    recurrences are the same instructions on the same values: the energies of three consecutive calls (carried states; column counts
+    that leave a workgroup's second column empty, a last column of fewer than 64 chunks, 1 .. 9 wavefronts per column) are BIT-IDENTICAL
+    to the form it replaces, which the oracle comparisons above hold to 1e-5."""
+    import torch
+    from friture_amd.filter import IirBank
+    boct, aoct = list(tabs[f"boct_{bpo}"]), list(tabs[f"aoct_{bpo}"])
+    n = 1024 * nblocks
+    x32 = np.stack([synth("noise" if c % 2 == 0 else "chirp", 3 * n, 41 + c) for c in range(C)])
+    alphas, _ = dsp.band_smoothing_setup(bpo, 0.125)
+    xd = torch.from_numpy(x32).cuda()
+    outs = {}
+    for cols in (1, 0):
+        option("iir_lane_columns", cols)
+        bank = IirBank(tabs["bdec"], tabs["adec"], boct, aoct, C)
+        bank.set_chunk(chunk)
+        outs[cols] = torch.cat([bank.energies(xd[:, i * n:(i + 1) * n].contiguous(), 1024, alphas) for i in range(3)], dim=1).cpu().numpy()
+    assert outs[1].shape == (C, 3 * nblocks, 9 * bpo)
+    assert np.isfinite(outs[1]).all() and outs[1].max() > 0
+    assert np.array_equal(outs[1], outs[0]), float(np.max(np.abs(outs[1].astype(np.float64) - outs[0]) / (np.abs(outs[0]) + 1e-30)))

@@ -3,6 +3,9 @@ import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__fil
 import numpy as np, torch, time
 from friture_amd import _lib, filter_design
 from friture_amd.filter import IirBank
+from pathlib import Path
+if os.environ.get('FRT_LIB_VARIANT'):
+    _lib.LIB_PATH = Path(__file__).resolve().parents[1] / 'variants' / os.environ['FRT_LIB_VARIANT'] / 'libfriture_hip.so'
 _lib.init(0)
 t = filter_design.load_tables()
 for bpo, C, n in ((3, 8, 1 << 22), (24, 8, 1 << 20)):
