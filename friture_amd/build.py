@@ -30,7 +30,10 @@ CXXFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-W
 # order (no fused multiply-add contraction) so that it can be bit-identical to lfilter.py:131-139
 # stft.hip: packed fp32 VALU instructions (v_pk_fma_f32 ...) issue slower than the scalar pair they
 # replace on gfx950 (measured: +7 % kernel time), so SLP packing of the butterflies is off
-EXTRA_FLAGS = {"iir.hip": ["-ffp-contract=off"], "pipeline.hip": ["-ffp-contract=off"], "pitch.hip": ["-ffp-contract=off"],
+# iir.hip, -amdgpu-mfma-vgpr-form: the float64 MFMA accumulators of iir_zero_state_mfma_kernel in vector registers — without it the
+# compiler keeps them in accumulation registers inside the loop and in vector registers across its back-edge: 16 v_accvgpr_write at
+# the top and 16 v_accvgpr_read (+ s_nop 8) at the bottom of every trip of 16 MFMAs (profiles/r06_iir_zero_state_pipeline.txt: -3 .. -6 us per call)
+EXTRA_FLAGS = {"iir.hip": ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"], "pipeline.hip": ["-ffp-contract=off"], "pitch.hip": ["-ffp-contract=off"],
                "specgram.hip": ["-ffp-contract=off"],
                "stft.hip": ["-fno-slp-vectorize", "-Wno-inline-asm"]}
 

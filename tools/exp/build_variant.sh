@@ -10,7 +10,8 @@ mkdir -p $D
 EXTRA=""
 case $SRC in
   stft.hip) EXTRA="-fno-slp-vectorize -Wno-inline-asm";;
-  iir.hip|pipeline.hip|pitch.hip|specgram.hip) EXTRA="-ffp-contract=off";;
+  iir.hip) EXTRA="-ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form";;
+  pipeline.hip|pitch.hip|specgram.hip) EXTRA="-ffp-contract=off";;
 esac
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DFRT_EXPERIMENTS -I$R/include $EXTRA "$@" -c $R/friture_amd/csrc/$SRC -o $D/${SRC%.hip}.o
 OBJS=$(ls $R/friture_amd/lib/obj/*.o | grep -v "/${SRC%.hip}.o")
