@@ -91,6 +91,10 @@ __global__ void __launch_bounds__(Pk16Plan::BLOCK, 2) stft_pk16_kernel(const Stf
     // unpack: thread t owns the bins k = 4 t + c (c < 4), k + 4096 and the mirrors M - k, 4096 - k: four 16-byte stores
 #pragma unroll
     for (int c = 0; c < 4; ++c) twur[c] = twn[4 * t + c];
+    // the twiddle of the self-mirrored pair (M/4, 3M/4), thread 0's: read HERE.  Read inside the frame loop (round 4 .. 6), its use was a
+    // vmcnt(0) in wave 0 behind the frame's four row stores — a wait for their write acknowledgements (and the next frame's sample copy)
+    // that the other seven wavefronts then spent at barrier A, every frame
+    const pk2 tw_quarter = twn[M / 4];
     float wg_q[2] = {0.f, 0.f};                                     // thread 0: bins 2048 and 6144
     if constexpr (KIND != 0) {
 #pragma unroll
@@ -325,7 +329,7 @@ __global__ void __launch_bounds__(Pk16Plan::BLOCK, 2) stft_pk16_kernel(const Stf
             // the pair (2048, 6144) is its own mirror image: Z[2048] = T0 + T1, Z[6144] = T0 - T1 of region 0, r + 16 w = 128
             const pk2 q0 = lds_rd(sm + 128 * 8), q1 = lds_rd(sm + (128 + 256) * 8);
             float pw[4];
-            pair_powers2(q0 + q1, q0 - q1, twn[M / 4], q0 + q1, q0 - q1, twn[M / 4], pw);
+            pair_powers2(q0 + q1, q0 - q1, tw_quarter, q0 + q1, q0 - q1, tw_quarter, pw);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int kk = e == 0 ? M / 4 : 3 * M / 4;
