@@ -487,34 +487,48 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
             const double* ends = a.chunk_end + ((size_t)c * a.nfilt + f) * a.nchunks * kStates;
             const double* carried = a.state_in + ((size_t)c * a.nfilt + f) * kStates;
             unsigned long long pw_at = (unsigned long long)(uintptr_t)(a.power_l + (size_t)f * kStates * kStates);
-            auto end_state = [&](int i, double (&e)[ORD]) {       // e[i]: chunk i's zero-state end state; the carried state for i = -1
+            // e[i]: chunk i's zero-state end state; the carried state for i = -1; zero in front of that.  The loads are unconditional (a
+            // lane in front of the channel's first chunk reads the carried state and zeroes it when it USES it) and the next step's
+            // request is pinned in front of this step's product: behind `if (k > 1)` and a per-lane `i >= -1 ? load : 0` every request was
+            // awaited where it was issued (the merge copies again) — a memory round trip per Horner step, most of the 1.4-1.9 us a
+            // step cost (192 multiply-adds are ~0.5 us).
+            auto request_end = [&](int i, double (&e)[ORD]) {
                 const double* src = i >= 0 ? ends + (size_t)i * chunk_state_stride(ORD) : carried;
 #pragma unroll
                 for (int t = 0; t < ORD; t += 2) {
-                    const double2 v = i >= -1 ? *(const double2*)(src + t) : double2{0.0, 0.0};
+                    const double2 v = *(const double2*)(src + t);
                     e[t] = v.x;
                     e[t + 1] = v.y;
                 }
             };
             double zz[ORD], en[ORD];
-            end_state(qc - a.lookback, zz);
-            if (a.lookback > 1) end_state(qc - a.lookback + 1, en);
+            request_end(qc - a.lookback, zz);
+            request_end(qc - a.lookback + (a.lookback > 1 ? 1 : 0), en);
+            {
+                const bool none = qc - a.lookback < -1;
+#pragma unroll
+                for (int t = 0; t < ORD; ++t) zz[t] = none ? 0.0 : zz[t];
+            }
             for (int k = a.lookback - 1; k >= 1; --k) {
                 double e[ORD];
+                const bool none = qc - k < -1;
 #pragma unroll
-                for (int t = 0; t < ORD; ++t) e[t] = en[t];
-                if (k > 1) end_state(qc - k + 1, en);             // the next step's end state is on its way during this product
+                for (int t = 0; t < ORD; ++t) {
+                    e[t] = none ? 0.0 : en[t];
+                    asm volatile("" : "+v"(e[t]));
+                }
+                request_end(qc - (k > 1 ? k : 2) + 1, en);        // the next step's end state travels during this product (the last step re-reads)
+                asm volatile("" ::: "memory");
                 // (the table's address as a value made in this trip: hoisted out of the loop its ORD x ORD entries — 288 scalar
                 // registers for the decimator — are spilled into vector-register lanes, the pass's coefficients with them)
                 asm volatile("" : "+s"(pw_at));
                 const ktable pw = (ktable)pw_at;
+                // column by column: ORD independent accumulations per column (row by row each row is one dependent chain of ORD
+                // multiply-adds, and a lone wavefront waits out every one of them)
 #pragma unroll
-                for (int r = 0; r < ORD; ++r) {
-                    double sum = e[r];
+                for (int t = 0; t < ORD; ++t)
 #pragma unroll
-                    for (int t = 0; t < ORD; ++t) sum = __builtin_fma(pw[r * kStates + t], zz[t], sum);
-                    e[r] = sum;
-                }
+                    for (int r = 0; r < ORD; ++r) e[r] = __builtin_fma(pw[r * kStates + t], zz[t], e[r]);
 #pragma unroll
                 for (int t = 0; t < ORD; ++t) zz[t] = e[t];
             }
@@ -1023,7 +1037,7 @@ static_assert(kZsRows % kZsRowsPerPass == 0, "row groups tile the padded table")
 #endif
 constexpr int kMaxSlices = 8;
 #ifndef FRT_IIR_LOOKBACK_MAX
-#define FRT_IIR_LOOKBACK_MAX 8
+#define FRT_IIR_LOOKBACK_MAX 16
 #endif
 constexpr int kLookbackMax = FRT_IIR_LOOKBACK_MAX;      // chunks an output pass looks back over instead of waiting for a scan launch
 
@@ -2177,7 +2191,11 @@ static int run_stages(frt_octbank* h, const void* d_x, int in_f32, long long x_s
             // The look-back form of the output pass (no scan launch) while the decay spans few chunks.  Measured (profiles/r06_iir_lookback.txt,
             // 8 ch x 27 bands, chunks of 1024): stage 0 (K = 6) output pass 135 -> 142 us for a scan launch of 19 us less; stage 1 (K = 13)
             // 65 -> 88 us for 15 us less — a Horner step costs a lane 1.4-1.9 us (192 multiply-adds fed through the scalar cache) against
-            // 0.3 us in the scan's DPP rows: it pays up to K = 8 only.
+            // 0.3 us in the scan's DPP rows: it paid up to K = 8 only.  Later in round 6 (profiles/r06_iir_lookback.txt, second part): most of
+            // a step's time was a memory round trip — every step's request of the next end state was awaited where it was issued — and
+            // the product walked one dependent chain per row; with the request pinned in front of a column-by-column product a step is
+            // ~0.9 us: stage 0 (K = 6) 16 + 109 -> 116 us, stage 1 (K = 13) 12 + 62 -> 73 us (even), 216 bands' stage 0 (K = 12) 19 + 115
+            // -> 127 us; K = 25 still loses (18 + 36 -> 60 us).  Up to K = 16.
             static const int look_max = exp_int("FRT_IIR_LOOKBACK_MAX", kLookbackMax);
             const bool look = lane_serves && !beside && !h->zero_state_by_recurrence && !use_vector_alu && h->slook[j] <= look_max && option(kOptIirLookback) != 0 &&
                               !lane_split_serves(a, h->n_channels, kWhichAll);
