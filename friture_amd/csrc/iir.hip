@@ -571,6 +571,7 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
     double* xn = DEC && a.xnext ? a.xnext + (long long)c * a.xnext_stride + (s0 >> 1) : nullptr;
     const int elen = a.eblock_len;
     const bool energy = !DEC && a.eblock != nullptr;
+    const bool big_blocks = !energy || elen >= 16;              // (uniform)
     constexpr bool f32 = F32;
 
     // Sixteen samples per trip (chunks are multiples of 64) — one 64-byte (float) or 128-byte (double) piece of the lane's own
@@ -587,16 +588,23 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
     typedef ColTile<F32> Tile;
     constexpr int S = Tile::kSamples, ESZ = F32 ? 4 : 8;       // (staged) samples of a tile row, bytes of a sample
     const char* tile_row = lds + lane * Tile::kRowBytes;        // (staged) this lane's row of the tile being filtered
+    constexpr int NI = F32 ? 4 : 8;                              // (staged) 16-byte pieces of a trip
+    int soff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) soff[i] = (i ^ (lane & (NI - 1))) << 4;
+    const int sbase = (lane & 15 & ~(NI - 1)) << 4;
     auto request = [&](auto slot, int k) {
         constexpr int d = decltype(slot)::value;
         if constexpr (STAGED) {
-            const int pj = (k & (S - 1)) * ESZ / 16, sw = lane & 15;
+            // piece pj + i (pj a multiple of NI) sits in slot (pj + i) ^ sw = (pj ^ (sw & ~(NI - 1))) | (i ^ (sw & (NI - 1))): the second
+            // term is the lane's own for the whole pass (soff), the first one XOR per trip
+            const char* src = tile_row + ((((k & (S - 1)) * ESZ)) ^ sbase);
             if (f32) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rf[d][i] = *(const float4*)(tile_row + (((pj + i) ^ sw) << 4));
+                for (int i = 0; i < 4; ++i) rf[d][i] = *(const float4*)(src + soff[i]);
             } else {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) rd[d][i] = *(const double2*)(tile_row + (((pj + i) ^ sw) << 4));
+                for (int i = 0; i < 8; ++i) rd[d][i] = *(const double2*)(src + soff[i]);
             }
         } else if (f32) {
 #pragma unroll
@@ -606,8 +614,11 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
             for (int i = 0; i < 8; ++i) rd[d][i] = *(const double2*)(xd + k + 2 * i);
         }
     };
-    auto trip = [&](auto slot, int k0) {
+    // bigc: the energy blocks are whole trips (>= 16 samples: every stage but the lowest rates) — a block begins and ends only where a
+    // trip does, and the per-group tests (eight scalar compare-and-branch pairs per trip, issue slots of a lone wavefront) are gone
+    auto trip = [&](auto slot, auto bigc, int k0) {
         constexpr int d = decltype(slot)::value;
+        constexpr bool BIG = decltype(bigc)::value;
         double xg[G];
         if constexpr (STAGED) request(slot, k0);                 // an LDS read: ~100 cycles in front of ~3000 of arithmetic
         if (f32) {
@@ -638,7 +649,7 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
 #pragma unroll
         for (int u4 = 0; u4 < G; u4 += 4) {
             const int k = k0 + u4;
-            if (energy && (k & (elen - 1)) == 0) {
+            if (energy && (BIG ? (u4 == 0 && (k0 & (elen - 1)) == 0) : (k & (elen - 1)) == 0)) {
 #pragma unroll
                 for (int m = 0; m < NF; ++m) acc[m] = 0.0;
             }
@@ -655,7 +666,7 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
                     else if (!(u & 1)) yd[(u4 + u) / 2] = y;                  // decimate.py:41: samples 0, 2, 4, ...
                 }
             }
-            if (energy && ((k + 4) & (elen - 1)) == 0 && valid) {
+            if (energy && (BIG ? (u4 == G - 4 && ((k0 + G) & (elen - 1)) == 0) : ((k + 4) & (elen - 1)) == 0) && valid) {
                 const long long blk = ((s0 + k) >> a.eblock_shift) * a.eblock_mul;      // first entry of the block axis this block spans
 #pragma unroll
                 for (int m = 0; m < NF; ++m) {
@@ -700,7 +711,8 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
         for (int t0 = 0; t0 < L; t0 += S, buf ^= 1) {
             if (t0 + S < L) fetch(t0 + S, buf ^ 1);
             tile_row = lds + buf * Tile::kBytes + lane * Tile::kRowBytes;
-            for (int k0 = t0; k0 < t0 + S; k0 += G) trip(std::integral_constant<int, 0>{}, k0);
+            if (big_blocks) for (int k0 = t0; k0 < t0 + S; k0 += G) trip(std::integral_constant<int, 0>{}, std::true_type{}, k0);
+            else for (int k0 = t0; k0 < t0 + S; k0 += G) trip(std::integral_constant<int, 0>{}, std::false_type{}, k0);
             __builtin_amdgcn_s_waitcnt(0x0F70);                 // the next tile has landed (and this wavefront's stores have left)
             __syncthreads();
         }
@@ -711,14 +723,18 @@ __device__ __forceinline__ void iir_lane_body(const IirStageArgs& a, int f0_grou
             request(std::integral_constant<int, 2>{}, 2 * G);
             request(std::integral_constant<int, 3>{}, 3 * G);
         }
-        for (int k0 = 0; k0 < L; k0 += G * D) {
-            trip(std::integral_constant<int, 0>{}, k0);
-            if constexpr (D > 1) trip(std::integral_constant<int, 1>{}, k0 + G);
-            if constexpr (D > 2) {
-                trip(std::integral_constant<int, 2>{}, k0 + 2 * G);
-                trip(std::integral_constant<int, 3>{}, k0 + 3 * G);
+        auto walk = [&](auto bigc) {
+            for (int k0 = 0; k0 < L; k0 += G * D) {
+                trip(std::integral_constant<int, 0>{}, bigc, k0);
+                if constexpr (D > 1) trip(std::integral_constant<int, 1>{}, bigc, k0 + G);
+                if constexpr (D > 2) {
+                    trip(std::integral_constant<int, 2>{}, bigc, k0 + 2 * G);
+                    trip(std::integral_constant<int, 3>{}, bigc, k0 + 3 * G);
+                }
             }
-        }
+        };
+        if (big_blocks) walk(std::true_type{});
+        else walk(std::false_type{});
     }
     if (DEC && xn && valid) {
 #pragma unroll
