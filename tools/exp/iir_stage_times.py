@@ -34,6 +34,9 @@ import os
 if os.environ.get("FRT_LIB_VARIANT"):      # A/B runs: a variant library built by tools/exp/build_variant.sh
     _lib.LIB_PATH = ROOT / "tools" / "variants" / os.environ["FRT_LIB_VARIANT"] / "libfriture_hip.so"
 _lib.init(0)
+for kv in os.environ.get("FRT_OPTIONS", "").split():      # product options for A/B runs: FRT_OPTIONS="iir_lane_columns=0 iir_lookback=0"
+    name, value = kv.split("=")
+    _lib.set_option(name, int(value))
 dev = torch.device("cuda", 0)
 t = filter_design.load_tables()
 n = 1 << log2n
